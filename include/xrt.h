@@ -1,0 +1,259 @@
+/*
+ * xrt.h — C-ABI of libxrt, the MI355X (gfx950) ray / octree / triangle hot path that drops in
+ * behind the xna-ray-trace C# host (P/Invoke), see INTEGRATION.md.
+ *
+ * Every entry point names the reference interface it replaces (file:line relative to the reference
+ * repository; aliases: RT = RayTraceProject/RayTraceProject/RayTracer.cs,
+ * OSM = RayTraceProject/RayTraceProject/Spatial/OctreeSpatialManager.cs,
+ * ISM = .../Spatial/ISpatialManager.cs, SO = .../SceneObject.cs, MO = RayTracerTypeLibrary/MeshOctree.cs,
+ * MESH = RayTracerTypeLibrary/Mesh.cs, MAT = RayTracerTypeLibrary/Material.cs,
+ * TRI = RayTracerTypeLibrary/Triangle.cs, SPOT/DIR = .../SpotLight.cs / DirectionalLight.cs).
+ *
+ * Conventions
+ *   - plain C, cdecl, POD structs with natural alignment, no C++ or torch types;
+ *   - every function returns int: XRT_OK (0) or a negative XRT_E_* code; xrt_last_error() gives the
+ *     thread-local message (precedent for the style: aviFileWrapper_src/Avi.cs:175-185 int HRESULTs);
+ *   - all host arrays are borrowed for the duration of the call and copied; the library owns all
+ *     device memory; handles are opaque;
+ *   - matrices are XNA row-vector convention (v' = v * M), 16 floats M11,M12,...,M44.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point returns
+ *     XRT_E_NO_DEVICE.
+ */
+#ifndef XRT_H
+#define XRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XRT_VERSION 100
+
+/* error codes (C# shim: BUSY -> InvalidOperationException (RT:26-27,62-63),
+ * INVALID_ARG -> ArgumentException (SO:123-124, MAT:85,97)) */
+#define XRT_OK              0
+#define XRT_E_INVALID_ARG  -1
+#define XRT_E_BUSY         -2
+#define XRT_E_NO_DEVICE    -3
+#define XRT_E_OOM          -4
+#define XRT_E_HIP          -5
+#define XRT_E_RCCL         -6
+#define XRT_E_INTERNAL     -7
+#define XRT_E_UNSUPPORTED  -8
+#define XRT_E_NOT_BUILT    -9
+
+/* enums mirror MAT:12-23 */
+#define XRT_FILTER_POINT     0
+#define XRT_FILTER_BILINEAR  1
+#define XRT_ADDRESS_CLAMP    0
+#define XRT_ADDRESS_WRAP     1
+#define XRT_ADDRESS_MIRROR   2
+
+#define XRT_LIGHT_SPOT         0   /* SPOT: IsPositionable == true  */
+#define XRT_LIGHT_DIRECTIONAL  1   /* DIR:  IsPositionable == false */
+
+/* multisampling modes of xrt_render_opts.use_multisampling */
+#define XRT_MS_OFF       0   /* RT:103-126 RenderInternal                                       */
+#define XRT_MS_ADAPTIVE  1   /* RT:128-168,170-311 RenderInternalWithMultisampling (faithful)   */
+#define XRT_MS_FIXED16   2   /* the 16 level-1 positions of RT:218-305, mean of 4 means of 4    */
+
+typedef struct xrt_scene xrt_scene;   /* replaces an OctreeSpatialManager + its SceneObjects (OSM:35, SO:12) */
+
+/* Ray of one ISpatialManager.GetRayIntersection query (ISM:15): Ray{Position,Direction} + the
+ * `ignoreTriangle` reference identity expressed as (mesh id, index in Mesh.Triangles[]) — instances
+ * of one Model share Triangle objects, so the pair is instance independent (SO:126-127, MO:290).
+ * ignore_tri < 0 means null. 32 bytes. */
+typedef struct xrt_ray {
+    float   o[3];
+    float   d[3];
+    int32_t ignore_mesh;
+    int32_t ignore_tri;
+} xrt_ray;
+
+/* IntersectionResult (OSM:11-33) with object / mesh / triangle references turned into indices.
+ * tri  = position in Mesh.Triangles[];
+ * leaf = DFS pre-order index (root = 0, children in 4i+2j+k order, MO:210-222) of the MeshOctree
+ *        leaf in which the winning strict-'<' test happened (MO:294);
+ * d    = OBJECT-space distance (OSM:373,450); w = worldPosition (OSM:443). 48 bytes. */
+typedef struct xrt_hit {
+    int32_t hit;
+    int32_t object;
+    int32_t mesh;
+    int32_t tri;
+    int32_t leaf;
+    float   u, v, d;
+    float   wx, wy, wz;
+    int32_t reserved;
+} xrt_hit;
+
+/* Material (MAT:25-69, 234-268). tex_argb = the locked Format32bppArgb bitmap (MAT:65): row-major,
+ * top-down, 0xAARRGGBB, tex_width*tex_height words; may be NULL when use_texture == 0. */
+typedef struct xrt_material {
+    float           reflectiveness;
+    int32_t         transparent;
+    float           refraction_index;
+    int32_t         interpolate_normals;
+    int32_t         use_texture;
+    int32_t         tex_width;
+    int32_t         tex_height;
+    int32_t         reserved;
+    const uint32_t *tex_argb;
+} xrt_material;
+
+/* Inputs of RayTracer.Render ray generation (RT:395-397): Camera.View, Camera.Projection and the
+ * GraphicsDevice.Viewport. */
+typedef struct xrt_camera {
+    float   view[16];
+    float   proj[16];
+    int32_t vp_x, vp_y, vp_width, vp_height;
+    float   vp_min_depth, vp_max_depth;
+} xrt_camera;
+
+/* ILight (ILight.cs:9-15) — SpotLight (SPOT:12-35) or DirectionalLight (DIR:10-20). */
+typedef struct xrt_light {
+    int32_t kind;
+    float   position[3];
+    float   direction[3];
+    float   color[3];
+    float   intensity;
+    float   spot_angle;       /* SPOT:19-27, radians */
+    float   decay_exponent;   /* SPOT:33, default 1.3f */
+} xrt_light;
+
+/* The RayTracer properties a frame reads (RT:19-41) + the image-tile shard of this process. */
+typedef struct xrt_render_opts {
+    int32_t max_reflections;      /* RT:33  */
+    int32_t use_multisampling;    /* RT:40, XRT_MS_* */
+    int32_t multisample_quality;  /* RT:41  */
+    int32_t address_mode;         /* RT:37, XRT_ADDRESS_* */
+    int32_t filtering;            /* RT:36, XRT_FILTER_*  */
+    int32_t shard_rank;           /* image-tile shard: this process renders tiles t with t % shard_count == shard_rank */
+    int32_t shard_count;          /* 0 or 1 = whole frame */
+    int32_t collect_stats;        /* 1: also run the (untimed) reference-work counting pass */
+} xrt_render_opts;
+
+/* Exact work counters of the REFERENCE algorithm for the rays of one call and the
+ * measured kernel times. Counts are those of the C# code path, not of the pruned GPU traversal. */
+typedef struct xrt_stats {
+    uint64_t rays_closest;        /* CastRay queries, RT:512 */
+    uint64_t rays_shadow;         /* IsLightPathObstructed queries, RT:485 */
+    uint64_t hits_closest;
+    uint64_t hits_shadow;
+    uint64_t scene_node_tests;    /* OSM:460 slab tests */
+    uint64_t instance_visits;     /* OSM:349-364 ray transforms */
+    uint64_t mesh_aabb_tests;     /* MESH:37 */
+    uint64_t mesh_queries;        /* MO:259 calls */
+    uint64_t node_tests;          /* MO:331 slab tests */
+    uint64_t leaf_refs;           /* MO:288 loop iterations in visited buckets */
+    uint64_t tri_tests;           /* RE:42 calls */
+    uint64_t shaded_hits;
+    uint64_t pixels;
+    uint64_t algorithmic_bytes;   /* SURVEY §8d formula over the counters above */
+    double   ms_total;            /* device time of the whole call */
+    double   ms_intersect;        /* summed durations of the traversal kernel launches (HIP events) */
+    uint32_t intersect_launches;
+    uint32_t reserved;
+} xrt_stats;
+
+/* Flattened octree node for inspection by tests (mirrors the private CubeNode, MO:32-40 / OSM:37-48). */
+typedef struct xrt_node_info {
+    float   bmin[3];
+    float   bmax[3];
+    int32_t is_leaf;
+    int32_t count;        /* containingObjects.Count */
+    int32_t dfs_index;    /* pre-order index */
+    int32_t depth;
+    int32_t first_ref;    /* offset of this node's list in the ref array returned next to it (leaves only) */
+    int32_t reserved;
+} xrt_node_info;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int         xrt_version(void);
+const char *xrt_last_error(void);                      /* thread-local, never NULL */
+int         xrt_device_count(int *count_out);          /* number of HIP devices visible */
+
+/* ---- scene upload: replaces SceneObject / Mesh / Triangle / Material graphs (SO:117-134,
+ *      MESH:17-32, TRI:14-25, MAT:45-69) -------------------------------------------------------- */
+int xrt_scene_create(int device, xrt_scene **scene_out);
+int xrt_scene_destroy(xrt_scene *scene);
+
+/* One Mesh (MESH:9-40). v,n: ntri*9 floats (v1,v2,v3 / n1,n2,n3), uv: ntri*6, surf_n: ntri*3
+ * (Triangle.surfaceNormal, TMP:199-203), color: ntri*4 (Triangle.color), bbox: Mesh.MeshBoundingBox
+ * min xyz max xyz (TMP:244-307). */
+int xrt_scene_add_mesh(xrt_scene *scene, const float *v, const float *n, const float *uv,
+                       const float *surf_n, const float *color, int32_t ntri,
+                       const xrt_material *material, const float bbox[6], int32_t *mesh_id_out);
+
+/* One SceneObject (SO:12): its shared mesh list (SO:126-127), World / InverseWorld (SO:183-199),
+ * BoundingBox (SO:131) and the un-normalised WorldBoundingBox (SO:195-196). */
+int xrt_scene_add_object(xrt_scene *scene, const int32_t *mesh_ids, int32_t n_meshes,
+                         const float world[16], const float inv_world[16],
+                         const float bbox[6], const float world_bbox[6], int32_t *object_id_out);
+
+/* Mesh.Init -> MeshOctree.Build for every mesh (MESH:27-32, MO:56-96, 204-236; threshold MO:42) and
+ * OctreeSpatialManager.Build (OSM:64-113, 218-248; threshold OSM:50); then uploads to HBM.
+ * Pass 0 for the reference defaults (50 / 20). */
+int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_threshold);
+
+/* Inspection of the built trees (test support). mesh_id >= 0: that mesh's MeshOctree; mesh_id == -1:
+ * the scene octree (refs are object ids). Call with NULL arrays to get the counts. Nodes are returned
+ * in DFS pre-order. */
+int xrt_scene_get_tree(const xrt_scene *scene, int32_t mesh_id, xrt_node_info *nodes,
+                       int64_t *n_nodes_inout, int32_t *refs, int64_t *n_refs_inout);
+
+/* ---- seam 1: ISpatialManager.GetRayIntersection (ISM:15 = OSM:312-455), batched --------------
+ * ignore_object (nullable, n entries) is the dead `Mesh ignoreObject` parameter (OSM:343 compares a
+ * Mesh with an ISpatialBody and can never be equal); it is accepted and ignored. Host buffers. */
+int xrt_scene_intersect(xrt_scene *scene, const xrt_ray *rays, const int32_t *ignore_object,
+                        int64_t n, xrt_hit *hits_out, xrt_stats *stats_out /* nullable */);
+
+/* Same with device pointers (HBM resident rays / hits), asynchronous on `stream` (a hipStream_t,
+ * NULL = default stream). Nothing is copied; the caller synchronises. */
+int xrt_scene_intersect_device(xrt_scene *scene, const void *d_rays, int64_t n, void *d_hits_out,
+                               void *stream);
+
+/* MeshOctree.GetRayIntersection of one mesh in object space (MO:259-326); hit.object = -1,
+ * w = objectSpacePosition (MO:310-312). */
+int xrt_mesh_intersect(xrt_scene *scene, int32_t mesh_id, const xrt_ray *rays, int64_t n,
+                       xrt_hit *hits_out);
+
+/* ---- seam 2: RayTracer.RenderInternal (RT:103-126) / RenderInternalWithMultisampling
+ *      (RT:128-168) -------------------------------------------------------------------------------
+ * Fills rgba_out[y*W + x] with the packed XNA Color (R in the low byte, RT:425). Blocking.
+ * rgb_f32_out (nullable, W*H*3) receives the iteration-0 colorVector before packing (RT:705/726).
+ * A second concurrent call on the same scene returns XRT_E_BUSY (RT:62-63). */
+int xrt_render(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights, int32_t n_lights,
+               const xrt_render_opts *opts, uint32_t *rgba_out, float *rgb_f32_out,
+               xrt_stats *stats_out /* nullable */);
+
+/* Same, writing to device memory. With opts->shard_count > 1 only this rank's tiles are rendered and
+ * d_rgba_out receives them contiguously, tile after tile (see xrt_shard_layout); otherwise the full
+ * W*H frame. The call enqueues on `stream` and synchronises it before returning (stats need it). */
+int xrt_render_device(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights,
+                      int32_t n_lights, const xrt_render_opts *opts, void *d_rgba_out,
+                      void *stream, xrt_stats *stats_out /* nullable */);
+
+/* Image-tile shard geometry: tiles are XRT_TILE_W x XRT_TILE_H pixels, numbered row-major, tile t is
+ * owned by rank t % shard_count and stored at slot t / shard_count of that rank's buffer. */
+#define XRT_TILE_W 64
+#define XRT_TILE_H 8
+int xrt_shard_layout(int32_t width, int32_t height, int32_t shard_count, int32_t *tiles_x_out,
+                     int32_t *tiles_y_out, int32_t *tiles_per_rank_out);
+
+/* De-tile the gathered per-rank buffers (shard_count * tiles_per_rank * 512 pixels, rank-major) into
+ * a W*H frame on the device (used on rank 0 after the RCCL gather). */
+int xrt_detile_device(int32_t width, int32_t height, int32_t shard_count, const void *d_gathered,
+                      void *d_rgba_out, void *stream);
+
+/* RayTracer.Progress (RT:43-46): fraction of the frame's ray generations completed; callable from
+ * another thread during xrt_render. */
+float xrt_progress(const xrt_scene *scene);
+
+/* Primary rays of RayTracer.Render (RT:410-421): two Viewport.Unproject per pixel, row-major. */
+int xrt_generate_primary_rays(xrt_scene *scene, const xrt_camera *camera, xrt_ray *rays_out /* W*H */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XRT_H */

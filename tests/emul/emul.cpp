@@ -1,0 +1,69 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.  Single-steps the traversal state machine of
+// xna-ray-trace_amd/csrc/traverse.h on the CPU, one lane at a time, so the pruned front-to-back walk can
+// be checked against the oracle without a GPU (`-m "not gpu"` host-logic tests).  libxrt never links
+// this file and has no CPU execution path.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../xna-ray-trace_amd/csrc/scene_host.h"
+#include "../../xna-ray-trace_amd/csrc/traverse.h"
+
+using namespace xrt;
+
+struct EmuStack {
+    unsigned w[256];
+    unsigned get(int i) const { return w[i]; }
+    void set(int i, unsigned v) { w[i] = v; }
+};
+
+struct emu_scene { HostScene hs; std::string err; };
+
+extern "C" {
+emu_scene *emu_create() { return new emu_scene(); }
+void emu_destroy(emu_scene *s) { delete s; }
+const char *emu_error(emu_scene *s) { return s->err.c_str(); }
+int emu_add_mesh(emu_scene *s, const float *v, const float *n, const float *uv, const float *sn, const float *color, int ntri,
+                 const xrt_material *m, const float *bbox) { return s->hs.add_mesh(v, n, uv, sn, color, ntri, m, bbox, s->err); }
+int emu_add_object(emu_scene *s, const int *ids, int n, const float *w, const float *iw, const float *bb, const float *wbb) {
+    return s->hs.add_object(ids, n, w, iw, bb, wbb, s->err);
+}
+int emu_build(emu_scene *s, int mt, int st) { return s->hs.build(mt, st, s->err) ? 0 : -1; }
+int emu_get_tree(emu_scene *s, int mesh, xrt_node_info *nodes, int64_t *nn, int *refs, int64_t *nr) {
+    const FlatTree &t = mesh < 0 ? s->hs.sceneTree : s->hs.meshTrees[mesh];
+    if (nodes) std::memcpy(nodes, t.info.data(), t.info.size() * sizeof(xrt_node_info));
+    if (refs) std::memcpy(refs, t.infoRefs.data(), t.infoRefs.size() * sizeof(int));
+    *nn = (int64_t)t.info.size(); *nr = (int64_t)t.infoRefs.size();
+    return 0;
+}
+void emu_tree_stats(emu_scene *s, int mesh, int *out) {
+    const FlatTree &t = s->hs.meshTrees[mesh];
+    out[0] = t.nodeCount; out[1] = t.leafCount; out[2] = t.emptyLeaves; out[3] = t.maxDepth; out[4] = t.ownTests; out[5] = t.interiors;
+}
+// mode 0: scene query, mode 1: mesh query.  steps_out (nullable, 3 per ray): scene / node / leaf steps.
+int emu_intersect(emu_scene *s, int mode, int mesh, const xrt_ray *rays, int64_t n, xrt_hit *hits, int64_t *steps_out) {
+    if (!s->hs.built) return -1;
+    SceneView S = s->hs.host_view();
+    if (S.sceneDepth + S.meshDepth > 256) return -2;
+    for (int64_t i = 0; i < n; i++) {
+        Lane L;
+        std::memset(&L, 0, sizeof(L));
+        EmuStack stk;
+        lane_begin(L, S, mk(rays[i].o[0], rays[i].o[1], rays[i].o[2]), mk(rays[i].d[0], rays[i].d[1], rays[i].d[2]),
+                   rays[i].ignore_mesh, rays[i].ignore_tri, (int)i, mode, mesh);
+        int64_t st[3] = {0, 0, 0};
+        while (L.state != ST_FINISH) {
+            if (L.state == ST_SCENE) { advance_scene(L, S, stk); st[0]++; }
+            else if (L.state == ST_NODE) { advance_node(L, S, stk, mode); st[1]++; }
+            else if (L.state == ST_LEAF) { advance_leaf(L, S); st[2]++; }
+        }
+        HitOut h = lane_result(L, S, mode);
+        xrt_hit &o = hits[i];
+        std::memset(&o, 0, sizeof(o));
+        o.hit = h.hit; o.object = h.object; o.mesh = h.mesh; o.tri = h.tri; o.leaf = h.leaf;
+        o.u = h.u; o.v = h.v; o.d = h.d; o.wx = h.wx; o.wy = h.wy; o.wz = h.wz;
+        if (steps_out) { steps_out[3 * i] = st[0]; steps_out[3 * i + 1] = st[1]; steps_out[3 * i + 2] = st[2]; }
+    }
+    return 0;
+}
+}

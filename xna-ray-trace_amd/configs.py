@@ -1,0 +1,161 @@
+"""The five BASELINE.json configurations made concrete (SURVEY §8d "Configs restated").
+
+A SceneSpec is backend neutral: build_product() turns it into the host-mirror objects that drive
+libxrt; oracle/oracle_py.py turns the same spec into an oracle scene.  "depth = k" means
+MaxReflections = k - 1; every config keeps one spot light.
+"""
+import math
+import numpy as np
+
+from . import fixtures, xna
+from . import _abi as abi
+
+f32 = np.float32
+
+
+class SceneSpec:
+    def __init__(self, name):
+        self.name = name
+        self.meshes = []        # (MeshData, dict material)
+        self.objects = []       # (mesh index list, pos, rot, scale)
+        self.camera = None      # dict(pos, target, up, fov, near, far)
+        self.lights = []        # dict(kind, position, direction, color, intensity, spot_angle, decay_exponent)
+        self.width = self.height = 0
+        self.max_reflections = 0
+        self.multisampling = abi.MS_OFF
+        self.multisample_quality = 0
+        self.address_mode = abi.ADDRESS_WRAP
+        self.filtering = abi.FILTER_POINT
+        self.mesh_threshold = 50
+        self.scene_threshold = 20
+
+    def with_size(self, w, h):
+        self.width, self.height = int(w), int(h)
+        return self
+
+
+def material(reflectiveness=0.5, transparent=False, refraction_index=0.0, interpolate_normals=False, texture=None):
+    return dict(reflectiveness=reflectiveness, transparent=transparent, refraction_index=refraction_index,
+                interpolate_normals=interpolate_normals, use_texture=texture is not None, texture=texture)
+
+
+def spot(pos, angle=math.pi / 2):
+    """Light pattern of Game1.cs:132-138: colour 1, direction = -normalize(position), intensity 1."""
+    p = xna.vec3(*pos)
+    n = xna.normalize(p)
+    return dict(kind=abi.LIGHT_SPOT, position=tuple(float(x) for x in p), direction=tuple(float(-x) for x in n),
+                color=(1.0, 1.0, 1.0), intensity=1.0, spot_angle=float(f32(angle)), decay_exponent=float(f32(1.3)))
+
+
+def directional(direction, color=(1.0, 1.0, 1.0), intensity=1.0):
+    return dict(kind=abi.LIGHT_DIRECTIONAL, position=(0.0, 0.0, 0.0), direction=tuple(direction), color=tuple(color),
+                intensity=intensity, spot_angle=0.0, decay_exponent=float(f32(1.3)))
+
+
+def camera(pos, target, fov=math.pi / 4, near=1.0, far=1000.0):
+    """Camera pattern of Game1.cs:111."""
+    return dict(pos=tuple(pos), target=tuple(target), up=(0.0, 1.0, 0.0), fov=float(f32(fov)), near=near, far=far)
+
+
+def crate_scene(width, height, max_reflections, textured=True):
+    """C1 (256x256, R=0) / C2 (1920x1080, R=2): one crate at the origin."""
+    s = SceneSpec("crate")
+    tex = fixtures.crate_texture() if textured else None
+    s.meshes.append((fixtures.crate(1), material(0.5, texture=tex)))
+    s.objects.append(([0], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    s.camera = camera((0, 32, 64), (0, 8, 0))
+    s.lights = [spot((0, 40, 60))]
+    s.max_reflections = max_reflections
+    return s.with_size(width, height)
+
+
+def crate_grid_scene(width, height, max_reflections=2, n=11, grid=8, textured=True):
+    """C3 / C4: grid x grid SceneObjects, spacing 40, sharing ONE tessellated crate(n) mesh (SO:126-127)."""
+    s = SceneSpec("crate_grid%dx%d_n%d" % (grid, grid, n))
+    tex = fixtures.crate_texture() if textured else None
+    s.meshes.append((fixtures.crate(n), material(0.5, texture=tex)))
+    half = 40.0 * (grid - 1) / 2.0
+    for ix in range(grid):
+        for iz in range(grid):
+            s.objects.append(([0], (-half + 40.0 * ix, 0.0, -half + 40.0 * iz), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    s.camera = camera((0, 120, 260), (0, 0, 0))
+    s.lights = [spot((0, 200, 300))]
+    s.max_reflections = max_reflections
+    return s.with_size(width, height)
+
+
+def heightfield_scene(width, height, m=707, max_reflections=2, multisampling=abi.MS_OFF):
+    """C5 (m=707, 999,698 triangles, 16 sub-rays per pixel) and the 100k-triangle variant (m=224)."""
+    s = SceneSpec("heightfield_m%d" % m)
+    s.meshes.append((fixtures.heightfield(m), material(0.3)))
+    s.objects.append(([0], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    s.camera = camera((0, 60, 110), (0, 0, 0))
+    s.lights = [spot((0, 120, 160))]
+    s.max_reflections = max_reflections
+    s.multisampling = multisampling
+    s.multisample_quality = 1
+    return s.with_size(width, height)
+
+
+def config(name, scale=1.0):
+    """BASELINE.json configs by id.  `scale` shrinks the image (parity tests at oracle-friendly sizes)."""
+    def sz(w, h):
+        return max(8, int(round(w * scale))), max(8, int(round(h * scale)))
+    if name == "C1":
+        return crate_scene(*sz(256, 256), max_reflections=0)
+    if name == "C2":
+        return crate_scene(*sz(1920, 1080), max_reflections=2)
+    if name == "C3":
+        return crate_grid_scene(*sz(1920, 1080))
+    if name == "C4":
+        return crate_grid_scene(*sz(3840, 2160))
+    if name == "C5":
+        return heightfield_scene(*sz(1920, 1080), m=707, multisampling=abi.MS_FIXED16)
+    if name == "C5_1spp":
+        return heightfield_scene(*sz(1920, 1080), m=707)
+    if name == "H100k":
+        return heightfield_scene(*sz(1920, 1080), m=224)
+    raise KeyError(name)
+
+
+def camera_matrices(spec):
+    c = spec.camera
+    view = xna.create_look_at(c["pos"], c["target"], c["up"])
+    proj = xna.create_perspective_fov(c["fov"], xna.aspect_ratio(spec.width, spec.height), c["near"], c["far"])
+    return xna.as_array(view), xna.as_array(proj)
+
+
+def build_product(spec, device=0):
+    """SceneSpec -> (OctreeSpatialManager, RayTracer) of the host mirror, scene built on `device`."""
+    from . import api
+    meshes = []
+    for data, m in spec.meshes:
+        mat = api.Material(m["reflectiveness"], m["use_texture"], m["transparent"], m["refraction_index"], m["texture"])
+        mat.InterpolateNormals = m["interpolate_normals"]
+        meshes.append(api.Mesh(data, mat, device=device))
+    scene = api.OctreeSpatialManager(device)
+    scene.itemTreshold, scene.meshItemTreshold = spec.scene_threshold, spec.mesh_threshold
+    for ids, pos, rot, scale in spec.objects:
+        o = api.SceneObject([meshes[i] for i in ids], pos, rot)
+        o.Scale = scale
+        scene.Bodies.append(o)
+    scene.Build()
+    tracer = api.RayTracer()
+    tracer.CurrentScene = scene
+    c = spec.camera
+    tracer.CurrentCamera = api.Camera(c["pos"], c["target"], c["up"], c["fov"], xna.aspect_ratio(spec.width, spec.height), c["near"], c["far"])
+    tracer.CurrentTarget = api.RenderTarget(spec.width, spec.height)
+    tracer.MaxReflections = spec.max_reflections
+    tracer.AddressMode, tracer.TextureFiltering = spec.address_mode, spec.filtering
+    tracer.UseMultisampling = spec.multisampling != abi.MS_OFF
+    tracer.MultisampleMode = spec.multisampling if spec.multisampling != abi.MS_OFF else None
+    tracer.MultisampleQuality = spec.multisample_quality
+    for l in spec.lights:
+        if l["kind"] == abi.LIGHT_SPOT:
+            L = api.SpotLight()
+            L.Position, L.SpotAngle, L.DecayExponent = l["position"], l["spot_angle"], l["decay_exponent"]
+        else:
+            L = api.DirectionalLight()
+        L.Direction, L.Color, L.Intensity = l["direction"], l["color"], l["intensity"]
+        tracer.Lights.append(L)
+    return scene, tracer

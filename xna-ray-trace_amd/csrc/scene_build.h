@@ -1,0 +1,44 @@
+// scene_build.h — host side of xrt_scene_build: MeshOctree.Build (MO:56-96, 204-236) and
+// OctreeSpatialManager.Build (OSM:64-113, 218-248) restated for flat, HBM-friendly arrays.
+// Plain C++ (no HIP): the arrays are uploaded by xrt_api.cpp.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/xrt.h"
+#include "xrt_core.h"
+
+namespace xrt {
+
+struct HostMesh {
+    std::vector<float> v, n, uv, sn, color;   // 9,9,6,3,4 floats per triangle
+    int ntri = 0;
+    float bbox[6] = {0, 0, 0, 0, 0, 0};
+    float reflectiveness = 0, refractionIndex = 0;
+    bool transparent = false, interpolateNormals = false, useTexture = false;
+    int texW = 0, texH = 0;
+    std::vector<uint32_t> texels;
+};
+
+struct HostObject {
+    std::vector<int> meshes;
+    float world[16], invWorld[16], bbox[6], worldBbox[6];
+};
+
+// One flattened tree.  `nodes` holds 2 f4 per record, indices local to the tree (root = record 0 of
+// block 0); `info`/`refs` are the DFS pre-order inspection view (xrt_scene_get_tree).
+struct FlatTree {
+    std::vector<f4> nodes;          // 2 per record
+    std::vector<f4> ownBox;         // 2 per interior record (mesh trees)
+    std::vector<int> nodeDfs;       // per record: DFS pre-order index (-1 for padding records)
+    std::vector<int> leafRefs;      // leaf order: local triangle index (mesh trees) or object id (scene tree)
+    std::vector<xrt_node_info> info;   // DFS order
+    std::vector<int> infoRefs;         // DFS order (same content as leafRefs, concatenated in DFS order)
+    int nodeCount = 0, leafCount = 0, emptyLeaves = 0, maxDepth = 0, ownTests = 0, interiors = 0;
+};
+
+// Returns false (and sets err) when the reference's recursion would not terminate.
+bool build_mesh_tree(const HostMesh &m, int threshold, FlatTree &out, std::string &err);
+bool build_scene_tree(const std::vector<HostObject> &objs, int threshold, FlatTree &out, std::string &err);
+
+}  // namespace xrt

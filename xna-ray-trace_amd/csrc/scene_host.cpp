@@ -1,0 +1,160 @@
+// scene_host.cpp — see scene_host.h.
+#include "scene_host.h"
+
+#include <cstring>
+
+namespace xrt {
+
+size_t SceneArrays::bytes() const {
+    return (nodes.size() + ownBox.size() + triRec.size() + snodes.size() + shade.size()) * sizeof(f4) +
+           (nodeDfs.size() + refTri.size() + srefs.size() + objMesh.size()) * sizeof(int) + meshes.size() * sizeof(MeshRec) +
+           objects.size() * sizeof(ObjRec) + materials.size() * sizeof(MaterialRec) + texels.size() * sizeof(uint32_t);
+}
+
+int HostScene::add_mesh(const float *v, const float *n, const float *uv, const float *sn, const float *color, int ntri,
+                        const xrt_material *m, const float bbox[6], std::string &err) {
+    if (!v || !sn || !m || !bbox || ntri < 0) { err = "xrt_scene_add_mesh: null argument"; return -1; }
+    if (ntri >= (1 << 28)) { err = "xrt_scene_add_mesh: too many triangles"; return -1; }
+    HostMesh hm;
+    hm.ntri = ntri;
+    hm.v.assign(v, v + (size_t)ntri * 9);
+    if (n) hm.n.assign(n, n + (size_t)ntri * 9); else hm.n.assign((size_t)ntri * 9, 0.0f);
+    if (uv) hm.uv.assign(uv, uv + (size_t)ntri * 6); else hm.uv.assign((size_t)ntri * 6, 0.0f);
+    hm.sn.assign(sn, sn + (size_t)ntri * 3);
+    if (color) hm.color.assign(color, color + (size_t)ntri * 4); else hm.color.assign((size_t)ntri * 4, 1.0f);
+    std::memcpy(hm.bbox, bbox, sizeof(hm.bbox));
+    hm.reflectiveness = m->reflectiveness;
+    hm.refractionIndex = m->refraction_index;
+    hm.transparent = m->transparent != 0;
+    hm.interpolateNormals = m->interpolate_normals != 0;
+    hm.useTexture = m->use_texture != 0;
+    if (hm.useTexture) {
+        if (!m->tex_argb || m->tex_width <= 0 || m->tex_height <= 0) { err = "xrt_scene_add_mesh: UseTexture without texels (Bitmap.FromFile would throw, MAT:63)"; return -1; }
+        hm.texW = m->tex_width; hm.texH = m->tex_height;
+        hm.texels.assign(m->tex_argb, m->tex_argb + (size_t)m->tex_width * m->tex_height);
+    }
+    meshes.push_back(std::move(hm));
+    built = false;
+    return (int)meshes.size() - 1;
+}
+
+int HostScene::add_object(const int *meshIds, int n, const float *world, const float *invWorld, const float *bbox,
+                          const float *worldBbox, std::string &err) {
+    if (!meshIds || n < 0 || !world || !invWorld || !bbox || !worldBbox) { err = "xrt_scene_add_object: null argument"; return -1; }
+    HostObject o;
+    for (int i = 0; i < n; i++) {
+        if (meshIds[i] < 0 || meshIds[i] >= (int)meshes.size()) { err = "xrt_scene_add_object: unknown mesh id"; return -1; }
+        o.meshes.push_back(meshIds[i]);
+    }
+    std::memcpy(o.world, world, 64); std::memcpy(o.invWorld, invWorld, 64);
+    std::memcpy(o.bbox, bbox, 24); std::memcpy(o.worldBbox, worldBbox, 24);
+    objects.push_back(std::move(o));
+    built = false;
+    return (int)objects.size() - 1;
+}
+
+bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
+    if (meshThreshold <= 0) meshThreshold = 50;    // MO:42
+    if (sceneThreshold <= 0) sceneThreshold = 20;  // OSM:50
+    built = false;
+    arrays = SceneArrays();
+    meshTrees.assign(meshes.size(), FlatTree());
+    SceneArrays &A = arrays;
+    int triBase = 0;
+    for (size_t mi = 0; mi < meshes.size(); mi++) {
+        const HostMesh &m = meshes[mi];
+        FlatTree &t = meshTrees[mi];
+        if (!build_mesh_tree(m, meshThreshold, t, err)) return false;   // Mesh.Init (MESH:27-32)
+        const int nodeBase = (int)(A.nodes.size() / 2);   // multiple of 8
+        const int sideBase = (int)(A.ownBox.size() / 2);
+        const int refBase = (int)A.refTri.size();
+        for (size_t r = 0; r < t.nodes.size() / 2; r++) {
+            f4 lo = t.nodes[2 * r], hi = t.nodes[2 * r + 1];
+            int a = f2i(lo.w), b = f2i(hi.w);
+            if (t.nodeDfs[r] >= 0) {
+                if (b < 0) a += refBase;
+                else { a += nodeBase; b = (b & ~NODE_SIDE_MASK) | ((b & NODE_SIDE_MASK) + sideBase); }
+            }
+            lo.w = i2f(a); hi.w = i2f(b);
+            A.nodes.push_back(lo); A.nodes.push_back(hi);
+        }
+        A.ownBox.insert(A.ownBox.end(), t.ownBox.begin(), t.ownBox.end());
+        A.nodeDfs.insert(A.nodeDfs.end(), t.nodeDfs.begin(), t.nodeDfs.end());
+        for (int tri : t.leafRefs) {   // leaf references in leaf order: (v1,N.x) (E1,N.y) (E2,N.z)
+            const float *p = &m.v[(size_t)tri * 9];
+            const float *sn = &m.sn[(size_t)tri * 3];
+            A.triRec.push_back(f4{p[0], p[1], p[2], sn[0]});
+            A.triRec.push_back(f4{p[3] - p[0], p[4] - p[1], p[5] - p[2], sn[1]});   // Edge1 = v2 - v1 (RE:54)
+            A.triRec.push_back(f4{p[6] - p[0], p[7] - p[1], p[8] - p[2], sn[2]});   // Edge2 = v3 - v1 (RE:55)
+            A.refTri.push_back(triBase + tri);
+        }
+        MaterialRec mat;
+        std::memset(&mat, 0, sizeof(mat));
+        mat.reflectiveness = m.reflectiveness;
+        mat.refractionIndex = m.refractionIndex;
+        mat.flags = (m.transparent ? MAT_TRANSPARENT : 0) | (m.interpolateNormals ? MAT_INTERP : 0) | (m.useTexture ? MAT_TEXTURE : 0);
+        mat.texOffset = (int)A.texels.size();
+        mat.texWidth = m.texW; mat.texHeight = m.texH;
+        A.texels.insert(A.texels.end(), m.texels.begin(), m.texels.end());
+        A.materials.push_back(mat);
+        A.anyTransparent = A.anyTransparent || m.transparent;
+        A.anyTexture = A.anyTexture || m.useTexture;
+        for (int i = 0; i < m.ntri; i++) {
+            const float *n = &m.n[(size_t)i * 9], *uv = &m.uv[(size_t)i * 6], *c = &m.color[(size_t)i * 4], *sn = &m.sn[(size_t)i * 3];
+            A.shade.push_back(f4{n[0], n[1], n[2], uv[0]});
+            A.shade.push_back(f4{n[3], n[4], n[5], uv[1]});
+            A.shade.push_back(f4{n[6], n[7], n[8], uv[2]});
+            A.shade.push_back(f4{c[0], c[1], c[2], c[3]});
+            A.shade.push_back(f4{uv[3], uv[4], uv[5], i2f((int)mi)});
+            A.shade.push_back(f4{sn[0], sn[1], sn[2], i2f((int)mi)});
+        }
+        MeshRec mr;
+        std::memset(&mr, 0, sizeof(mr));
+        for (int a = 0; a < 3; a++) { mr.bmin[a] = m.bbox[a]; mr.bmax[a] = m.bbox[3 + a]; }
+        mr.rootNode = nodeBase; mr.triBase = triBase; mr.ntri = m.ntri; mr.material = (int)mi; mr.maxDepth = t.maxDepth;
+        A.meshes.push_back(mr);
+        if (t.maxDepth > A.meshDepth) A.meshDepth = t.maxDepth;
+        triBase += m.ntri;
+    }
+    A.totalTris = triBase;
+    if (!build_scene_tree(objects, sceneThreshold, sceneTree, err)) return false;   // OSM:64-99
+    A.snodes = sceneTree.nodes;
+    A.srefs = sceneTree.leafRefs;
+    A.sceneDepth = sceneTree.maxDepth;
+    for (const HostObject &o : objects) {
+        ObjRec r;
+        std::memset(&r, 0, sizeof(r));
+        std::memcpy(r.invWorld, o.invWorld, 64); std::memcpy(r.world, o.world, 64);
+        r.meshStart = (int)A.objMesh.size(); r.meshCount = (int)o.meshes.size();
+        A.objMesh.insert(A.objMesh.end(), o.meshes.begin(), o.meshes.end());
+        A.objects.push_back(r);
+    }
+    // never hand out empty arrays (a zero-size allocation has no address)
+    if (A.ownBox.empty()) A.ownBox.assign(2, f4{0, 0, 0, 0});
+    if (A.triRec.empty()) A.triRec.assign(3, f4{0, 0, 0, 0});
+    if (A.refTri.empty()) A.refTri.assign(1, -1);
+    if (A.srefs.empty()) A.srefs.assign(1, -1);
+    if (A.objMesh.empty()) A.objMesh.assign(1, -1);
+    if (A.shade.empty()) A.shade.assign(SHADE_F4, f4{0, 0, 0, 0});
+    if (A.texels.empty()) A.texels.assign(1, 0u);
+    if (A.meshes.empty()) { MeshRec z; std::memset(&z, 0, sizeof(z)); A.meshes.push_back(z); }
+    if (A.objects.empty()) { ObjRec z; std::memset(&z, 0, sizeof(z)); A.objects.push_back(z); }
+    if (A.materials.empty()) { MaterialRec z; std::memset(&z, 0, sizeof(z)); A.materials.push_back(z); }
+    if (A.nodes.empty()) A.nodes.assign(16, f4{0, 0, 0, 0});
+    if (A.nodeDfs.empty()) A.nodeDfs.assign(8, -1);
+    built = true;
+    return true;
+}
+
+SceneView HostScene::host_view() const {
+    SceneView S;
+    const SceneArrays &A = arrays;
+    S.nodes = A.nodes.data(); S.ownBox = A.ownBox.data(); S.nodeDfs = A.nodeDfs.data();
+    S.triRec = A.triRec.data(); S.refTri = A.refTri.data(); S.meshes = A.meshes.data();
+    S.snodes = A.snodes.data(); S.srefs = A.srefs.data(); S.objects = A.objects.data(); S.objMesh = A.objMesh.data();
+    S.nMeshes = (int)meshes.size(); S.nObjects = (int)objects.size();
+    S.sceneDepth = A.sceneDepth + 1; S.meshDepth = A.meshDepth + 1;
+    return S;
+}
+
+}  // namespace xrt

@@ -1,0 +1,46 @@
+// scene_host.h — host representation of one xrt_scene: the uploaded Mesh / SceneObject graph
+// (xrt_scene_add_mesh / xrt_scene_add_object) and, after build(), the flat arrays that go to HBM.
+// Plain C++ (no HIP).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "scene_build.h"
+#include "traverse.h"
+
+namespace xrt {
+
+constexpr int SHADE_F4 = 6;   // f4 per triangle shading record:
+//   s0 = (n1.xyz, uv1.x) s1 = (n2.xyz, uv1.y) s2 = (n3.xyz, uv2.x) s3 = color.xyzw
+//   s4 = (uv2.y, uv3.x, uv3.y, as_float(material))  s5 = (surfaceNormal.xyz, as_float(mesh))
+
+struct SceneArrays {
+    std::vector<f4> nodes, ownBox, triRec, snodes, shade;
+    std::vector<int> nodeDfs, refTri, srefs, objMesh;
+    std::vector<MeshRec> meshes;
+    std::vector<ObjRec> objects;
+    std::vector<MaterialRec> materials;
+    std::vector<uint32_t> texels;
+    int sceneDepth = 0, meshDepth = 0;
+    int totalTris = 0;
+    bool anyTransparent = false, anyTexture = false;
+    size_t bytes() const;
+};
+
+struct HostScene {
+    std::vector<HostMesh> meshes;
+    std::vector<HostObject> objects;
+    std::vector<FlatTree> meshTrees;
+    FlatTree sceneTree;
+    SceneArrays arrays;
+    bool built = false;
+
+    int add_mesh(const float *v, const float *n, const float *uv, const float *sn, const float *color, int ntri,
+                 const xrt_material *m, const float bbox[6], std::string &err);
+    int add_object(const int *meshIds, int n, const float *world, const float *invWorld, const float *bbox,
+                   const float *worldBbox, std::string &err);
+    bool build(int meshThreshold, int sceneThreshold, std::string &err);
+    SceneView host_view() const;   // pointers into `arrays` (CPU single-stepping in tests/emul only)
+};
+
+}  // namespace xrt

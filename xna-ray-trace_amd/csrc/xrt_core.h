@@ -1,0 +1,295 @@
+// xrt_core.h — records laid out in HBM and the strict-binary32 arithmetic of the hot path.
+//
+// Everything here is `__host__ __device__`: the HIP kernels (kernels.hip) are the product; the host
+// side uses the same inline functions only to prepare per-frame constants (inverse view-projection)
+// and, in tests/emul, to single-step the traversal state machine on the CPU for debugging.
+//
+// Arithmetic contract: IEEE-754 binary32, one rounding per operation, NO fma
+// contraction (the library is built with -ffp-contract=off; division and sqrt are the correctly
+// rounded expansions hipcc emits by default), `double` exactly where the C# calls System.Math.
+// Each function cites the reference line it reproduces (aliases as in include/xrt.h).
+#pragma once
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define XRT_HD __host__ __device__ __forceinline__
+#else
+#define XRT_HD inline
+#endif
+
+namespace xrt {
+
+struct alignas(16) f4 { float x, y, z, w; };
+struct v3 { float x, y, z; };
+
+XRT_HD int   f2i(float f) { return __builtin_bit_cast(int, f); }
+XRT_HD float i2f(int i)   { return __builtin_bit_cast(float, i); }
+
+// ---- HBM records ------------------------------------------------------------------------------------
+// Octree node, 32 B = two f4.  Children of an interior node are 8 consecutive records starting at an
+// index that is a multiple of 8 (child c = 4i+2j+k, MO:210-222); each tree's root sits in slot 0 of a
+// block of its own.
+//   lo = (box.min.xyz, a)   hi = (box.max.xyz, b)
+//   leaf:     a = first leaf reference (index into triRec / refTri), b = NODE_LEAF | count
+//   interior: a = index of child 0, b = flags | side index of its own box
+// For an INTERIOR node the box stored is the union of the boxes of its non-empty descendant leaves
+// (the exact lower bound of their bucket keys); the reference's own box lives
+// in the side array ownBox[2*side .. 2*side+1] and the traversal needs it only when a descendant
+// protrudes from it (NODE_OWN_TEST).
+constexpr int NODE_LEAF     = (int)0x80000000;
+constexpr int NODE_EMPTY    = 0x40000000;   // interior without any triangle below it
+constexpr int NODE_OWN_TEST = 0x20000000;
+constexpr int NODE_SIDE_MASK = 0x1fffffff;
+
+// Leaf reference, 48 B = three f4, stored in leaf order so a leaf is one contiguous run:
+//   a = (v1.xyz, N.x)  b = (E1.xyz, N.y)  c = (E2.xyz, N.z),  E1 = v2 - v1, E2 = v3 - v1 (RE:54-55,
+//   the same single binary32 subtraction the reference performs per test).  refTri[] holds the
+//   scene-global triangle id of each reference.
+
+struct MeshRec {        // 48 B
+    float bmin[3];      // Mesh.MeshBoundingBox (MESH:14)
+    int   rootNode;     // index of the root record (multiple of 8)
+    float bmax[3];
+    int   triBase;      // global id of Triangles[0]
+    int   ntri;
+    int   material;
+    int   maxDepth;
+    int   pad;
+};
+
+struct ObjRec {         // 144 B
+    float invWorld[16]; // SO:198
+    float world[16];    // SO:193
+    int   meshStart;    // into objMesh[]
+    int   meshCount;
+    int   pad0, pad1;
+};
+
+struct MaterialRec {    // 32 B (MAT:234-268)
+    float reflectiveness;
+    float refractionIndex;
+    int   flags;        // bit0 transparent, bit1 interpolateNormals, bit2 useTexture
+    int   texOffset;    // into texels[]
+    int   texWidth, texHeight;
+    int   pad0, pad1;
+};
+constexpr int MAT_TRANSPARENT = 1, MAT_INTERP = 2, MAT_TEXTURE = 4;
+
+// Per-triangle shading record, 80 B = five f4 (TRI:16-24 minus the intersection fields):
+//   s0 = (n1.xyz, uv1.x) s1 = (n2.xyz, uv1.y) s2 = (n3.xyz, uv2.x) s3 = (color.xyzw) s4 = (uv2.y, uv3.x, uv3.y, material)
+// plus the surface normal, read from the leaf reference.
+
+struct LightRec {       // 64 B
+    int    kind;
+    float  px, py, pz;
+    float  dx, dy, dz;
+    float  cr, cg, cb;
+    float  intensity;
+    float  angleCosine; // SPOT:25
+    double decayDenom;  // Math.Pow(1 - angleCosine, DecayExponent), SPOT:54
+    int    pad0, pad1;
+};
+
+// ---- Vector3 (XNA definitions) ---------------------------------------------------------
+XRT_HD v3 mk(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+XRT_HD v3 add(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+XRT_HD v3 sub(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+XRT_HD v3 neg(v3 a) { return mk(-a.x, -a.y, -a.z); }
+XRT_HD v3 scale(v3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+XRT_HD v3 mul(v3 a, v3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+XRT_HD v3 divf(v3 a, float d) { float n = 1.0f / d; return mk(a.x * n, a.y * n, a.z * n); }
+XRT_HD float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+XRT_HD v3 cross(v3 a, v3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+XRT_HD float sqrt_rn(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_sqrtf(x);   // correctly rounded expansion (checked in the ISA: v_sqrt + fma fix-up)
+#else
+    return sqrtf(x);
+#endif
+}
+XRT_HD float length(v3 a) { return sqrt_rn((a.x * a.x + a.y * a.y) + a.z * a.z); }
+XRT_HD v3 normalize(v3 a) {
+    float n = (a.x * a.x + a.y * a.y) + a.z * a.z;
+    float s = 1.0f / sqrt_rn(n);
+    return mk(a.x * s, a.y * s, a.z * s);
+}
+XRT_HD v3 transform(v3 p, const float *m) {   // Vector3.Transform(position, matrix)
+    return mk(((p.x * m[0] + p.y * m[4]) + p.z * m[8]) + m[12],
+              ((p.x * m[1] + p.y * m[5]) + p.z * m[9]) + m[13],
+              ((p.x * m[2] + p.y * m[6]) + p.z * m[10]) + m[14]);
+}
+XRT_HD v3 reflect(v3 v, v3 n) {   // RT:549
+    float k = (v.x * n.x + v.y * n.y) + v.z * n.z;
+    return mk(v.x - (2.0f * k) * n.x, v.y - (2.0f * k) * n.y, v.z - (2.0f * k) * n.z);
+}
+XRT_HD v3 lerp(v3 a, v3 b, float t) {   // RT:584
+    return mk(a.x + (b.x - a.x) * t, a.y + (b.y - a.y) * t, a.z + (b.z - a.z) * t);
+}
+XRT_HD bool is_nan(float a) { return a != a; }
+XRT_HD float math_max(float a, float b) { return a > b ? a : (is_nan(a) ? a : b); }   // System.Math.Max
+XRT_HD float math_min(float a, float b) { return a < b ? a : (is_nan(a) ? a : b); }   // System.Math.Min
+
+// ---- ray with the per-axis reciprocals BoundingBox.Intersects recomputes on every call -----------------
+struct RayPre {
+    v3 o, d, inv;
+    int par;   // bit k set: fabs(d_k) < 1e-6f (the parallel branch)
+};
+XRT_HD RayPre make_ray(v3 o, v3 d) {
+    RayPre r;
+    r.o = o; r.d = d;
+    r.par = (fabsf(d.x) < 1e-06f ? 1 : 0) | (fabsf(d.y) < 1e-06f ? 2 : 0) | (fabsf(d.z) < 1e-06f ? 4 : 0);
+    r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    return r;
+}
+// Front-to-back child permutation: visit child (p ^ dirmask) for p = 0..7.
+XRT_HD int dir_mask(v3 d) { return (d.x < 0.0f ? 4 : 0) | (d.y < 0.0f ? 2 : 0) | (d.z < 0.0f ? 1 : 0); }
+
+// BoundingBox.Intersects(ref Ray, out float?) (MO:331, OSM:460, MESH:37): entry distance or miss.
+XRT_HD bool slab(const RayPre &r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float &key) {
+    float num = 0.0f, num2 = FLT_MAX;
+    bool ok = true;
+    if (r.par & 1) { ok = ok && !(r.o.x < mnx || r.o.x > mxx); }
+    else {
+        float t1 = (mnx - r.o.x) * r.inv.x, t2 = (mxx - r.o.x) * r.inv.x;
+        if (t1 > t2) { float t = t1; t1 = t2; t2 = t; }
+        num = math_max(t1, num); num2 = math_min(t2, num2);
+        ok = ok && !(num > num2);
+    }
+    if (r.par & 2) { ok = ok && !(r.o.y < mny || r.o.y > mxy); }
+    else {
+        float t1 = (mny - r.o.y) * r.inv.y, t2 = (mxy - r.o.y) * r.inv.y;
+        if (t1 > t2) { float t = t1; t1 = t2; t2 = t; }
+        num = math_max(t1, num); num2 = math_min(t2, num2);
+        ok = ok && !(num > num2);
+    }
+    if (r.par & 4) { ok = ok && !(r.o.z < mnz || r.o.z > mxz); }
+    else {
+        float t1 = (mnz - r.o.z) * r.inv.z, t2 = (mxz - r.o.z) * r.inv.z;
+        if (t1 > t2) { float t = t1; t1 = t2; t2 = t; }
+        num = math_max(t1, num); num2 = math_min(t2, num2);
+        ok = ok && !(num > num2);
+    }
+    key = num;
+    return ok;
+}
+
+// RayExtensions.IntersectsTriangleBackfaceCulling (RE:42-75) on a leaf reference (a,b,c).
+XRT_HD bool tri_test(v3 O, v3 D, f4 a, f4 b, f4 c, float &u, float &v, float &dist) {
+    float nd = (a.w * D.x + b.w * D.y) + c.w * D.z;   // RE:49
+    v3 T = mk(O.x - a.x, O.y - a.y, O.z - a.z);       // RE:46
+    v3 E1 = mk(b.x, b.y, b.z), E2 = mk(c.x, c.y, c.z);
+    v3 P = cross(D, E2);                              // RE:58
+    v3 Q = cross(T, E1);                              // RE:59
+    float row1 = dot(Q, E2), row2 = dot(P, T), row3 = dot(Q, D);   // RE:62-64
+    float inv = 1.0f / dot(P, E1);                    // RE:66
+    dist = row1 * inv; u = row2 * inv; v = row3 * inv;
+    return !(nd > 0.0f) && u >= 0.0f && v >= 0.0f && dist >= 0.0f && (u + v) <= 1.0f;   // RE:50,71-74
+}
+
+// ---- Color (RT:584,705,726,732) ---------------------------------------------------------------------------
+XRT_HD uint32_t pack_unorm255(float v) {
+    v = v * 255.0f;
+    if (is_nan(v)) return 0u;
+    if (v < 0.0f) return 0u;       // also -inf
+    if (v > 255.0f) return 255u;   // also +inf
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_rintf(v);   // round half to even (Math.Round)
+#else
+    return (uint32_t)nearbyintf(v);
+#endif
+}
+XRT_HD uint32_t pack_color(v3 c) { return pack_unorm255(c.x) | (pack_unorm255(c.y) << 8) | (pack_unorm255(c.z) << 16) | 0xff000000u; }
+XRT_HD v3 unpack_color(uint32_t p) {
+    return mk((float)(p & 0xffu) / 255.0f, (float)((p >> 8) & 0xffu) / 255.0f, (float)((p >> 16) & 0xffu) / 255.0f);
+}
+
+// ---- Matrix (host only: per-frame constants) -------------------------------------------------------------------
+inline void mat_multiply(const float *a, const float *b, float *r) {
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            r[4 * i + j] = ((a[4 * i] * b[j] + a[4 * i + 1] * b[4 + j]) + a[4 * i + 2] * b[8 + j]) + a[4 * i + 3] * b[12 + j];
+}
+inline void mat_invert(const float *m, float *r) {   // Matrix.Invert
+    float n5 = m[0], n4 = m[1], n3 = m[2], n2 = m[3], n9 = m[4], n8 = m[5], n7 = m[6], n6 = m[7];
+    float n17 = m[8], n16 = m[9], n15 = m[10], n14 = m[11], n13 = m[12], n12 = m[13], n11 = m[14], n10 = m[15];
+    float n23 = n15 * n10 - n14 * n11, n22 = n16 * n10 - n14 * n12, n21 = n16 * n11 - n15 * n12;
+    float n20 = n17 * n10 - n14 * n13, n19 = n17 * n11 - n15 * n13, n18 = n17 * n12 - n16 * n13;
+    float n39 = (n8 * n23 - n7 * n22) + n6 * n21;
+    float n38 = -((n9 * n23 - n7 * n20) + n6 * n19);
+    float n37 = (n9 * n22 - n8 * n20) + n6 * n18;
+    float n36 = -((n9 * n21 - n8 * n19) + n7 * n18);
+    float num = 1.0f / (((n5 * n39 + n4 * n38) + n3 * n37) + n2 * n36);
+    r[0] = n39 * num; r[4] = n38 * num; r[8] = n37 * num; r[12] = n36 * num;
+    r[1] = -((n4 * n23 - n3 * n22) + n2 * n21) * num;
+    r[5] = ((n5 * n23 - n3 * n20) + n2 * n19) * num;
+    r[9] = -((n5 * n22 - n4 * n20) + n2 * n18) * num;
+    r[13] = ((n5 * n21 - n4 * n19) + n3 * n18) * num;
+    float n35 = n7 * n10 - n6 * n11, n34 = n8 * n10 - n6 * n12, n33 = n8 * n11 - n7 * n12;
+    float n32 = n9 * n10 - n6 * n13, n31 = n9 * n11 - n7 * n13, n30 = n9 * n12 - n8 * n13;
+    r[2] = ((n4 * n35 - n3 * n34) + n2 * n33) * num;
+    r[6] = -((n5 * n35 - n3 * n32) + n2 * n31) * num;
+    r[10] = ((n5 * n34 - n4 * n32) + n2 * n30) * num;
+    r[14] = -((n5 * n33 - n4 * n31) + n3 * n30) * num;
+    float n29 = n7 * n14 - n6 * n15, n28 = n8 * n14 - n6 * n16, n27 = n8 * n15 - n7 * n16;
+    float n26 = n9 * n14 - n6 * n17, n25 = n9 * n15 - n7 * n17, n24 = n9 * n16 - n8 * n17;
+    r[3] = -((n4 * n29 - n3 * n28) + n2 * n27) * num;
+    r[7] = ((n5 * n29 - n3 * n26) + n2 * n25) * num;
+    r[11] = -((n5 * n28 - n4 * n26) + n2 * n24) * num;
+    r[15] = ((n5 * n27 - n4 * n25) + n3 * n24) * num;
+}
+
+// Per-frame ray-generation constants: Viewport.Unproject inverts world*view*proj on every call
+// (RT:415,419) — the same matrix for every pixel, so it is computed once on the host with the same
+// arithmetic and handed to the kernel.
+struct RayGenParams {
+    float m[16];          // Invert(Multiply(Multiply(Identity, view), proj))
+    float vpX, vpY, vpW, vpH, minDepth, depthRange;
+    int   width, height;
+    int   tilesX, tilesY;
+    int   shardRank, shardCount;   // path -> tile mapping
+    int   samples;                 // 1, or 16 for XRT_MS_FIXED16
+    int   pad;
+};
+
+// One Viewport.Unproject (RT:415 / RT:419) given the hoisted inverse matrix.
+XRT_HD v3 unproject(const RayGenParams &g, float sx, float sy, float sz) {
+    float X = (((sx - g.vpX) / g.vpW) * 2.0f) - 1.0f;
+    float Y = -((((sy - g.vpY) / g.vpH) * 2.0f) - 1.0f);
+    float Z = (sz - g.minDepth) / g.depthRange;
+    v3 vec = transform(mk(X, Y, Z), g.m);
+    float a = (((X * g.m[3]) + (Y * g.m[7])) + (Z * g.m[11])) + g.m[15];
+    float num = a - 1.0f;
+    bool within = (-1.401298E-45f <= num) && (num <= 1.401298E-45f);
+    if (!within) vec = divf(vec, a);
+    return vec;
+}
+
+// SPOT:55 Math.Pow(surfaceDot, 12) as the double multiply chain of SURVEY Q14.
+XRT_HD double pow12(double x) { double x2 = x * x; double x4 = x2 * x2; double x8 = x4 * x4; return x8 * x4; }
+
+// ILight.GetLightForFragment (SPOT:37-62, DIR:23-30)
+XRT_HD v3 light_for_fragment(const LightRec &L, v3 position, v3 normal) {
+    if (L.kind == 0) {
+        v3 dirToLight = normalize(sub(mk(L.px, L.py, L.pz), position));
+        float surfaceDot = dot(dirToLight, normal);
+        if (surfaceDot < 0.0f) return mk(0, 0, 0);
+        float lightDot = dot(neg(dirToLight), mk(L.dx, L.dy, L.dz));
+        if (lightDot > L.angleCosine) {
+            float spotIntensity = L.intensity * (float)((double)(lightDot - L.angleCosine) / L.decayDenom);
+            v3 c = scale(scale(mk(L.cr, L.cg, L.cb), spotIntensity), surfaceDot);
+            float s12 = (float)pow12((double)surfaceDot);
+            return add(c, scale(mk(1.0f, 1.0f, 1.0f), s12));
+        }
+        return mk(0, 0, 0);
+    }
+    float surfaceDot = dot(mk(L.dx, L.dy, L.dz), normal);
+    if (surfaceDot < 0.0f) surfaceDot = 0.0f;
+    return scale(scale(mk(L.cr, L.cg, L.cb), surfaceDot), L.intensity);
+}
+
+// float % 1.0f of C# (fmod, exact) for MAT:125-136.
+XRT_HD float fmod1(float x) { return x - truncf(x); }
+
+}  // namespace xrt
