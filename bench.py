@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the ray / octree / triangle hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5|C5_1spp|H100k] [--scale S]
+
+One step = one frame of the workload: every pixel's CastRay tree (closest-hit, shadow and reflection
+queries).  Default workload is BASELINE.json configs[1] (C2: Free_crate mesh, 1920x1080, depth 3, 1 spp);
+the other configs are reported as short side measurements in "other_configs" at N=1.
+For N > 1 the driver starts one process per GPU (torch.distributed.run); the frame is sharded by 64x8 image
+tiles (total work fixed -> "strong" scaling), each rank renders its tiles from its own scene replica, and the
+per-frame exchange step is one RCCL gather of the tile buffers onto rank 0 followed by a de-tile kernel.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+xrt = importlib.import_module("xna-ray-trace_amd")
+
+WORKLOADS = {
+    "C1": "C1: Free_crate mesh (12 triangles), 256x256, depth=1 (MaxReflections 0), 1 spot light",
+    "C2": "C2: Free_crate mesh (12 triangles), 1920x1080, depth=3 (reflect+shadow, MaxReflections 2), 1 spp, 1 spot light",
+    "C3": "C3: Free_crate x64 instanced grid (tessellated crate n=11, 92,928 instanced triangles), 1920x1080, depth=3",
+    "C4": "C4: C3 scene at 3840x2160, depth=3",
+    "C5": "C5: 1M-triangle heightfield (999,698 triangles), 1920x1080, depth=3, 16 sub-rays per pixel",
+    "C5_1spp": "C5 scene, 1920x1080, depth=3, 1 spp",
+    "H100k": "100k-triangle heightfield (100,352 triangles), 1920x1080, depth=3, 1 spp",
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def intersect_bytes(st):
+    """Algorithmic bytes of the traversal kernel for one frame: everything except the shading
+    terms (80 B per shaded hit, 4 B per pixel write)."""
+    return st["algorithmic_bytes"] - 80 * st["shaded_hits"] - 4 * st["pixels"]
+
+
+def time_frames(tracer, out, steps, warmup, rank, world, width, height, gathered_out):
+    """W warm-up frames, then K timed frames bracketed by barrier + synchronize on both sides."""
+    def frame():
+        st = tracer.RenderDevice(out.data_ptr(), shard_rank=rank, shard_count=world)
+        if world > 1:
+            g = xrt.dist.gather_frame(out, width, height)      # the path's exchange step (RCCL gather over xGMI)
+            if rank == 0:
+                xrt.dist.detile_device(g, width, height, world, gathered_out)
+        return st
+    for _ in range(warmup):
+        frame()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms_intersect, launches = 0.0, 0
+    for _ in range(steps):
+        st = frame()
+        ms_intersect += st["ms_intersect"]
+        launches += st["intersect_launches"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt, ms_intersect, launches
+
+
+def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=True):
+    spec = xrt.configs.config(name, scale)
+    t0 = time.perf_counter()
+    scene, tracer = xrt.configs.build_product(spec, device=local_rank)
+    build_s = time.perf_counter() - t0
+    W, H = spec.width, spec.height
+    tx, ty, tpr = xrt.dist.shard_layout(W, H, world)
+    n_out = tpr * 512 if world > 1 else W * H
+    out = torch.zeros(n_out, dtype=torch.int32, device="cuda")
+    final = torch.zeros(W * H, dtype=torch.int32, device="cuda") if (world > 1 and rank == 0) else None
+    # untimed: exact reference-work counters of this rank's shard (algorithmic bytes, ray counts)
+    tracer.collect_stats = with_stats
+    st0 = tracer.RenderDevice(out.data_ptr(), shard_rank=rank, shard_count=world)
+    tracer.collect_stats = False
+    dt, ms_int, launches = time_frames(tracer, out, steps, warmup, rank, world, W, H, final)
+    rays = st0["rays_closest"] + st0["rays_shadow"]
+    res = dict(rays=rays, seconds=dt, ms_intersect=ms_int, launches=launches, stats=st0, build_s=build_s, width=W, height=H,
+               tris=sum(m[0].ntri for m in spec.meshes), instances=len(spec.objects))
+    return res, spec
+
+
+def cpu_baseline(spec, budget_s=12.0):
+    """The CPU oracle (C++ restatement of the reference's C# path, kind "port") on the host cores, rank 0 at
+    N=1 only, on a bounded sample of the same workload: whole frames if they fit the budget, else centre rows."""
+    from oracle import oracle_py as orc
+    o = orc.OracleScene(spec)
+    H = spec.height
+    # probe 8 centre rows to size the sample
+    t0 = time.perf_counter()
+    _, _, st = o.render(nthreads=1, rows=(H // 2 - 4, H // 2 + 4), want_float=False)
+    probe = max(time.perf_counter() - t0, 1e-4)
+    rows = int(min(H, max(8, 8 * budget_s / probe)))
+    r0 = max(0, H // 2 - rows // 2)
+    t0 = time.perf_counter()
+    _, _, st = o.render(nthreads=1, rows=(r0, r0 + rows), want_float=False)
+    dt = time.perf_counter() - t0
+    rays = st["rays_closest"] + st["rays_shadow"]
+    ncpu = os.cpu_count() or 1
+    nt = min(ncpu, 16)
+    t0 = time.perf_counter()
+    _, _, stm = o.render(nthreads=nt, rows=(r0, r0 + rows), want_float=False)
+    dtm = time.perf_counter() - t0
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": "rows %d..%d of the %dx%d frame (%d rays, %.1f s), oracle/ single thread as the shipped reference (RayTracer.cs:99)" % (r0, r0 + rows, spec.width, H, rays, dt),
+            "value_all_cores": round(rays / dtm / 1e6, 4), "cores_all": nt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2", choices=list(WORKLOADS))
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the image (debug only; invalid as a benchmark)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements of the other configs")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    args = ap.parse_args()
+
+    rank, local_rank, world = xrt.dist.env_rank_world()
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus %d needs one process per GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+              "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    res, spec = run_config(args.config, args.scale, args.steps, args.warmup, rank, local_rank, world)
+    # max over ranks of the timed region; total rays over ranks
+    t = torch.tensor([res["seconds"]], dtype=torch.float64, device="cuda")
+    r = torch.tensor([float(res["rays"]), float(intersect_bytes(res["stats"])), res["ms_intersect"], float(res["launches"])],
+                     dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rsum = r.clone()
+        dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
+    else:
+        rsum = r
+    seconds = float(t.item())
+    rays_frame = float(rsum[0].item())
+    value = rays_frame * args.steps / seconds / 1e6
+
+    if rank == 0:
+        st = res["stats"]
+        # roofline of the dominant kernel (k_intersect), this rank: algorithmic bytes per launch / mean launch time
+        launches = max(res["launches"], 1)
+        bytes_per_launch = intersect_bytes(st) * args.steps / launches
+        ms_per_launch = res["ms_intersect"] / launches
+        achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+        line = {
+            "metric": "Mrays/sec (primary+shadow+reflection queries), 1920x1080" if args.scale == 1.0 else "Mrays/sec (scaled image, not a benchmark)",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(seconds / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.config], "width": res["width"], "height": res["height"], "triangles": res["tris"],
+                       "instances": res["instances"], "rays_per_frame": int(rays_frame), "parallelism": "image tiles 64x8 round-robin x%d" % world,
+                       "scene_build_s": round(res["build_s"], 3)},
+            "roofline": {"bound": "hbm", "kernel": "k_intersect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch), "ms_per_launch": round(ms_per_launch, 5),
+                         "launches_per_frame": launches // max(args.steps, 1),
+                         "note": "numerator = the REFERENCE algorithm's bytes (SURVEY 8d); every fixture fits the 256 MiB Infinity Cache"},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(spec)
+        if world == 1 and not args.no_extra and args.scale == 1.0:
+            other = {}
+            for name, k in (("C3", 5), ("C5_1spp", 3)):
+                if name == args.config:
+                    continue
+                try:
+                    r2, _ = run_config(name, 1.0, k, 1, 0, local_rank, 1)
+                    l2 = max(r2["launches"], 1)
+                    ach = intersect_bytes(r2["stats"]) * k / l2 / (r2["ms_intersect"] / l2 * 1e-3) / 1e9
+                    other[name] = {"workload": WORKLOADS[name], "Mrays_per_s": round(r2["rays"] * k / r2["seconds"] / 1e6, 2),
+                                   "ms_per_step": round(r2["seconds"] / k * 1e3, 3), "rays_per_frame": int(r2["rays"]),
+                                   "intersect_GBps_algorithmic": round(ach, 1), "roofline_frac": round(ach / HBM_PEAK_GBS, 4),
+                                   "scene_build_s": round(r2["build_s"], 2)}
+                except Exception as e:   # a side measurement must not take the headline down
+                    other[name] = {"error": str(e)[:200]}
+            line["other_configs"] = other
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -100,7 +100,7 @@ struct Material {
     }
 };
 
-struct Counters {
+struct alignas(128) Counters {   // one cache-line pair per render thread
     uint64_t rays_closest = 0, rays_shadow = 0, hits_closest = 0, hits_shadow = 0;
     uint64_t scene_node_tests = 0, instance_visits = 0, mesh_aabb_tests = 0, mesh_queries = 0;
     uint64_t node_tests = 0, leaf_refs = 0, tri_tests = 0, shaded_hits = 0;
@@ -211,11 +211,14 @@ struct MeshOctree {
         Number(root.get(), counter, 0);
         nodeCount = counter;
     }
+    int builtNodes = 1;
     void BuildTree(CubeNode *parent, int level) {   // MO:84-96
+        if (overflow) return;
         if ((int)parent->containingObjects.size() > itemTreshold) {
             // The C# recursion has no depth limit and overflows the stack when more than
-            // itemTreshold triangles share a vertex; the oracle stops at 64 levels and flags it.
-            if (level >= 64) { overflow = true; return; }
+            // itemTreshold triangles share a vertex; the oracle stops at 64 levels / 2^24 nodes and flags it.
+            builtNodes += 8;
+            if (level >= 64 || builtNodes > (1 << 24)) { overflow = true; return; }
             depth++;
             SplitCuboid(parent);
             for (int i = 0; i < 8; i++) BuildTree(parent->children[i].get(), level + 1);
@@ -379,9 +382,12 @@ struct OctreeSpatialManager {
         Number(root.get(), counter, 0);
         nodeCount = counter;
     }
+    int builtNodes = 1;
     void BuildTree(CubeNode *parent, int level) {   // OSM:101-113
+        if (overflow) return;
         if ((int)parent->containingObjects.size() > itemTreshold) {
-            if (level >= 32) { overflow = true; return; }   // the C# would recurse forever (stack overflow)
+            builtNodes += 8;
+            if (level >= 24 || builtNodes > (1 << 20)) { overflow = true; return; }   // the C# would recurse forever (stack overflow)
             SplitCuboid(parent);
             for (int i = 0; i < 8; i++) BuildTree(parent->children[i].get(), level + 1);
         }

@@ -1,0 +1,281 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the
+CPU oracle on the same seeded inputs — bit-exact hit-triangle index, octree leaf id, u/v/d, world position,
+packed RGBA8 and the fp32 colour vector (tolerance 0: the north star allows 1e-5 on fp32 RGB, we assert
+equality of the bit patterns and report the max abs difference if that ever fails)."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from util import hits_equal, random_rays, secondary_rays, triangle_soup
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RGB_TOL = 1e-5   # north-star tolerance for fp32 pixel RGB; we expect exactly 0
+
+
+def assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf):
+    if rgbf is not None:
+        diff = float(np.abs(rgbf.astype(np.float64) - o_rgbf.astype(np.float64)).max()) if rgbf.size else 0.0
+        assert diff <= RGB_TOL, "fp32 RGB max abs diff %g" % diff
+        assert np.array_equal(rgbf.view(np.uint32), o_rgbf.view(np.uint32)), "fp32 RGB not bit-identical (max abs diff %g)" % diff
+    assert np.array_equal(rgba, o_rgba), "%d RGBA8 pixels differ" % int((rgba != o_rgba).sum())
+
+
+def test_library_loaded_and_device_visible(xrt):
+    n = C.c_int(0)
+    assert xrt.abi.lib().xrt_device_count(C.byref(n)) == 0 and n.value >= 1
+
+
+SCENES = {
+    "crate": lambda x: x.configs.config("C1"),
+    "grid": lambda x: x.configs.crate_grid_scene(160, 90),
+    "h64": lambda x: x.configs.heightfield_scene(160, 90, m=64),
+    "h224": lambda x: x.configs.heightfield_scene(160, 90, m=224),
+}
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_tree_raygen_and_intersection_parity(xrt, orc, name):
+    spec = SCENES[name](xrt)
+    scene, tracer = xrt.configs.build_product(spec)
+    o = orc.OracleScene(spec)
+    for mesh, mid in ((None, -1), (scene.meshes[0], 0)):
+        n1, r1 = scene.tree(mesh)
+        n2, r2 = o.tree(mid)
+        assert n1.tobytes() == n2.tobytes() and np.array_equal(r1, r2)
+    rays = tracer.GeneratePrimaryRays()          # RT:410-421 on the GPU
+    o_rays = o.primary_rays()
+    assert rays.tobytes() == o_rays.tobytes(), "primary rays differ"
+    hits, st = scene.IntersectBatch(rays, stats=True)
+    o_hits, o_st = o.intersect(rays, stats=True)
+    assert hits_equal(o_hits, hits) == {}
+    for k in ("rays_closest", "hits_closest", "scene_node_tests", "instance_visits", "mesh_aabb_tests", "mesh_queries", "node_tests", "leaf_refs", "tri_tests"):
+        assert st[k] == o_st[k], (k, st[k], o_st[k])
+    sec = secondary_rays(xrt, o_hits)
+    if len(sec):
+        h2, st2 = scene.IntersectBatch(sec, stats=True)
+        o2, ost2 = o.intersect(sec, stats=True)
+        assert hits_equal(o2, h2) == {}
+        for k in ("node_tests", "leaf_refs", "tri_tests", "scene_node_tests", "instance_visits"):
+            assert st2[k] == ost2[k], (k, st2[k], ost2[k])
+    # MeshOctree.GetRayIntersection (MO:259) through Mesh.Init / xrt_mesh_intersect
+    mesh = scene.meshes[0]
+    mesh.Init()
+    assert hits_equal(o.mesh_intersect(0, rays[::3]), mesh.Octree.IntersectBatch(rays[::3])) == {}
+
+
+def test_golden_hit_vectors_on_gpu(xrt):
+    for name, spec in (("c3", xrt.configs.crate_grid_scene(160, 90)), ("h224", xrt.configs.heightfield_scene(160, 90, m=224))):
+        scene, tracer = xrt.configs.build_product(spec)
+        rays = np.load(os.path.join(GOLDEN, name + "_rays.npy"))
+        gold = np.load(os.path.join(GOLDEN, name + "_hits.npy"))
+        assert hits_equal(gold, scene.IntersectBatch(rays)) == {}
+
+
+def soup_spec(xrt, n, seed, threshold, size):
+    s = xrt.configs.SceneSpec("soup")
+    s.meshes.append((triangle_soup(n, seed, size), xrt.configs.material(0.5)))
+    s.objects.append(([0], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    s.camera = xrt.configs.camera((0, 3, 3), (0, 0, 0))
+    s.lights = [xrt.configs.spot((0, 5, 5))]
+    s.mesh_threshold = threshold
+    return s.with_size(64, 64)
+
+
+@pytest.mark.parametrize("n,seed,threshold,size", [(60, 3, 2, 0.9), (300, 5, 4, 0.5), (2000, 7, 20, 0.15), (500, 9, 50, 1.5)])
+def test_leaf_group_quirk_ties_and_ignore_on_soups(xrt, orc, n, seed, threshold, size):
+    spec = soup_spec(xrt, n, seed, threshold, size)
+    scene, tracer = xrt.configs.build_product(spec)
+    o = orc.OracleScene(spec)
+    rays = random_rays(xrt, 20000, seed + 100)
+    o_hits = o.intersect(rays)
+    assert hits_equal(o_hits, scene.IntersectBatch(rays)) == {}
+    sec = secondary_rays(xrt, o_hits, seed)
+    assert hits_equal(o.intersect(sec), scene.IntersectBatch(sec)) == {}
+    rgba, rgbf = tracer_render(tracer, 2)
+    o_rgba, o_rgbf, _ = orc.OracleScene(spec_with(spec, 2)).render(nthreads=8)
+    assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+
+
+def spec_with(spec, R):
+    spec.max_reflections = R
+    return spec
+
+
+def tracer_render(tracer, R):
+    tracer.MaxReflections = R
+    return tracer.Render(want_float=True)
+
+
+def test_single_ray_interface_and_edge_batches(xrt, orc):
+    spec = xrt.configs.config("C1")
+    scene, tracer = xrt.configs.build_product(spec)
+    o = orc.OracleScene(spec)
+    # ISpatialManager.GetRayIntersection single-ray signature (ISM:15)
+    found, res = scene.GetRayIntersection(((0, 32, 64), tuple(xrt.xna.as_array(xrt.xna.normalize(xrt.xna.vec3(0, -24, -64))))))
+    assert found and res["mesh"] is scene.meshes[0] and 0 <= res["triangle"] < 12
+    found, res = scene.GetRayIntersection(((0, 32, 64), (0, 1, 0)))
+    assert not found and res is None
+    # empty batch, one ray, a batch that is not a multiple of the wave size
+    assert len(scene.IntersectBatch(xrt.rays_array(np.zeros((0, 3)), np.zeros((0, 3))))) == 0
+    rays = o.primary_rays()
+    for n in (1, 63, 65, 257, 1000):
+        assert hits_equal(o.intersect(rays[30000:30000 + n]), scene.IntersectBatch(rays[30000:30000 + n])) == {}
+    # degenerate rays: zero / NaN direction, origin far away, near-parallel direction
+    nan = float("nan")
+    bad = xrt.rays_array([(0, 50, 0), (0, 50, 0), (1e30, 0, 0), (0, 50, 0)], [(0, 0, 0), (nan, -1, 0), (-1, 0, 0), (1e-7, -1, 1e-7)])
+    assert hits_equal(o.intersect(bad), scene.IntersectBatch(bad)) == {}
+
+
+def test_instances_rotated_scaled_two_meshes(xrt, orc):
+    s = xrt.configs.SceneSpec("inst")
+    s.meshes.append((xrt.fixtures.crate(3), xrt.configs.material(0.5, texture=xrt.fixtures.crate_texture())))
+    s.meshes.append((triangle_soup(80, 11, 0.4), xrt.configs.material(0.2, interpolate_normals=True)))
+    k = 0
+    for ix in range(5):
+        for iz in range(5):
+            s.objects.append(([0] if (k % 3) else [0, 1], (-60.0 + 30.0 * ix, 2.0 * (k % 2), -60.0 + 30.0 * iz),
+                              (0.1 * ix, 0.37 * iz, 0.05 * (ix + iz)), (1.0 + 0.1 * ix, 1.0, 0.8 + 0.1 * iz)))
+            k += 1
+    s.camera = xrt.configs.camera((0, 80, 160), (0, 0, 0))
+    s.lights = [xrt.configs.spot((0, 100, 100)), xrt.configs.directional((0.3, 0.8, 0.5), (0.4, 0.5, 0.6), 0.7)]
+    s.max_reflections = 3
+    s = s.with_size(160, 90)
+    scene, tracer = xrt.configs.build_product(s)
+    o = orc.OracleScene(s)
+    rays = o.primary_rays()
+    o_hits = o.intersect(rays)
+    assert hits_equal(o_hits, scene.IntersectBatch(rays)) == {}
+    sec = secondary_rays(xrt, o_hits)
+    assert hits_equal(o.intersect(sec), scene.IntersectBatch(sec)) == {}
+    tracer.collect_stats = True
+    rgba, rgbf = tracer.Render(want_float=True)
+    o_rgba, o_rgbf, o_st = o.render(nthreads=8)
+    assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+    for k in ("rays_closest", "rays_shadow", "hits_closest", "hits_shadow", "node_tests", "leaf_refs", "tri_tests", "shaded_hits",
+              "scene_node_tests", "instance_visits", "mesh_aabb_tests", "mesh_queries", "algorithmic_bytes"):
+        assert tracer.last_stats[k] == o_st[k], (k, tracer.last_stats[k], o_st[k])
+
+
+RENDERS = {
+    "C1": lambda x: x.configs.config("C1"),                                          # the reference-runnable case, full size
+    "C2_small": lambda x: x.configs.crate_scene(240, 136, max_reflections=2),
+    "C2_flat": lambda x: x.configs.crate_scene(240, 136, max_reflections=2, textured=False),
+    "C3_small": lambda x: x.configs.crate_grid_scene(192, 108),
+    "H224_R8": lambda x: x.configs.heightfield_scene(128, 72, m=224, max_reflections=8),
+    "C5_small_ms16": lambda x: x.configs.heightfield_scene(64, 36, m=224, multisampling=x.abi.MS_FIXED16),
+    "odd_size": lambda x: x.configs.crate_grid_scene(101, 37),                        # edge tiles with dead lanes
+}
+
+
+@pytest.mark.parametrize("name", list(RENDERS))
+def test_render_parity(xrt, orc, name):
+    spec = RENDERS[name](xrt)
+    scene, tracer = xrt.configs.build_product(spec)
+    tracer.collect_stats = True
+    rgba, rgbf = tracer.Render(want_float=True)
+    o_rgba, o_rgbf, o_st = orc.OracleScene(spec).render(nthreads=8)
+    assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+    st = tracer.last_stats
+    for k in ("rays_closest", "rays_shadow", "hits_closest", "hits_shadow", "node_tests", "leaf_refs", "tri_tests", "shaded_hits", "pixels", "algorithmic_bytes"):
+        assert st[k] == o_st[k], (k, st[k], o_st[k])
+    assert st["ms_intersect"] > 0 and st["intersect_launches"] >= 2
+
+
+def test_golden_frames_on_gpu(xrt):
+    for fname, spec in (("c1_rgba.npy", xrt.configs.config("C1")), ("c3_96x54_rgba.npy", xrt.configs.crate_grid_scene(96, 54)),
+                        ("h224_48x27_ms16_rgba.npy", xrt.configs.heightfield_scene(48, 27, m=224, multisampling=xrt.abi.MS_FIXED16))):
+        scene, tracer = xrt.configs.build_product(spec)
+        assert np.array_equal(tracer.Render(), np.load(os.path.join(GOLDEN, fname))), fname
+
+
+def test_directional_light_and_transparent_blocker(xrt, orc):
+    """DIR:23-30 (+Direction shading, -Direction shadow rays, Q18) and the alpha of a Transparent blocker
+    as shadow attenuation (RT:489-492).  MaxReflections 0: refraction itself is a 'next' row."""
+    s = xrt.configs.SceneSpec("lights")
+    s.meshes.append((xrt.fixtures.heightfield(48), xrt.configs.material(0.3)))
+    soup = triangle_soup(40, 21, 6.0)
+    soup.v[:, :, 1] += np.float32(12.0)
+    soup = xrt.fixtures.MeshData(soup.v, soup.n, soup.uv, soup.color)
+    s.meshes.append((soup, xrt.configs.material(0.1, transparent=True, refraction_index=1.32)))
+    s.objects.append(([0], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    s.objects.append(([1], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (8.0, 1.0, 8.0)))
+    s.camera = xrt.configs.camera((0, 60, 110), (0, 0, 0))
+    s.lights = [xrt.configs.directional((0.2, 0.9, 0.1), (1.0, 0.9, 0.8), 0.9), xrt.configs.spot((0, 120, 160))]
+    s.max_reflections = 0
+    s = s.with_size(160, 90)
+    scene, tracer = xrt.configs.build_product(s)
+    rgba, rgbf = tracer.Render(want_float=True)
+    o_rgba, o_rgbf, o_st = orc.OracleScene(s).render(nthreads=8)
+    assert o_st["hits_shadow"] > 0
+    assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+
+
+def test_error_conventions_on_gpu(xrt):
+    spec = xrt.configs.config("C1")
+    scene, tracer = xrt.configs.build_product(spec)
+    tracer.AddressMode = 9
+    with pytest.raises(ValueError):       # ArgumentException of MAT:85
+        tracer.Render()
+    tracer.AddressMode = xrt.abi.ADDRESS_WRAP
+    # RenderAsync while busy -> InvalidOperationException (RT:62-63); completion callback fires (RT:435-436)
+    done = threading.Event()
+    tracer.RenderCompleted = lambda t: done.set()
+    th = tracer.RenderAsync()
+    try:
+        with pytest.raises(RuntimeError):
+            if tracer.IsBusy:
+                tracer.RenderAsync()
+            else:
+                raise RuntimeError("finished already")
+    finally:
+        th.join()
+    assert done.is_set() and not tracer.IsBusy and 0.99 <= tracer.Progress <= 1.0
+
+
+def test_full_size_properties_c2(xrt):
+    """C2 at its full 1920x1080 size (too slow for a full oracle frame in a unit test): idempotence, ray
+    accounting, sampled rows against the oracle, and sharded == unsharded."""
+    import torch
+    spec = xrt.configs.config("C2")
+    scene, tracer = xrt.configs.build_product(spec)
+    a = tracer.Render().copy()
+    st = dict(tracer.last_stats)
+    b = tracer.Render().copy()
+    assert np.array_equal(a, b)
+    assert st["pixels"] == 1920 * 1080 and st["rays_closest"] >= st["pixels"] and st["rays_shadow"] == st["shaded_hits"]
+    from oracle import oracle_py as orc
+    o = orc.OracleScene(spec)
+    rows = (530, 546)
+    o_rgba, _, _ = o.render(nthreads=8, rows=rows, want_float=False)
+    assert np.array_equal(a.reshape(1080, 1920)[rows[0]:rows[1]], o_rgba.reshape(1080, 1920)[rows[0]:rows[1]])
+    # image-tile shards rendered one after the other on this GPU, gathered and de-tiled = the whole frame
+    world = 4
+    tx, ty, tpr = C.c_int32(), C.c_int32(), C.c_int32()
+    xrt.abi.lib().xrt_shard_layout(1920, 1080, world, C.byref(tx), C.byref(ty), C.byref(tpr))
+    gathered = torch.zeros(world * tpr.value * 512, dtype=torch.int32, device="cuda")
+    for r in range(world):
+        part = gathered[r * tpr.value * 512:(r + 1) * tpr.value * 512]
+        tracer.RenderDevice(part.data_ptr(), shard_rank=r, shard_count=world)
+    out = torch.zeros(1920 * 1080, dtype=torch.int32, device="cuda")
+    xrt.abi.check(xrt.abi.lib().xrt_detile_device(1920, 1080, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), a)
+
+
+def test_device_pointer_intersect(xrt, orc):
+    import torch
+    spec = xrt.configs.heightfield_scene(160, 90, m=64)
+    scene, tracer = xrt.configs.build_product(spec)
+    o = orc.OracleScene(spec)
+    rays = o.primary_rays()
+    d_rays = torch.from_numpy(rays.view(np.uint8).reshape(-1, 32).copy()).cuda()
+    d_hits = torch.zeros((len(rays), 48), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    xrt.abi.check(xrt.abi.lib().xrt_scene_intersect_device(scene.handle, C.c_void_p(d_rays.data_ptr()), len(rays), C.c_void_p(d_hits.data_ptr()), None))
+    torch.cuda.synchronize()
+    hits = d_hits.cpu().numpy().reshape(-1).view(xrt.HIT_DTYPE)
+    assert hits_equal(o.intersect(rays), hits) == {}

@@ -1,0 +1,184 @@
+"""Host-side logic of the product, checked on the CPU (no GPU, no compute calls):
+  * libxrt.so loads and exports every symbol include/xrt.h declares;
+  * the native octree build (scene_build.cpp) produces the reference's trees (vs the oracle);
+  * the pruned front-to-back traversal state machine (traverse.h), single-stepped by tests/emul,
+    returns the oracle's answer bit for bit — including the leaf-group quirk, ties and ignoreTriangle;
+  * error conventions of the C-ABI."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from util import hits_equal, random_rays, secondary_rays, triangle_soup
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol(xrt):
+    hdr = open(os.path.join(ROOT, "include", "xrt.h")).read()
+    declared = set(re.findall(r"\b(xrt_[a-z_]+)\s*\(", hdr))
+    declared -= {"xrt_scene"}
+    assert declared == set(xrt.abi.SYMBOLS), declared ^ set(xrt.abi.SYMBOLS)
+    lib = xrt.abi.lib()                      # resolves all of them or raises
+    assert lib.xrt_version() == 100
+    assert C.sizeof(xrt.abi.xrt_ray) == 32 and C.sizeof(xrt.abi.xrt_hit) == 48
+    assert lib.xrt_last_error() is not None
+
+
+def test_no_cpu_fallback_and_error_codes(xrt):
+    lib, abi = xrt.abi.lib(), xrt.abi
+    h = C.c_void_p()
+    n = C.c_int(-1)
+    assert lib.xrt_device_count(C.byref(n)) == 0
+    if n.value == 0:
+        assert lib.xrt_scene_create(0, C.byref(h)) == abi.XRT_E_NO_DEVICE
+        assert b"no CPU execution path" in lib.xrt_last_error()
+    assert lib.xrt_scene_create(-5, C.byref(h)) == abi.XRT_E_INVALID_ARG
+    # host-only scene: trees can be built and inspected, nothing can be traced
+    assert lib.xrt_scene_create(-1, C.byref(h)) == 0
+    spec = xrt.configs.config("C1")
+    data, m = spec.meshes[0]
+    from oracle.oracle_py import material_abi
+    mat, keep = material_abi(m)
+    mid = C.c_int32(-1)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    sn = np.ascontiguousarray(data.surface_normal)
+    assert lib.xrt_scene_add_mesh(h, fp(data.v), fp(data.n), fp(data.uv), fp(sn), fp(data.color), data.ntri, C.byref(mat), fp(data.bbox), C.byref(mid)) == 0
+    assert mid.value == 0
+    bad = np.array([7], dtype=np.int32)
+    oid = C.c_int32(-1)
+    eye = np.eye(4, dtype=np.float32).reshape(-1)
+    assert lib.xrt_scene_add_object(h, bad.ctypes.data_as(C.POINTER(C.c_int32)), 1, fp(eye), fp(eye), fp(data.bbox), fp(data.bbox), C.byref(oid)) == abi.XRT_E_INVALID_ARG
+    rays = xrt.rays_array([(0, 0, 5)], [(0, 0, -1)])
+    hits = np.zeros(1, dtype=xrt.HIT_DTYPE)
+    assert lib.xrt_scene_intersect(h, rays.ctypes.data_as(C.POINTER(abi.xrt_ray)), None, 1, hits.ctypes.data_as(C.POINTER(abi.xrt_hit)), None) == abi.XRT_E_NO_DEVICE
+    ok = np.array([0], dtype=np.int32)
+    assert lib.xrt_scene_add_object(h, ok.ctypes.data_as(C.POINTER(C.c_int32)), 1, fp(eye), fp(eye), fp(data.bbox), fp(data.bbox), C.byref(oid)) == 0
+    assert lib.xrt_scene_build(h, 0, 0) == 0
+    nn, nr = C.c_int64(0), C.c_int64(0)
+    assert lib.xrt_scene_get_tree(h, 0, None, C.byref(nn), None, C.byref(nr)) == 0 and (nn.value, nr.value) == (1, 12)
+    cam = xrt.abi.xrt_camera()
+    opts = xrt.abi.xrt_render_opts()
+    out = np.zeros(4, dtype=np.uint32)
+    assert lib.xrt_render(h, C.byref(cam), None, 0, C.byref(opts), out.ctypes.data_as(C.POINTER(C.c_uint32)), None, None) == abi.XRT_E_NO_DEVICE
+    with pytest.raises(xrt.abi.XrtError):
+        abi.check(abi.XRT_E_NO_DEVICE)
+    with pytest.raises(ValueError):
+        abi.check(abi.XRT_E_INVALID_ARG)
+    assert lib.xrt_scene_destroy(h) == 0
+    # shard layout: 64x8 tiles dealt round-robin
+    tx, ty, tpr = C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.xrt_shard_layout(1920, 1080, 8, C.byref(tx), C.byref(ty), C.byref(tpr)) == 0
+    assert (tx.value, ty.value, tpr.value) == (30, 135, 507)
+    assert lib.xrt_shard_layout(100, 20, 3, C.byref(tx), C.byref(ty), C.byref(tpr)) == 0 and (tx.value, ty.value, tpr.value) == (2, 3, 2)
+
+
+SCENES = {
+    "crate": lambda x: x.configs.config("C1"),
+    "grid": lambda x: x.configs.crate_grid_scene(96, 54),
+    "h64": lambda x: x.configs.heightfield_scene(96, 54, m=64),
+    "h224": lambda x: x.configs.heightfield_scene(80, 45, m=224),
+}
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_native_tree_equals_reference_tree(xrt, orc, emul, name):
+    spec = SCENES[name](xrt)
+    o, e = orc.OracleScene(spec), emul.EmulScene(spec)
+    for mesh in (-1, 0):
+        no, ro = o.tree(mesh)
+        ne, re_ = e.tree(mesh)
+        assert no.tobytes() == ne.tobytes() and np.array_equal(ro, re_)
+    st = e.tree_stats(0)
+    no, ro = o.tree(0)
+    assert st["nodes"] == len(no) and st["leaves"] == int(no["is_leaf"].sum())
+    assert st["empty_leaves"] == int(((no["is_leaf"] == 1) & (no["count"] == 0)).sum())
+
+
+def test_tree_sizes_of_the_baseline_fixtures(xrt, emul):
+    # crate(11): 137 nodes / 120 leaves / 16 empty / 2,484 refs / depth 3;
+    # heightfield(224): 25,577 / 22,380 / 10,892 / 257,946 / depth 6
+    e = emul.EmulScene(xrt.configs.crate_grid_scene(16, 16))
+    st, (n, r) = e.tree_stats(0), e.tree(0)
+    assert (st["nodes"], st["leaves"], st["empty_leaves"], len(r), st["max_depth"]) == (137, 120, 16, 2484, 3)
+    ns, rs = e.tree(-1)
+    assert len(ns) == 9 and ns[0]["count"] == 64 and (ns["count"][1:] == 16).all()
+    e = emul.EmulScene(xrt.configs.heightfield_scene(16, 16, m=224))
+    st, (n, r) = e.tree_stats(0), e.tree(0)
+    assert (st["nodes"], st["leaves"], st["empty_leaves"], len(r), st["max_depth"]) == (25577, 22380, 10892, 257946, 6)
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_pruned_traversal_equals_reference_answer(xrt, orc, emul, name):
+    spec = SCENES[name](xrt)
+    o, e = orc.OracleScene(spec), emul.EmulScene(spec)
+    rays = o.primary_rays()
+    ho = o.intersect(rays)
+    assert hits_equal(ho, e.intersect(rays)) == {}
+    sec = secondary_rays(xrt, ho)
+    if len(sec):
+        assert hits_equal(o.intersect(sec), e.intersect(sec)) == {}
+    # mesh-level query (MO:259) in object space
+    assert hits_equal(o.mesh_intersect(0, rays[::5]), e.intersect(rays[::5], mode=1, mesh=0)) == {}
+
+
+def soup_spec(xrt, n, seed, threshold, size):
+    s = xrt.configs.SceneSpec("soup")
+    s.meshes.append((triangle_soup(n, seed, size), xrt.configs.material(0.5)))
+    s.objects.append(([0], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    s.camera = xrt.configs.camera((0, 3, 3), (0, 0, 0))
+    s.lights = [xrt.configs.spot((0, 5, 5))]
+    s.mesh_threshold = threshold
+    return s.with_size(32, 32)
+
+
+@pytest.mark.parametrize("n,seed,threshold,size", [(60, 3, 2, 0.9), (300, 5, 4, 0.5), (2000, 7, 20, 0.15), (500, 9, 50, 1.5)])
+def test_leaf_group_quirk_and_ties_on_triangle_soups(xrt, orc, emul, n, seed, threshold, size):
+    """Large overlapping triangles + tiny thresholds: hits outside their leaf box, triangles missing from
+    leaves they cross (Q5), later buckets holding nearer hits (Q1) — the arg-min formulation must agree."""
+    spec = soup_spec(xrt, n, seed, threshold, size)
+    o, e = orc.OracleScene(spec), emul.EmulScene(spec)
+    rays = random_rays(xrt, 6000, seed + 100)
+    ho = o.intersect(rays)
+    assert ho["hit"].sum() > 500
+    assert hits_equal(ho, e.intersect(rays)) == {}
+    sec = secondary_rays(xrt, ho, seed)
+    assert hits_equal(o.intersect(sec), e.intersect(sec)) == {}
+
+
+def test_instances_rotated_scaled_and_shared_ignore(xrt, orc, emul):
+    """Two-level scene with rotation and non-unit scale (Q6/Q7 awake) and a mesh shared by all instances:
+    ignoreTriangle applies in every instance (Q9)."""
+    s = xrt.configs.SceneSpec("inst")
+    s.meshes.append((xrt.fixtures.crate(3), xrt.configs.material(0.5)))
+    s.meshes.append((triangle_soup(80, 11, 0.4), xrt.configs.material(0.2)))
+    k = 0
+    for ix in range(5):
+        for iz in range(5):
+            rot = (0.1 * ix, 0.37 * iz, 0.05 * (ix + iz))
+            sc = (1.0 + 0.1 * ix, 1.0, 0.8 + 0.1 * iz)
+            s.objects.append(([0] if (k % 3) else [0, 1], (-60.0 + 30.0 * ix, 2.0 * (k % 2), -60.0 + 30.0 * iz), rot, sc))
+            k += 1
+    s.camera = xrt.configs.camera((0, 80, 160), (0, 0, 0))
+    s.lights = [xrt.configs.spot((0, 100, 100))]
+    s = s.with_size(96, 54)
+    o, e = orc.OracleScene(s), emul.EmulScene(s)
+    ns, rs = o.tree(-1)
+    assert len(ns) > 1, "scene octree must split (25 bodies > 20)"
+    rays = o.primary_rays()
+    ho = o.intersect(rays)
+    assert ho["hit"].sum() > 300
+    assert hits_equal(ho, e.intersect(rays)) == {}
+    sec = secondary_rays(xrt, ho)
+    assert hits_equal(o.intersect(sec), e.intersect(sec)) == {}
+
+
+def test_degenerate_rays(xrt, orc, emul):
+    spec = SCENES["h64"](xrt)
+    o, e = orc.OracleScene(spec), emul.EmulScene(spec)
+    nan = float("nan")
+    rays = xrt.rays_array([(0, 50, 0), (0, 50, 0), (0, 50, 0), (1e30, 0, 0), (0, 50, 0), (0, 4.0, 0)],
+                          [(0, 0, 0), (nan, -1, 0), (0, -1, 0), (-1, 0, 0), (1e-7, -1, 1e-7), (0, 1, 0)])
+    assert hits_equal(o.intersect(rays), e.intersect(rays)) == {}

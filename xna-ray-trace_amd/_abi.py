@@ -118,6 +118,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("libxrt.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` (%s)" % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever is loaded first
+        # serves the whole process, and tensors handed to xrt_render_device must belong to the same runtime,
+        # so let torch load its copy first when it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)   # AttributeError if the export is missing

@@ -1,0 +1,66 @@
+// kernels.h — launch interface between xrt_api.cpp and kernels.hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/xrt.h"
+#include "traverse.h"
+
+namespace xrt {
+
+// device view of the shading-side arrays
+struct ShadeView {
+    const f4 *shade;              // SHADE_F4 per global triangle
+    const MaterialRec *materials;
+    const uint32_t *texels;
+    const MeshRec *meshes;
+    const LightRec *lights;
+    int nLights;
+    int addressMode, filtering;
+};
+
+struct IntersectArgs {
+    const xrt_ray *rays;
+    xrt_hit *hits;
+    const int *nDev;    // when non-null the ray count is (*nDev) * nMul, else n
+    int nMul;
+    int n;
+    unsigned *queue;    // zeroed work-queue head of this launch
+    int mode, meshId;
+};
+
+// reference-work counters accumulated on the device (same order as the head of xrt_stats)
+enum { C_RAYS = 0, C_HITS, C_SCENE_NODES, C_INSTANCES, C_MESH_AABB, C_MESH_QUERIES, C_NODES, C_REFS, C_TRIS, C_COUNT };
+
+constexpr int FLAG_MISS = 0, FLAG_HIT = 1;
+
+struct FrameBuffers {
+    xrt_ray *rays[2];
+    int *rayPath[2];
+    xrt_hit *hits;
+    xrt_ray *shadowRays;
+    xrt_hit *shadowHits;
+    int *shadowSrc;
+    f4 *lvlA, *lvlB;          // [(R+1) * P]
+    uint32_t *sampleColor;    // [P]
+    float *sampleF32;         // [3 P] or null
+    int *cnt;                 // ray count per level  [R+2]
+    int *scnt;                // shaded hits per level [R+1]
+    unsigned *queues;         // one per intersect launch [2 (R+1)]
+};
+
+int  intersect_stack_capacity(int needed);   // smallest compiled capacity >= needed, or -1
+void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeeded, int gridBlocks, hipStream_t st);
+int  intersect_blocks_per_cu(int stackNeeded);
+void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long *counters, hipStream_t st);
+void launch_raygen(const RayGenParams &g, xrt_ray *rays, int P, long long pathBase, hipStream_t st);
+void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
+                    const int *rayPath, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level, hipStream_t st);
+void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath,
+                    const int *scnt, const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB, xrt_ray *nextRays,
+                    int *nextPath, int *nextCnt, int P, int level, int maxReflections, hipStream_t st);
+void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P /* level stride */, int maxReflections, uint32_t *sampleColor, float *sampleF32, hipStream_t st);
+void launch_resolve(const RayGenParams &g, const uint32_t *sampleColor, const float *sampleF32, int pixels, long long pixelBase,
+                    uint32_t *out, float *outF32, hipStream_t st);
+void launch_detile(int width, int height, int shardCount, int tilesPerRank, const uint32_t *gathered, uint32_t *out, hipStream_t st);
+
+}  // namespace xrt

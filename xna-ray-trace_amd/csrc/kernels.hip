@@ -1,0 +1,588 @@
+// kernels.hip — hand-written HIP kernels for gfx950 (MI355X, wave64).
+//
+//   k_intersect   the hot kernel: persistent wavefronts pull rays from a global queue; one lane = one
+//                 ISpatialManager.GetRayIntersection query (OSM:312 -> MO:259 -> RE:42); per-lane octree
+//                 stack in LDS ([level][lane], bank == lane, conflict free); lanes that finish are refilled
+//                 in groups chosen with __ballot so the wave stays populated (active-lane compaction).
+//                 Branchy scalar fp32 — no MFMA by design.
+//   k_count       the REFERENCE algorithm's work counters, untimed.
+//   k_raygen      RayTracer.Render ray generation (RT:410-421) in 64x8 tile order.
+//   k_shade_a/b   CastRay shading (RT:516-584, 708-727), IsLightPathObstructed (RT:465-502), lights.
+//   k_compose     the recursion's return path: per-level RGBA8 quantisation (RT:584,705,726,732).
+//   k_resolve     supersample averaging (RT:309) and the framebuffer write (RT:425).
+//
+// Built with -ffp-contract=off: every result must be bit-identical to the oracle.
+#include "kernels.h"
+
+namespace xrt {
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+struct LdsStack {
+    unsigned *base;   // &stk[wave][0][lane]
+    __device__ __forceinline__ unsigned get(int i) const { return base[i * 64]; }
+    __device__ __forceinline__ void set(int i, unsigned v) { base[i * 64] = v; }
+};
+
+struct alignas(16) Hit16 { int i0, i1, i2, i3; };
+
+__device__ __forceinline__ void store_hit(xrt_hit *dst, const HitOut &h) {
+    Hit16 *p = reinterpret_cast<Hit16 *>(dst);
+    p[0] = Hit16{h.hit, h.object, h.mesh, h.tri};
+    p[1] = Hit16{h.leaf, f2i(h.u), f2i(h.v), f2i(h.d)};
+    p[2] = Hit16{f2i(h.wx), f2i(h.wy), f2i(h.wz), 0};
+}
+__device__ __forceinline__ void load_ray(const xrt_ray *src, v3 &o, v3 &d, int &im, int &it) {
+    const f4 *p = reinterpret_cast<const f4 *>(src);
+    f4 a = p[0], b = p[1];
+    o = mk(a.x, a.y, a.z);
+    d = mk(a.w, b.x, b.y);
+    im = f2i(b.z);
+    it = f2i(b.w);
+}
+__device__ __forceinline__ void store_ray(xrt_ray *dst, v3 o, v3 d, int im, int it) {
+    f4 *p = reinterpret_cast<f4 *>(dst);
+    p[0] = f4{o.x, o.y, o.z, d.x};
+    p[1] = f4{d.y, d.z, i2f(im), i2f(it)};
+}
+constexpr int DEAD_RAY = -2;   // ignore_mesh marker of a path without a pixel (edge tiles)
+
+// ---- the hot kernel ------------------------------------------------------------------------------------------
+constexpr int RAY_BATCH = 256;     // rays a wave takes per queue atomic
+constexpr int REFILL_MIN = 24;     // refill as soon as this many lanes are idle
+
+template <int T>
+__global__ __launch_bounds__(256) void k_intersect(SceneView S, IntersectArgs A) {
+    __shared__ unsigned stk[4 * T * 64];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    LdsStack st{&stk[wave * T * 64 + lane]};
+    const int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
+    Lane L;
+    L.state = ST_IDLE;
+    int batchNext = 0, batchEnd = 0;
+    bool exhausted = false;
+    for (;;) {
+        const unsigned long long idle = __ballot(L.state == ST_IDLE);
+        if (idle != 0ull) {
+            const int nIdle = __popcll(idle);
+            if (!exhausted && (nIdle >= REFILL_MIN || idle == ~0ull)) {
+                if (batchNext >= batchEnd) {
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(A.queue, (unsigned)RAY_BATCH);
+                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                    batchNext = (int)base;
+                    batchEnd = min((int)base + RAY_BATCH, n);
+                    if ((int)base >= n || (int)base < 0) exhausted = true;
+                }
+                if (!exhausted) {
+                    const int take = min(nIdle, batchEnd - batchNext);
+                    const int rank = lanes_below(idle);
+                    if (L.state == ST_IDLE && rank < take) {
+                        const int idx = batchNext + rank;
+                        v3 o, d; int im, it;
+                        load_ray(A.rays + idx, o, d, im, it);
+                        if (im == DEAD_RAY) { L.rayIndex = idx; L.sfound = 0; L.state = ST_FINISH; }
+                        else lane_begin(L, S, o, d, im, it, idx, A.mode, A.meshId);
+                    }
+                    batchNext += take;
+                }
+            }
+            if (exhausted && idle == ~0ull) break;
+        }
+        if (L.state == ST_SCENE) advance_scene(L, S, st);
+        if (L.state == ST_NODE) advance_node(L, S, st, A.mode);
+        if (L.state == ST_LEAF) advance_leaf(L, S);
+        if (L.state == ST_FINISH) {
+            store_hit(A.hits + L.rayIndex, lane_result(L, S, A.mode));
+            L.state = ST_IDLE;
+        }
+    }
+}
+
+int intersect_stack_capacity(int needed) {
+    const int caps[] = {8, 12, 16, 24, 40, 72};
+    for (int c : caps) if (needed <= c) return c;
+    return -1;
+}
+template <int T> static int bpc() {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_intersect<T>, 256, 0) != hipSuccess || nb < 1) nb = 1;
+    return nb > 8 ? 8 : nb;
+}
+int intersect_blocks_per_cu(int stackNeeded) {
+    switch (intersect_stack_capacity(stackNeeded)) {
+        case 8: return bpc<8>();
+        case 12: return bpc<12>();
+        case 16: return bpc<16>();
+        case 24: return bpc<24>();
+        case 40: return bpc<40>();
+        case 72: return bpc<72>();
+    }
+    return 1;
+}
+void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeeded, int gridBlocks, hipStream_t st) {
+    dim3 g((unsigned)gridBlocks), b(256);
+    switch (intersect_stack_capacity(stackNeeded)) {
+        case 8: hipLaunchKernelGGL(k_intersect<8>, g, b, 0, st, S, A); break;
+        case 12: hipLaunchKernelGGL(k_intersect<12>, g, b, 0, st, S, A); break;
+        case 16: hipLaunchKernelGGL(k_intersect<16>, g, b, 0, st, S, A); break;
+        case 24: hipLaunchKernelGGL(k_intersect<24>, g, b, 0, st, S, A); break;
+        case 40: hipLaunchKernelGGL(k_intersect<40>, g, b, 0, st, S, A); break;
+        default: hipLaunchKernelGGL(k_intersect<72>, g, b, 0, st, S, A); break;
+    }
+}
+
+// ---- reference work counters (untimed) ---------------------------------------------------------------------------
+// Counts what the C# code path does for each ray: every slab test of OSM:460 / MO:331, every
+// body visit, mesh box test and mesh query of the scene buckets up to and including the first one with a
+// hit (OSM:334), and every leaf-list entry / triangle test of the mesh buckets up to and including the
+// first with a hit (MO:281).  The winning keys come from the same state machine the hot kernel runs.
+struct LocalStack {
+    unsigned w[160];
+    __device__ __forceinline__ unsigned get(int i) const { return w[i]; }
+    __device__ __forceinline__ void set(int i, unsigned v) { w[i] = v; }
+};
+
+__device__ void count_mesh(const SceneView &S, const RayPre &r, int mesh, int ignoreId, bool mfound, float mKey,
+                           unsigned long long *c, LocalStack &stk) {
+    int sp = 0;
+    int blk = S.meshes[mesh].rootNode >> 3, mask = 1;
+    for (;;) {
+        if (mask == 0) {
+            if (sp == 0) break;
+            unsigned wv = stk.get(--sp);
+            blk = (int)(wv >> 8); mask = (int)(wv & 0xffu);
+            continue;
+        }
+        int ch = ctz32((unsigned)mask);
+        mask &= mask - 1;
+        int node = blk * 8 + ch;
+        f4 lo = S.nodes[2 * node], hi = S.nodes[2 * node + 1];
+        int a = f2i(lo.w), b = f2i(hi.w);
+        c[C_NODES]++;
+        float key;
+        if (b < 0) {
+            if (!slab(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, key)) continue;
+            int cnt = b & 0x0fffffff;
+            if (!mfound || key <= mKey) {
+                c[C_REFS] += (unsigned long long)cnt;
+                int ign = 0;
+                if (ignoreId >= 0) for (int i = 0; i < cnt; i++) ign += (S.refTri[a + i] == ignoreId) ? 1 : 0;
+                c[C_TRIS] += (unsigned long long)(cnt - ign);
+            }
+        } else {
+            int side = b & NODE_SIDE_MASK;
+            f4 olo = S.ownBox[2 * side], ohi = S.ownBox[2 * side + 1];
+            if (!slab(r, olo.x, olo.y, olo.z, ohi.x, ohi.y, ohi.z, key)) continue;
+            if (mask) stk.set(sp++, ((unsigned)blk << 8) | (unsigned)mask);
+            blk = a >> 3; mask = 0xff;
+        }
+    }
+}
+
+__device__ void run_query(Lane &L, const SceneView &S, LocalStack &stk, int mode) {
+    while (L.state != ST_FINISH) {
+        if (L.state == ST_SCENE) advance_scene(L, S, stk);
+        else if (L.state == ST_NODE) advance_node(L, S, stk, mode);
+        else advance_leaf(L, S);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_count(SceneView S, IntersectArgs A, unsigned long long *counters) {
+    const int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
+    unsigned long long c[C_COUNT];
+    for (int i = 0; i < C_COUNT; i++) c[i] = 0;
+    LocalStack stk, stk2;
+    for (int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x); idx < n; idx += (int)(gridDim.x * blockDim.x)) {
+        v3 o, d; int im, it;
+        load_ray(A.rays + idx, o, d, im, it);
+        if (im == DEAD_RAY) continue;
+        c[C_RAYS]++;
+        Lane L;
+        lane_begin(L, S, o, d, im, it, idx, A.mode, A.meshId);
+        run_query(L, S, stk, A.mode);
+        if (L.sfound) c[C_HITS]++;
+        if (A.mode == MODE_MESH) {
+            c[C_MESH_QUERIES]++;
+            count_mesh(S, L.w, A.meshId, L.ignoreId, L.mfound != 0, L.mKey, c, stk);
+            continue;
+        }
+        const bool sfound = L.sfound != 0;
+        const float sbKey = L.sbKey;
+        const int ignoreId = L.ignoreId;
+        const RayPre w = L.w;
+        int sp = 0, blk = 0, mask = 1;
+        for (;;) {
+            if (mask == 0) {
+                if (sp == 0) break;
+                unsigned wv = stk2.get(--sp);
+                blk = (int)(wv >> 8); mask = (int)(wv & 0xffu);
+                continue;
+            }
+            int ch = ctz32((unsigned)mask);
+            mask &= mask - 1;
+            int node = blk * 8 + ch;
+            f4 lo = S.snodes[2 * node], hi = S.snodes[2 * node + 1];
+            int a = f2i(lo.w), b = f2i(hi.w);
+            c[C_SCENE_NODES]++;
+            float key;
+            if (!slab(w, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, key)) continue;
+            if (b >= 0) {
+                if (mask) stk2.set(sp++, ((unsigned)blk << 8) | (unsigned)mask);
+                blk = a >> 3; mask = 0xff;
+                continue;
+            }
+            int cnt = b & 0x0fffffff;
+            if (sfound && key > sbKey) continue;
+            for (int oi = 0; oi < cnt; oi++) {
+                const ObjRec &ob = S.objects[S.srefs[a + oi]];
+                c[C_INSTANCES]++;
+                v3 v1 = transform(w.o, ob.invWorld);
+                v3 v2 = transform(add(w.o, w.d), ob.invWorld);
+                RayPre r = make_ray(v1, normalize(sub(v2, v1)));
+                for (int mi = 0; mi < ob.meshCount; mi++) {
+                    int m = S.objMesh[ob.meshStart + mi];
+                    const MeshRec &mr = S.meshes[m];
+                    c[C_MESH_AABB]++;
+                    float k;
+                    if (!slab(r, mr.bmin[0], mr.bmin[1], mr.bmin[2], mr.bmax[0], mr.bmax[1], mr.bmax[2], k)) continue;
+                    c[C_MESH_QUERIES]++;
+                    Lane Q;
+                    lane_begin(Q, S, r.o, r.d, -1, -1, idx, MODE_MESH, m);
+                    Q.ignoreId = ignoreId;
+                    run_query(Q, S, stk, MODE_MESH);
+                    count_mesh(S, r, m, ignoreId, Q.mfound != 0, Q.mKey, c, stk);
+                }
+            }
+        }
+    }
+    for (int i = 0; i < C_COUNT; i++) {
+        unsigned long long v = c[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane_id() == 0 && v) atomicAdd(&counters[i], v);
+    }
+}
+
+void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long *counters, hipStream_t st) {
+    hipLaunchKernelGGL(k_count, dim3(1024), dim3(256), 0, st, S, A, counters);
+}
+
+// ---- ray generation (RT:410-421 / RT:224-232) ----------------------------------------------------------------------
+// Path p of a frame: pixel slot = p / samples (64x8 tiles, row-major inside a tile, tiles dealt round-robin
+// to shards), sample = p % samples.
+__device__ __forceinline__ bool path_pixel(const RayGenParams &g, long long pix, int &x, int &y) {
+    long long slot = pix >> 9;
+    int within = (int)(pix & 511);
+    long long t = slot * g.shardCount + g.shardRank;
+    if (t >= (long long)g.tilesX * g.tilesY) return false;
+    int tx = (int)(t % g.tilesX), ty = (int)(t / g.tilesX);
+    x = tx * XRT_TILE_W + (within & 63);
+    y = ty * XRT_TILE_H + (within >> 6);
+    return x < g.width && y < g.height;
+}
+
+__global__ __launch_bounds__(256) void k_raygen(RayGenParams g, xrt_ray *rays, int P, long long pathBase) {
+    for (int p = (int)(blockIdx.x * blockDim.x + threadIdx.x); p < P; p += (int)(gridDim.x * blockDim.x)) {
+        long long gp = pathBase + p;
+        int s = (int)(gp % g.samples);
+        int x, y;
+        if (!path_pixel(g, gp / g.samples, x, y)) { store_ray(rays + p, mk(0, 0, 0), mk(0, 0, 0), DEAD_RAY, -1); continue; }
+        float sx = (float)x, sy = (float)y;
+        if (g.samples == 16) {   // XRT_MS_FIXED16: corner q = s/4 at +-0.25, sub-sample s%4 at +-0.125 (RT:218-305)
+            int q = s >> 2, r = s & 3;
+            sx = (sx + ((q & 1) ? 0.25f : -0.25f)) + ((r & 1) ? 0.125f : -0.125f);
+            sy = (sy + ((q & 2) ? 0.25f : -0.25f)) + ((r & 2) ? 0.125f : -0.125f);
+        }
+        v3 nearP = unproject(g, sx, sy, 0.0f);   // RT:415
+        v3 farP = unproject(g, sx, sy, 1.0f);    // RT:419
+        v3 dir = normalize(sub(farP, nearP));    // RT:420-421
+        store_ray(rays + p, nearP, dir, -1, -1);
+    }
+}
+void launch_raygen(const RayGenParams &g, xrt_ray *rays, int P, long long pathBase, hipStream_t st) {
+    int blocks = (P + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, g, rays, P, pathBase);
+}
+
+// ---- shading ----------------------------------------------------------------------------------------------------------
+struct ShadePoint {
+    v3 normal, world;
+    int gtri, mat;
+};
+__device__ __forceinline__ void load_hit(const xrt_hit *src, int &hit, int &object, int &mesh, int &tri, float &u, float &v, float &d, v3 &w) {
+    const Hit16 *p = reinterpret_cast<const Hit16 *>(src);
+    Hit16 a = p[0], b = p[1], c = p[2];
+    hit = a.i0; object = a.i1; mesh = a.i2; tri = a.i3;
+    u = i2f(b.i1); v = i2f(b.i2); d = i2f(b.i3);
+    w = mk(i2f(c.i0), i2f(c.i1), i2f(c.i2));
+}
+// RT:520-531 fragment normal
+__device__ __forceinline__ v3 fragment_normal(const ShadeView &V, int gtri, int matFlags, float u, float v) {
+    const f4 *s = V.shade + (size_t)gtri * 6;
+    if (matFlags & MAT_INTERP) {
+        f4 s0 = s[0], s1 = s[1], s2 = s[2];
+        v3 n1 = mk(s0.x, s0.y, s0.z), n2 = mk(s1.x, s1.y, s1.z), n3 = mk(s2.x, s2.y, s2.z);
+        v3 a = sub(n2, n1), b = sub(n3, n1);
+        return normalize(add(add(n1, scale(a, u)), scale(b, v)));
+    }
+    f4 s5 = s[5];
+    return mk(s5.x, s5.y, s5.z);
+}
+// RT:469-479 direction and distance towards a light
+__device__ __forceinline__ void light_dir(const LightRec &L, v3 world, v3 &dir, float &dist) {
+    if (L.kind == 0) {
+        v3 t = sub(mk(L.px, L.py, L.pz), world);
+        dist = length(t);
+        dir = normalize(t);
+    } else {
+        dir = neg(mk(L.dx, L.dy, L.dz));
+        dist = FLT_MAX;
+    }
+}
+
+// Stage A of CastRay for one generation of rays: misses terminate their path (RT:729-733); every hit
+// emits one shadow ray per light (RT:535-537 -> RT:482-485), compacted with one atomic per wave.
+__global__ __launch_bounds__(256) void k_shade_a(SceneView S, ShadeView V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev,
+                                                 int nHost, const int *rayPath, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc,
+                                                 int *scnt, int P, int level) {
+    const int n = nDev ? *nDev : nHost;
+    const int stride = (int)(gridDim.x * blockDim.x);
+    const int rounds = (n + stride - 1) / stride;
+    for (int it = 0; it < rounds; it++) {
+        const int i = it * stride + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        int hit = 0, object, mesh = 0, tri = 0;
+        float u = 0, v = 0, d = 0;
+        v3 w = mk(0, 0, 0);
+        int p = 0;
+        if (i < n) {
+            load_hit(hits + i, hit, object, mesh, tri, u, v, d, w);
+            p = rayPath ? rayPath[i] : i;
+            if (!hit) lvlB[(size_t)level * P + p] = f4{0, 0, 0, i2f(FLAG_MISS)};
+        }
+        const unsigned long long m = __ballot(hit != 0);
+        if (m == 0ull) continue;
+        int base = 0;
+        const int leader = (int)__builtin_ctzll(m);
+        if (lane_id() == leader) base = atomicAdd(scnt, (int)__popcll(m));
+        base = __shfl(base, leader);
+        if (hit) {
+            const int slot = base + lanes_below(m);
+            shadowSrc[slot] = i;
+            for (int l = 0; l < V.nLights; l++) {
+                v3 dir; float dist;
+                light_dir(V.lights[l], w, dir, dist);
+                store_ray(shadowRays + (size_t)slot * V.nLights + l, w, dir, mesh, tri);   // ignore = shaded triangle (RT:485)
+            }
+        }
+    }
+}
+void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
+                    const int *rayPath, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level, hipStream_t st) {
+    hipLaunchKernelGGL(k_shade_a, dim3(2048), dim3(256), 0, st, S, V, rays, hits, nDev, nHost, rayPath, lvlB, shadowRays, shadowSrc, scnt, P, level);
+}
+
+// MAT:71-160 LookupUV: address mode + point sample
+__device__ __forceinline__ v3 lookup_uv(const ShadeView &V, const MaterialRec &M, float ux, float uy) {
+    if (V.addressMode == XRT_ADDRESS_WRAP) {   // MAT:125-136
+        if (ux > 1.0f) ux = fmod1(ux);
+        if (uy > 1.0f) uy = fmod1(uy);
+        if (ux < 0.0f) ux = 1.0f + fmod1(ux);
+        if (uy < 0.0f) uy = 1.0f + fmod1(uy);
+    } else if (V.addressMode == XRT_ADDRESS_CLAMP) {   // MAT:138-143
+        ux = (ux > 1.0f) ? 1.0f : ux; ux = (ux < 0.0f) ? 0.0f : ux;
+        uy = (uy > 1.0f) ? 1.0f : uy; uy = (uy < 0.0f) ? 0.0f : uy;
+    } else {   // MAT:102-123
+        float ox = ux, oy = uy;
+        if (ux > 1.0f) ux = fmod1(ux);
+        if (uy > 1.0f) uy = fmod1(uy);
+        if (ux < 0.0f) ux = 1.0f + fmod1(ux);
+        if (uy < 0.0f) uy = 1.0f + fmod1(uy);
+        if (((int)(ox - ux)) % 2 == 0) ux = 1.0f - ux;
+        if (((int)(oy - uy)) % 2 == 0) uy = 1.0f - uy;
+    }
+    int x = (int)(ux * (float)(M.texWidth - 1));    // MAT:147
+    int y = (int)(uy * (float)(M.texHeight - 1));   // MAT:148
+    long long idx = (long long)M.texWidth * y + x;
+    if (idx < 0 || idx >= (long long)M.texWidth * M.texHeight) idx = 0;   // the C# reads through a raw pointer; guard NaN uv
+    uint32_t argb = V.texels[M.texOffset + idx];
+    const float BYTE_RECIPROCAL = 1.0f / 255.0f;   // MAT:27
+    return mk((float)((argb >> 16) & 0xffu) * BYTE_RECIPROCAL, (float)((argb >> 8) & 0xffu) * BYTE_RECIPROCAL, (float)(argb & 0xffu) * BYTE_RECIPROCAL);
+}
+
+// Stage B: light accumulation with the shadow answers (RT:534-542), surface colour (RT:568-581 / 711-724),
+// the level record the return path needs, and the reflection ray of the next generation (RT:545-559).
+__global__ __launch_bounds__(256) void k_shade_b(SceneView S, ShadeView V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath,
+                                                 const int *scnt, const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB,
+                                                 xrt_ray *nextRays, int *nextPath, int *nextCnt, int P, int level, int maxReflections) {
+    const int n = *scnt;
+    const int stride = (int)(gridDim.x * blockDim.x);
+    const int rounds = (n + stride - 1) / stride;
+    for (int it = 0; it < rounds; it++) {
+        const int s = it * stride + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        const bool valid = s < n;
+        v3 w = mk(0, 0, 0), normal = mk(0, 0, 0), rdir = mk(0, 0, 0);
+        int mesh = 0, tri = 0, p = 0;
+        if (valid) {
+            const int i = shadowSrc[s];
+            int hit, object; float u, v, d;
+            load_hit(hits + i, hit, object, mesh, tri, u, v, d, w);
+            p = rayPath ? rayPath[i] : i;
+            const int gtri = V.meshes[mesh].triBase + tri;
+            const MaterialRec M = V.materials[V.meshes[mesh].material];
+            normal = fragment_normal(V, gtri, M.flags, u, v);
+            v3 lightResult = mk(0, 0, 0);
+            for (int l = 0; l < V.nLights; l++) {
+                const LightRec &Lt = V.lights[l];
+                v3 dir; float dist;
+                light_dir(Lt, w, dir, dist);
+                int sh, sobj, smesh, stri; float su, sv, sd; v3 sw;
+                load_hit(shadowHits + (size_t)s * V.nLights + l, sh, sobj, smesh, stri, su, sv, sd, sw);
+                float lightAmount = 0.0f;   // RT:485-501
+                if (sh && sd < dist) {
+                    const MaterialRec SM = V.materials[V.meshes[smesh].material];
+                    if (SM.flags & MAT_TRANSPARENT) lightAmount = V.shade[(size_t)(V.meshes[smesh].triBase + stri) * 6 + 3].w;
+                    else lightAmount = 1.0f;
+                }
+                if (lightAmount != 1.0f) lightResult = add(lightResult, scale(light_for_fragment(Lt, w, normal), 1.0f - lightAmount));   // RT:538-541
+            }
+            v3 surf;
+            const f4 *sr = V.shade + (size_t)gtri * 6;
+            if (M.flags & MAT_TEXTURE) {   // RT:568-575
+                f4 s0 = sr[0], s1 = sr[1], s2 = sr[2], s4 = sr[4];
+                float uv1x = s0.w, uv1y = s1.w, uv2x = s2.w, uv2y = s4.x, uv3x = s4.y, uv3y = s4.z;
+                float ax = uv2x - uv1x, ay = uv2y - uv1y, bx = uv3x - uv1x, by = uv3y - uv1y;
+                float ix = (uv1x + ax * u) + bx * v, iy = (uv1y + ay * u) + by * v;
+                surf = lookup_uv(V, M, ix, iy);
+            } else {
+                f4 c = sr[3];
+                surf = mk(c.x, c.y, c.z);
+            }
+            lvlA[(size_t)level * P + p] = f4{lightResult.x, lightResult.y, lightResult.z, M.reflectiveness};
+            lvlB[(size_t)level * P + p] = f4{surf.x, surf.y, surf.z, i2f(FLAG_HIT)};
+            if (level < maxReflections) {
+                v3 o, d; int im, itri;
+                load_ray(rays + i, o, d, im, itri);
+                rdir = normalize(reflect(d, normal));   // RT:549-550
+            }
+        }
+        if (level < maxReflections) {   // wave-uniform
+            const unsigned long long m = __ballot(valid);
+            if (m == 0ull) continue;
+            int base = 0;
+            const int leader = (int)__builtin_ctzll(m);
+            if (lane_id() == leader) base = atomicAdd(nextCnt, (int)__popcll(m));
+            base = __shfl(base, leader);
+            if (valid) {
+                const int slot = base + lanes_below(m);
+                store_ray(nextRays + slot, w, rdir, mesh, tri);   // origin = result.triangle (RT:559)
+                nextPath[slot] = p;
+            }
+        }
+    }
+}
+void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath, const int *scnt,
+                    const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB, xrt_ray *nextRays, int *nextPath, int *nextCnt,
+                    int P, int level, int maxReflections, hipStream_t st) {
+    hipLaunchKernelGGL(k_shade_b, dim3(2048), dim3(256), 0, st, S, V, rays, hits, rayPath, scnt, shadowSrc, shadowHits, lvlA, lvlB, nextRays,
+                       nextPath, nextCnt, P, level, maxReflections);
+}
+
+// The return path of the CastRay recursion: deepest generation first, one RGBA8 quantisation per level.
+__global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32) {
+    for (int p = (int)(blockIdx.x * blockDim.x + threadIdx.x); p < count; p += (int)(gridDim.x * blockDim.x)) {
+        int kd = 0;
+        int flag;
+        for (;;) {
+            flag = f2i(lvlB[(size_t)kd * P + p].w);
+            if (flag == FLAG_MISS || kd == maxReflections) break;
+            kd++;
+        }
+        v3 cv = mk(0, 0, 0);
+        uint32_t col;
+        if (flag == FLAG_MISS) col = pack_color(mk(0, 0, 0));   // RT:732
+        else {   // RT:708-727: generation MaxReflections has no reflection term
+            f4 a = lvlA[(size_t)kd * P + p], b = lvlB[(size_t)kd * P + p];
+            cv = mul(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z));
+            col = pack_color(cv);
+        }
+        for (int k = kd - 1; k >= 0; k--) {   // RT:584 + RT:705
+            f4 a = lvlA[(size_t)k * P + p], b = lvlB[(size_t)k * P + p];
+            cv = mul(lerp(unpack_color(col), mk(b.x, b.y, b.z), 1.0f - a.w), mk(a.x, a.y, a.z));
+            col = pack_color(cv);
+        }
+        sampleColor[p] = col;
+        if (sampleF32) { sampleF32[3 * (size_t)p] = cv.x; sampleF32[3 * (size_t)p + 1] = cv.y; sampleF32[3 * (size_t)p + 2] = cv.z; }
+    }
+}
+void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32, hipStream_t st) {
+    int blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_compose, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, lvlA, lvlB, count, P, maxReflections, sampleColor, sampleF32);
+}
+
+// Supersample averaging (RT:309: mean of four quantised colours, re-quantised, twice for 16 samples) and the
+// framebuffer write renderTargetData[y*W + x] = color (RT:425) — or the shard's tile-contiguous buffer.
+__global__ __launch_bounds__(256) void k_resolve(RayGenParams g, const uint32_t *sampleColor, const float *sampleF32, int pixels, long long pixelBase,
+                                                 uint32_t *out, float *outF32) {
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < pixels; i += (int)(gridDim.x * blockDim.x)) {
+        long long pix = pixelBase + i;
+        int x, y;
+        bool ok = path_pixel(g, pix, x, y);
+        uint32_t col;
+        v3 cv;
+        if (g.samples == 1) {
+            col = sampleColor[i];
+            cv = sampleF32 ? mk(sampleF32[3 * (size_t)i], sampleF32[3 * (size_t)i + 1], sampleF32[3 * (size_t)i + 2]) : unpack_color(col);
+        } else {
+            uint32_t corner[4];
+            for (int q = 0; q < 4; q++) {
+                const uint32_t *s = sampleColor + (size_t)i * 16 + q * 4;
+                v3 sum = add(add(add(unpack_color(s[0]), unpack_color(s[1])), unpack_color(s[2])), unpack_color(s[3]));
+                corner[q] = pack_color(divf(sum, 4.0f));
+            }
+            v3 sum = add(add(add(unpack_color(corner[0]), unpack_color(corner[1])), unpack_color(corner[2])), unpack_color(corner[3]));
+            col = pack_color(divf(sum, 4.0f));
+            cv = unpack_color(col);
+        }
+        if (g.shardCount > 1) {
+            out[pix] = ok ? col : 0u;
+        } else if (ok) {
+            size_t o = (size_t)y * g.width + x;
+            out[o] = col;
+            if (outF32) { outF32[3 * o] = cv.x; outF32[3 * o + 1] = cv.y; outF32[3 * o + 2] = cv.z; }
+        }
+    }
+}
+void launch_resolve(const RayGenParams &g, const uint32_t *sampleColor, const float *sampleF32, int pixels, long long pixelBase, uint32_t *out,
+                    float *outF32, hipStream_t st) {
+    int blocks = (pixels + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, g, sampleColor, sampleF32, pixels, pixelBase, out, outF32);
+}
+
+// rank-major gathered tiles -> W*H frame (rank 0 after the RCCL gather)
+__global__ __launch_bounds__(256) void k_detile(int width, int height, int shardCount, int tilesPerRank, int tilesX, int tilesY,
+                                                const uint32_t *gathered, uint32_t *out) {
+    const long long total = (long long)shardCount * tilesPerRank * 512;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int rank = (int)(i / ((long long)tilesPerRank * 512));
+        long long rem = i % ((long long)tilesPerRank * 512);
+        long long slot = rem >> 9;
+        int within = (int)(rem & 511);
+        long long t = slot * shardCount + rank;
+        if (t >= (long long)tilesX * tilesY) continue;
+        int x = (int)(t % tilesX) * XRT_TILE_W + (within & 63), y = (int)(t / tilesX) * XRT_TILE_H + (within >> 6);
+        if (x < width && y < height) out[(size_t)y * width + x] = gathered[i];
+    }
+}
+void launch_detile(int width, int height, int shardCount, int tilesPerRank, const uint32_t *gathered, uint32_t *out, hipStream_t st) {
+    int tilesX = (width + XRT_TILE_W - 1) / XRT_TILE_W, tilesY = (height + XRT_TILE_H - 1) / XRT_TILE_H;
+    hipLaunchKernelGGL(k_detile, dim3(2048), dim3(256), 0, st, width, height, shardCount, tilesPerRank, tilesX, tilesY, gathered, out);
+}
+
+}  // namespace xrt

@@ -54,6 +54,7 @@ struct MeshBuilder {
     std::string &err;
     int dfs = 0;
     static constexpr int kMaxLevel = 64;
+    static constexpr int kMaxNodes = 1 << 24;
 
     bool tri_in(const Box &b, int tri) const {   // MO:226-228: any of the three vertices inside-or-on
         const float *p = &m.v[(size_t)tri * 9];
@@ -78,7 +79,7 @@ struct MeshBuilder {
             uniValid = !list.empty();
             return true;
         }
-        if (level >= kMaxLevel) {
+        if (level >= kMaxLevel || t.nodeCount > kMaxNodes) {
             err = "MeshOctree.BuildTree would not terminate: more than the item threshold triangles share a vertex (MO:84-96 has no depth limit)";
             return false;
         }
@@ -180,7 +181,7 @@ struct SceneBuilder {
             t.leafCount++;
             return true;
         }
-        if (level >= 24) { err = "OctreeSpatialManager.BuildTree would not terminate (OSM:101-113 has no depth limit)"; return false; }
+        if (level >= 24 || t.nodeCount > (1 << 20)) { err = "OctreeSpatialManager.BuildTree would not terminate (OSM:101-113 has no depth limit)"; return false; }
         push_info(t, box, false, (int)list.size(), myDfs, level, -1);
         t.interiors++;
         const int first = alloc_block(t);

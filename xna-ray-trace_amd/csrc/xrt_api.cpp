@@ -1,0 +1,621 @@
+// xrt_api.cpp — the C-ABI of include/xrt.h: scene upload, HBM residency, and the per-frame wavefront
+// schedule that replaces the body of RayTracer.RenderInternal (RT:105-120).  Compiled by hipcc (host side
+// uses the HIP runtime API); all arithmetic of the path runs in kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/xrt.h"
+#include "kernels.h"
+#include "scene_host.h"
+
+using namespace xrt;
+
+namespace {
+
+thread_local std::string g_err = "";
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHECK(expr)                                                                                         \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? XRT_E_OOM : XRT_E_HIP, "%s failed: %s (%s:%d)", #expr,     \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                            \
+    } while (0)
+
+constexpr int MAX_CHUNK_PATHS = 1 << 22;   // paths in flight per chunk (multiple of 512 * 16)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t n) {
+        if (n <= cap && p) return XRT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        if (n == 0) n = 1;
+        HIPCHECK(hipMalloc((void **)&p, n * sizeof(T)));
+        cap = n;
+        return XRT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+template <class T>
+int upload(DevBuf<T> &b, const std::vector<T> &v) {
+    int rc = b.ensure(v.size());
+    if (rc != XRT_OK) return rc;
+    if (!v.empty()) HIPCHECK(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return XRT_OK;
+}
+
+}  // namespace
+
+struct xrt_scene {
+    int device = -1;   // -1: host-only scene (inspection of the built trees; every compute call fails)
+    HostScene hs;
+    // HBM-resident scene
+    DevBuf<f4> nodes, ownBox, triRec, snodes, shade;
+    DevBuf<int> nodeDfs, refTri, srefs, objMesh;
+    DevBuf<MeshRec> meshes;
+    DevBuf<ObjRec> objects;
+    DevBuf<MaterialRec> materials;
+    DevBuf<uint32_t> texels;
+    SceneView view{};
+    bool resident = false;
+    int numCUs = 256;
+    int stackNeeded = 2;
+    int blocksPerCU = 1;
+    hipStream_t stream = nullptr;
+    // per-frame work buffers
+    DevBuf<xrt_ray> rays0, rays1, shadowRays, apiRays;
+    DevBuf<xrt_hit> hits, shadowHits, apiHits;
+    DevBuf<int> path0, path1, shadowSrc, cnts;
+    DevBuf<unsigned> queues;
+    DevBuf<f4> lvlA, lvlB;
+    DevBuf<uint32_t> sampleColor, outRGBA;
+    DevBuf<float> sampleF32, outF32;
+    DevBuf<LightRec> lights;
+    DevBuf<unsigned long long> counters;
+    std::vector<hipEvent_t> events;
+    std::atomic<bool> busy{false};
+    std::atomic<float> progress{0.0f};
+
+    ~xrt_scene() {
+        if (device >= 0) {
+            (void)hipSetDevice(device);
+            for (auto e : events) (void)hipEventDestroy(e);
+            if (stream) (void)hipStreamDestroy(stream);
+            nodes.release(); ownBox.release(); triRec.release(); snodes.release(); shade.release();
+            nodeDfs.release(); refTri.release(); srefs.release(); objMesh.release(); meshes.release();
+            objects.release(); materials.release(); texels.release();
+            rays0.release(); rays1.release(); shadowRays.release(); apiRays.release(); hits.release();
+            shadowHits.release(); apiHits.release(); path0.release(); path1.release(); shadowSrc.release();
+            cnts.release(); queues.release(); lvlA.release(); lvlB.release(); sampleColor.release();
+            outRGBA.release(); sampleF32.release(); outF32.release(); lights.release(); counters.release();
+        }
+    }
+};
+
+namespace {
+
+struct BusyGuard {
+    xrt_scene *s;
+    bool owned;
+    explicit BusyGuard(xrt_scene *sc) : s(sc) {
+        bool expected = false;
+        owned = s->busy.compare_exchange_strong(expected, true);
+    }
+    ~BusyGuard() { if (owned) s->busy.store(false); }
+};
+
+int need_device(xrt_scene *s, const char *fn) {
+    if (!s) return fail(XRT_E_INVALID_ARG, "%s: null scene", fn);
+    if (s->device < 0) return fail(XRT_E_NO_DEVICE, "%s: host-only scene (created with device -1); libxrt has no CPU execution path", fn);
+    if (!s->hs.built || !s->resident) return fail(XRT_E_NOT_BUILT, "%s: call xrt_scene_build first", fn);
+    HIPCHECK(hipSetDevice(s->device));
+    return XRT_OK;
+}
+
+hipEvent_t get_event(xrt_scene *s, size_t i) {
+    while (s->events.size() <= i) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        s->events.push_back(e);
+    }
+    return s->events[i];
+}
+
+int persistent_grid(xrt_scene *s, long long nHost) {
+    int full = s->numCUs * s->blocksPerCU;
+    if (nHost >= 0) {
+        long long want = (nHost + 255) / 256;   // one block covers >= 256 rays
+        if (want < 1) want = 1;
+        if (want < full) return (int)want;
+    }
+    return full;
+}
+
+void fill_stats(xrt_stats *st, const unsigned long long *c /* 2*C_COUNT: closest, shadow */, unsigned long long shaded, unsigned long long pixels) {
+    const unsigned long long *a = c, *b = c + C_COUNT;
+    st->rays_closest = a[C_RAYS]; st->rays_shadow = b[C_RAYS];
+    st->hits_closest = a[C_HITS]; st->hits_shadow = b[C_HITS];
+    st->scene_node_tests = a[C_SCENE_NODES] + b[C_SCENE_NODES];
+    st->instance_visits = a[C_INSTANCES] + b[C_INSTANCES];
+    st->mesh_aabb_tests = a[C_MESH_AABB] + b[C_MESH_AABB];
+    st->mesh_queries = a[C_MESH_QUERIES] + b[C_MESH_QUERIES];
+    st->node_tests = a[C_NODES] + b[C_NODES];
+    st->leaf_refs = a[C_REFS] + b[C_REFS];
+    st->tri_tests = a[C_TRIS] + b[C_TRIS];
+    st->shaded_hits = shaded;
+    st->pixels = pixels;
+    // per query 32 (ray in) + 48 (hit out) + 32 N_node + 4 N_ref + 48 N_tri, two-level terms
+    // 32 N_scene_node + 64 N_instance + 24 N_mesh_aabb + 64 per hit (World); shading 76 + 4 per shaded hit; 4 per pixel.
+    unsigned long long rays = st->rays_closest + st->rays_shadow, hits = st->hits_closest + st->hits_shadow;
+    st->algorithmic_bytes = rays * 80ull + 32ull * st->node_tests + 4ull * st->leaf_refs + 48ull * st->tri_tests +
+                            32ull * st->scene_node_tests + 64ull * st->instance_visits + 24ull * st->mesh_aabb_tests + 64ull * hits +
+                            80ull * st->shaded_hits + 4ull * pixels;
+}
+
+LightRec make_light(const xrt_light &l) {
+    LightRec r;
+    std::memset(&r, 0, sizeof(r));
+    r.kind = l.kind;
+    r.px = l.position[0]; r.py = l.position[1]; r.pz = l.position[2];
+    r.dx = l.direction[0]; r.dy = l.direction[1]; r.dz = l.direction[2];
+    r.cr = l.color[0]; r.cg = l.color[1]; r.cb = l.color[2];
+    r.intensity = l.intensity;
+    r.angleCosine = (float)std::cos((double)(l.spot_angle * 0.5f));                        // SPOT:25
+    r.decayDenom = std::pow((double)(1 - r.angleCosine), (double)l.decay_exponent);        // SPOT:54, constant per light
+    if (l.kind == XRT_LIGHT_DIRECTIONAL) { r.px = r.py = r.pz = 0.0f; }                     // DIR:14
+    return r;
+}
+
+int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g) {
+    if (cam->vp_width <= 0 || cam->vp_height <= 0) return fail(XRT_E_INVALID_ARG, "viewport must be positive");
+    float wv[16], wvp[16], ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    mat_multiply(ident, cam->view, wv);     // Matrix.Multiply(world = Identity, view)   (Viewport.Unproject, RT:415)
+    mat_multiply(wv, cam->proj, wvp);       // Matrix.Multiply(.., projection)
+    mat_invert(wvp, g.m);                   // Matrix.Invert
+    g.vpX = (float)cam->vp_x; g.vpY = (float)cam->vp_y; g.vpW = (float)cam->vp_width; g.vpH = (float)cam->vp_height;
+    g.minDepth = cam->vp_min_depth; g.depthRange = cam->vp_max_depth - cam->vp_min_depth;
+    g.width = cam->vp_width; g.height = cam->vp_height;
+    g.tilesX = (g.width + XRT_TILE_W - 1) / XRT_TILE_W; g.tilesY = (g.height + XRT_TILE_H - 1) / XRT_TILE_H;
+    g.shardCount = o->shard_count > 1 ? o->shard_count : 1;
+    g.shardRank = o->shard_count > 1 ? o->shard_rank : 0;
+    g.samples = (o->use_multisampling == XRT_MS_FIXED16) ? 16 : 1;
+    g.pad = 0;
+    if (g.shardRank < 0 || g.shardRank >= g.shardCount) return fail(XRT_E_INVALID_ARG, "shard_rank out of range");
+    return XRT_OK;
+}
+
+// The frame: for every chunk of paths  raygen -> [intersect -> shade_a -> intersect(shadow) -> shade_b] x (R+1) -> compose -> resolve.
+int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts, uint32_t *d_out,
+                float *d_outF32, hipStream_t st, xrt_stats *stats) {
+    if (!cam || !opts || (!lights && nLights > 0) || nLights < 0) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
+    if (opts->max_reflections < 0 || opts->max_reflections > 64) return fail(XRT_E_INVALID_ARG, "max_reflections out of range");
+    if (opts->address_mode < XRT_ADDRESS_CLAMP || opts->address_mode > XRT_ADDRESS_MIRROR)
+        return fail(XRT_E_INVALID_ARG, "Value does not fall within the expected range: addressMode (MAT:85)");
+    if (opts->filtering != XRT_FILTER_POINT && opts->filtering != XRT_FILTER_BILINEAR)
+        return fail(XRT_E_INVALID_ARG, "Value does not fall within the expected range: filtering (MAT:97)");
+    if (opts->filtering == XRT_FILTER_BILINEAR && s->hs.arrays.anyTexture)
+        return fail(XRT_E_UNSUPPORTED, "bilinear texture filtering (MAT:162-232) is not implemented yet (SURVEY 8f N3)");
+    if (s->hs.arrays.anyTransparent && opts->max_reflections > 0)
+        return fail(XRT_E_UNSUPPORTED, "refraction through Transparent materials (RT:586-702) is not implemented yet (SURVEY 8f N2)");
+    if (opts->use_multisampling == XRT_MS_ADAPTIVE)
+        return fail(XRT_E_UNSUPPORTED, "adaptive supersampling (RT:170-311) is not implemented yet (SURVEY 8f N1); use XRT_MS_FIXED16");
+    if (opts->use_multisampling != XRT_MS_OFF && opts->use_multisampling != XRT_MS_FIXED16) return fail(XRT_E_INVALID_ARG, "use_multisampling");
+    RayGenParams g;
+    int rc = make_raygen(cam, opts, g);
+    if (rc != XRT_OK) return rc;
+    const int R = opts->max_reflections;
+    const int nL = nLights;
+    const long long totalTiles = (long long)g.tilesX * g.tilesY;
+    const long long myTiles = (totalTiles + g.shardCount - 1) / g.shardCount;   // tiles_per_rank (slots, some may be past the end)
+    const long long totalPixels = myTiles * 512;
+    const long long totalPaths = totalPixels * g.samples;
+    const long long chunkPaths = totalPaths < MAX_CHUNK_PATHS ? totalPaths : MAX_CHUNK_PATHS;
+    const int P = (int)chunkPaths;
+    const int nChunks = (int)((totalPaths + chunkPaths - 1) / chunkPaths);
+    const bool wantF32 = d_outF32 != nullptr;
+    // buffers
+    if ((rc = s->rays0.ensure(P)) || (rc = s->rays1.ensure(P)) || (rc = s->hits.ensure(P)) || (rc = s->path0.ensure(P)) ||
+        (rc = s->path1.ensure(P)) || (rc = s->shadowSrc.ensure(P)) || (rc = s->shadowRays.ensure((size_t)P * (nL > 0 ? nL : 1))) ||
+        (rc = s->shadowHits.ensure((size_t)P * (nL > 0 ? nL : 1))) || (rc = s->lvlA.ensure((size_t)P * (R + 1))) ||
+        (rc = s->lvlB.ensure((size_t)P * (R + 1))) || (rc = s->sampleColor.ensure(P)) || (rc = s->lights.ensure(nL > 0 ? nL : 1)) ||
+        (rc = s->counters.ensure(2 * C_COUNT)))
+        return rc;
+    if (wantF32 && (rc = s->sampleF32.ensure((size_t)P * 3))) return rc;
+    const int cntStride = 2 * (R + 2);          // per chunk: cnt[R+2] then scnt[R+2]
+    const int qStride = 2 * (R + 1);
+    if ((rc = s->cnts.ensure((size_t)nChunks * cntStride)) || (rc = s->queues.ensure((size_t)nChunks * qStride))) return rc;
+    HIPCHECK(hipMemsetAsync(s->cnts.p, 0, (size_t)nChunks * cntStride * sizeof(int), st));
+    HIPCHECK(hipMemsetAsync(s->queues.p, 0, (size_t)nChunks * qStride * sizeof(unsigned), st));
+    HIPCHECK(hipMemsetAsync(s->counters.p, 0, 2 * C_COUNT * sizeof(unsigned long long), st));
+    std::vector<LightRec> hl(nL > 0 ? nL : 1);
+    for (int i = 0; i < nL; i++) {
+        if (lights[i].kind != XRT_LIGHT_SPOT && lights[i].kind != XRT_LIGHT_DIRECTIONAL) return fail(XRT_E_INVALID_ARG, "unknown light kind");
+        hl[i] = make_light(lights[i]);
+    }
+    if (nL > 0) HIPCHECK(hipMemcpyAsync(s->lights.p, hl.data(), nL * sizeof(LightRec), hipMemcpyHostToDevice, st));
+    ShadeView V;
+    V.shade = s->shade.p; V.materials = s->materials.p; V.texels = s->texels.p; V.meshes = s->meshes.p;
+    V.lights = s->lights.p; V.nLights = nL; V.addressMode = opts->address_mode; V.filtering = opts->filtering;
+    const SceneView &S = s->view;
+    xrt_ray *rays[2] = {s->rays0.p, s->rays1.p};
+    int *paths[2] = {s->path0.p, s->path1.p};
+    size_t ev = 0;
+    std::vector<std::pair<size_t, size_t>> pairs;
+    hipEvent_t e0 = get_event(s, ev++), e1 = get_event(s, ev++);
+    if (!e0 || !e1) return fail(XRT_E_HIP, "hipEventCreate failed");
+    HIPCHECK(hipEventRecord(e0, st));
+    s->progress.store(0.0f);
+    for (int c = 0; c < nChunks; c++) {
+        const long long pathBase = (long long)c * chunkPaths;
+        const int Pc = (int)((totalPaths - pathBase) < chunkPaths ? (totalPaths - pathBase) : chunkPaths);
+        int *cnt = s->cnts.p + (size_t)c * cntStride, *scnt = cnt + (R + 2);
+        unsigned *q = s->queues.p + (size_t)c * qStride;
+        launch_raygen(g, rays[0], Pc, pathBase, st);
+        for (int k = 0; k <= R; k++) {
+            const int cur = k & 1, nxt = cur ^ 1;
+            IntersectArgs A;
+            A.rays = rays[cur]; A.hits = s->hits.p; A.nDev = k == 0 ? nullptr : cnt + k; A.nMul = 1; A.n = Pc;
+            A.queue = q + 2 * k; A.mode = MODE_SCENE; A.meshId = 0;
+            hipEvent_t a0 = get_event(s, ev), a1 = get_event(s, ev + 1);
+            if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
+            pairs.push_back({ev, ev + 1}); ev += 2;
+            HIPCHECK(hipEventRecord(a0, st));
+            launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st);
+            HIPCHECK(hipEventRecord(a1, st));
+            if (opts->collect_stats) launch_count(S, A, s->counters.p, st);
+            launch_shade_a(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : cnt + k, Pc, k == 0 ? nullptr : paths[cur], s->lvlB.p,
+                           s->shadowRays.p, s->shadowSrc.p, scnt + k, P, k, st);
+            if (nL > 0) {
+                IntersectArgs B;
+                B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.nDev = scnt + k; B.nMul = nL; B.n = 0;
+                B.queue = q + 2 * k + 1; B.mode = MODE_SCENE; B.meshId = 0;
+                hipEvent_t b0 = get_event(s, ev), b1 = get_event(s, ev + 1);
+                if (!b0 || !b1) return fail(XRT_E_HIP, "hipEventCreate failed");
+                pairs.push_back({ev, ev + 1}); ev += 2;
+                HIPCHECK(hipEventRecord(b0, st));
+                launch_intersect(S, B, s->stackNeeded, persistent_grid(s, -1), st);
+                HIPCHECK(hipEventRecord(b1, st));
+                if (opts->collect_stats) launch_count(S, B, s->counters.p + C_COUNT, st);
+            }
+            launch_shade_b(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : paths[cur], scnt + k, s->shadowSrc.p, s->shadowHits.p, s->lvlA.p,
+                           s->lvlB.p, rays[nxt], paths[nxt], cnt + k + 1, P, k, R, st);
+        }
+        launch_compose(s->lvlA.p, s->lvlB.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
+        launch_resolve(g, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, Pc / g.samples, pathBase / g.samples, d_out, d_outF32, st);
+        if (nChunks > 1) {
+            HIPCHECK(hipStreamSynchronize(st));
+            s->progress.store((float)(c + 1) / (float)nChunks);
+        }
+    }
+    HIPCHECK(hipEventRecord(e1, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    HIPCHECK(hipGetLastError());
+    s->progress.store(1.0f);
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        std::vector<int> hc((size_t)nChunks * cntStride);
+        HIPCHECK(hipMemcpy(hc.data(), s->cnts.p, hc.size() * sizeof(int), hipMemcpyDeviceToHost));
+        unsigned long long hcnt[2 * C_COUNT];
+        HIPCHECK(hipMemcpy(hcnt, s->counters.p, sizeof(hcnt), hipMemcpyDeviceToHost));
+        unsigned long long shaded = 0, closest = 0;
+        for (int c = 0; c < nChunks; c++)
+            for (int k = 0; k <= R; k++) {
+                shaded += (unsigned long long)hc[(size_t)c * cntStride + (R + 2) + k];
+                if (k > 0) closest += (unsigned long long)hc[(size_t)c * cntStride + k];
+            }
+        // valid pixels of this shard
+        unsigned long long validPixels = 0;
+        for (long long t = g.shardRank; t < totalTiles; t += g.shardCount) {
+            int tx = (int)(t % g.tilesX), ty = (int)(t / g.tilesX);
+            int w = g.width - tx * XRT_TILE_W; if (w > XRT_TILE_W) w = XRT_TILE_W;
+            int h = g.height - ty * XRT_TILE_H; if (h > XRT_TILE_H) h = XRT_TILE_H;
+            validPixels += (unsigned long long)w * h;
+        }
+        if (!opts->collect_stats) {
+            std::memset(hcnt, 0, sizeof(hcnt));
+            hcnt[C_RAYS] = validPixels * g.samples + closest;
+            hcnt[C_HITS] = shaded;
+            hcnt[C_COUNT + C_RAYS] = shaded * (unsigned long long)nL;
+        }
+        fill_stats(stats, hcnt, shaded, validPixels);
+        if (!opts->collect_stats) stats->algorithmic_bytes = 0;   // needs the counting pass
+        float ms = 0;
+        HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+        stats->ms_total = ms;
+        double mi = 0;
+        for (auto &pr : pairs) {
+            float t = 0;
+            HIPCHECK(hipEventElapsedTime(&t, s->events[pr.first], s->events[pr.second]));
+            mi += t;
+        }
+        stats->ms_intersect = mi;
+        stats->intersect_launches = (uint32_t)pairs.size();
+    }
+    return XRT_OK;
+}
+
+int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hits, int mode, int meshId, hipStream_t st, xrt_stats *stats,
+                  bool sync) {
+    if (n > 0x7fffffff / 2) return fail(XRT_E_INVALID_ARG, "too many rays in one call");
+    int rc;
+    if ((rc = s->queues.ensure(8)) || (rc = s->counters.ensure(2 * C_COUNT))) return rc;
+    HIPCHECK(hipMemsetAsync(s->queues.p, 0, sizeof(unsigned), st));
+    IntersectArgs A;
+    A.rays = d_rays; A.hits = d_hits; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.queue = s->queues.p; A.mode = mode; A.meshId = meshId;
+    hipEvent_t a0 = nullptr, a1 = nullptr;
+    if (stats) {
+        a0 = get_event(s, 0); a1 = get_event(s, 1);
+        if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
+        HIPCHECK(hipMemsetAsync(s->counters.p, 0, 2 * C_COUNT * sizeof(unsigned long long), st));
+        HIPCHECK(hipEventRecord(a0, st));
+    }
+    if (n > 0) launch_intersect(s->view, A, s->stackNeeded, persistent_grid(s, n), st);
+    if (stats) {
+        HIPCHECK(hipEventRecord(a1, st));
+        if (n > 0) launch_count(s->view, A, s->counters.p, st);
+    }
+    HIPCHECK(hipGetLastError());
+    if (sync || stats) HIPCHECK(hipStreamSynchronize(st));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        unsigned long long hcnt[2 * C_COUNT];
+        HIPCHECK(hipMemcpy(hcnt, s->counters.p, sizeof(hcnt), hipMemcpyDeviceToHost));
+        fill_stats(stats, hcnt, 0, 0);
+        float ms = 0;
+        HIPCHECK(hipEventElapsedTime(&ms, a0, a1));
+        stats->ms_total = ms; stats->ms_intersect = ms; stats->intersect_launches = n > 0 ? 1 : 0;
+    }
+    return XRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xrt_version(void) { return XRT_VERSION; }
+const char *xrt_last_error(void) { return g_err.c_str(); }
+
+int xrt_device_count(int *count_out) {
+    if (!count_out) return fail(XRT_E_INVALID_ARG, "xrt_device_count: null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count_out = 0; (void)hipGetLastError(); return XRT_OK; }
+    *count_out = n;
+    return XRT_OK;
+}
+
+int xrt_scene_create(int device, xrt_scene **scene_out) {
+    if (!scene_out) return fail(XRT_E_INVALID_ARG, "xrt_scene_create: null argument");
+    *scene_out = nullptr;
+    if (device < -1) return fail(XRT_E_INVALID_ARG, "xrt_scene_create: bad device index");
+    if (device >= 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(XRT_E_NO_DEVICE, "no HIP device visible; libxrt has no CPU execution path"); }
+        if (device >= n) return fail(XRT_E_NO_DEVICE, "device %d not present (%d visible)", device, n);
+        HIPCHECK(hipSetDevice(device));
+    }
+    xrt_scene *s = new xrt_scene();
+    s->device = device;
+    if (device >= 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete s; return fail(XRT_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    }
+    *scene_out = s;
+    return XRT_OK;
+}
+
+int xrt_scene_destroy(xrt_scene *scene) {
+    if (!scene) return XRT_OK;
+    if (scene->busy.load()) return fail(XRT_E_BUSY, "xrt_scene_destroy: a render is in flight");
+    delete scene;
+    return XRT_OK;
+}
+
+int xrt_scene_add_mesh(xrt_scene *scene, const float *v, const float *n, const float *uv, const float *surf_n, const float *color,
+                       int32_t ntri, const xrt_material *material, const float bbox[6], int32_t *mesh_id_out) {
+    if (!scene || !mesh_id_out) return fail(XRT_E_INVALID_ARG, "xrt_scene_add_mesh: null argument");
+    if (scene->busy.load()) return fail(XRT_E_BUSY, "scene is rendering");
+    std::string err;
+    int id = scene->hs.add_mesh(v, n, uv, surf_n, color, ntri, material, bbox, err);
+    if (id < 0) return fail(XRT_E_INVALID_ARG, "%s", err.c_str());
+    scene->resident = false;
+    *mesh_id_out = id;
+    return XRT_OK;
+}
+
+int xrt_scene_add_object(xrt_scene *scene, const int32_t *mesh_ids, int32_t n_meshes, const float world[16], const float inv_world[16],
+                         const float bbox[6], const float world_bbox[6], int32_t *object_id_out) {
+    if (!scene || !object_id_out) return fail(XRT_E_INVALID_ARG, "xrt_scene_add_object: null argument");
+    if (scene->busy.load()) return fail(XRT_E_BUSY, "scene is rendering");
+    std::string err;
+    int id = scene->hs.add_object(mesh_ids, n_meshes, world, inv_world, bbox, world_bbox, err);
+    if (id < 0) return fail(XRT_E_INVALID_ARG, "%s", err.c_str());
+    scene->resident = false;
+    *object_id_out = id;
+    return XRT_OK;
+}
+
+int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_threshold) {
+    if (!scene) return fail(XRT_E_INVALID_ARG, "xrt_scene_build: null scene");
+    if (scene->busy.load()) return fail(XRT_E_BUSY, "scene is rendering");
+    std::string err;
+    scene->resident = false;
+    if (!scene->hs.build(mesh_threshold, scene_threshold, err)) return fail(XRT_E_UNSUPPORTED, "%s", err.c_str());
+    const SceneArrays &A = scene->hs.arrays;
+    scene->stackNeeded = (A.sceneDepth + 1) + (A.meshDepth + 1);
+    if (intersect_stack_capacity(scene->stackNeeded) < 0) return fail(XRT_E_UNSUPPORTED, "octree too deep for the LDS stack (%d levels)", scene->stackNeeded);
+    if (scene->device < 0) return XRT_OK;   // host-only scene: trees can be inspected, nothing can be traced
+    HIPCHECK(hipSetDevice(scene->device));
+    int rc;
+    if ((rc = upload(scene->nodes, A.nodes)) || (rc = upload(scene->ownBox, A.ownBox)) || (rc = upload(scene->triRec, A.triRec)) ||
+        (rc = upload(scene->snodes, A.snodes)) || (rc = upload(scene->shade, A.shade)) || (rc = upload(scene->nodeDfs, A.nodeDfs)) ||
+        (rc = upload(scene->refTri, A.refTri)) || (rc = upload(scene->srefs, A.srefs)) || (rc = upload(scene->objMesh, A.objMesh)) ||
+        (rc = upload(scene->meshes, A.meshes)) || (rc = upload(scene->objects, A.objects)) || (rc = upload(scene->materials, A.materials)) ||
+        (rc = upload(scene->texels, A.texels)))
+        return rc;
+    SceneView &S = scene->view;
+    S.nodes = scene->nodes.p; S.ownBox = scene->ownBox.p; S.nodeDfs = scene->nodeDfs.p; S.triRec = scene->triRec.p;
+    S.refTri = scene->refTri.p; S.meshes = scene->meshes.p; S.snodes = scene->snodes.p; S.srefs = scene->srefs.p;
+    S.objects = scene->objects.p; S.objMesh = scene->objMesh.p;
+    S.nMeshes = (int)scene->hs.meshes.size(); S.nObjects = (int)scene->hs.objects.size();
+    S.sceneDepth = A.sceneDepth + 1; S.meshDepth = A.meshDepth + 1;
+    scene->blocksPerCU = intersect_blocks_per_cu(scene->stackNeeded);
+    scene->resident = true;
+    return XRT_OK;
+}
+
+int xrt_scene_get_tree(const xrt_scene *scene, int32_t mesh_id, xrt_node_info *nodes, int64_t *n_nodes_inout, int32_t *refs,
+                       int64_t *n_refs_inout) {
+    if (!scene || !n_nodes_inout || !n_refs_inout) return fail(XRT_E_INVALID_ARG, "xrt_scene_get_tree: null argument");
+    if (!scene->hs.built) return fail(XRT_E_NOT_BUILT, "xrt_scene_get_tree: call xrt_scene_build first");
+    if (mesh_id >= (int)scene->hs.meshTrees.size()) return fail(XRT_E_INVALID_ARG, "xrt_scene_get_tree: unknown mesh id");
+    const FlatTree &t = mesh_id < 0 ? scene->hs.sceneTree : scene->hs.meshTrees[mesh_id];
+    if (nodes) {
+        if (*n_nodes_inout < (int64_t)t.info.size()) return fail(XRT_E_INVALID_ARG, "node array too small");
+        std::memcpy(nodes, t.info.data(), t.info.size() * sizeof(xrt_node_info));
+    }
+    if (refs) {
+        if (*n_refs_inout < (int64_t)t.infoRefs.size()) return fail(XRT_E_INVALID_ARG, "ref array too small");
+        std::memcpy(refs, t.infoRefs.data(), t.infoRefs.size() * sizeof(int32_t));
+    }
+    *n_nodes_inout = (int64_t)t.info.size();
+    *n_refs_inout = (int64_t)t.infoRefs.size();
+    return XRT_OK;
+}
+
+int xrt_scene_intersect(xrt_scene *scene, const xrt_ray *rays, const int32_t *ignore_object, int64_t n, xrt_hit *hits_out, xrt_stats *stats_out) {
+    (void)ignore_object;   // dead in the reference (OSM:343), SURVEY Q8
+    int rc = need_device(scene, "xrt_scene_intersect");
+    if (rc != XRT_OK) return rc;
+    if (n < 0 || (n > 0 && (!rays || !hits_out))) return fail(XRT_E_INVALID_ARG, "xrt_scene_intersect: null argument");
+    if ((rc = scene->apiRays.ensure((size_t)n)) || (rc = scene->apiHits.ensure((size_t)n))) return rc;
+    hipStream_t st = scene->stream;
+    if (n > 0) HIPCHECK(hipMemcpyAsync(scene->apiRays.p, rays, (size_t)n * sizeof(xrt_ray), hipMemcpyHostToDevice, st));
+    if ((rc = run_intersect(scene, scene->apiRays.p, n, scene->apiHits.p, MODE_SCENE, 0, st, stats_out, false))) return rc;
+    if (n > 0) HIPCHECK(hipMemcpyAsync(hits_out, scene->apiHits.p, (size_t)n * sizeof(xrt_hit), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return XRT_OK;
+}
+
+int xrt_scene_intersect_device(xrt_scene *scene, const void *d_rays, int64_t n, void *d_hits_out, void *stream) {
+    int rc = need_device(scene, "xrt_scene_intersect_device");
+    if (rc != XRT_OK) return rc;
+    if (n < 0 || (n > 0 && (!d_rays || !d_hits_out))) return fail(XRT_E_INVALID_ARG, "xrt_scene_intersect_device: null argument");
+    if (((uintptr_t)d_rays & 15) || ((uintptr_t)d_hits_out & 15)) return fail(XRT_E_INVALID_ARG, "device buffers must be 16-byte aligned");
+    return run_intersect(scene, (const xrt_ray *)d_rays, n, (xrt_hit *)d_hits_out, MODE_SCENE, 0, (hipStream_t)stream, nullptr, false);
+}
+
+int xrt_mesh_intersect(xrt_scene *scene, int32_t mesh_id, const xrt_ray *rays, int64_t n, xrt_hit *hits_out) {
+    int rc = need_device(scene, "xrt_mesh_intersect");
+    if (rc != XRT_OK) return rc;
+    if (mesh_id < 0 || mesh_id >= (int)scene->hs.meshes.size()) return fail(XRT_E_INVALID_ARG, "xrt_mesh_intersect: unknown mesh id");
+    if (n < 0 || (n > 0 && (!rays || !hits_out))) return fail(XRT_E_INVALID_ARG, "xrt_mesh_intersect: null argument");
+    if ((rc = scene->apiRays.ensure((size_t)n)) || (rc = scene->apiHits.ensure((size_t)n))) return rc;
+    hipStream_t st = scene->stream;
+    if (n > 0) HIPCHECK(hipMemcpyAsync(scene->apiRays.p, rays, (size_t)n * sizeof(xrt_ray), hipMemcpyHostToDevice, st));
+    if ((rc = run_intersect(scene, scene->apiRays.p, n, scene->apiHits.p, MODE_MESH, mesh_id, st, nullptr, false))) return rc;
+    if (n > 0) HIPCHECK(hipMemcpyAsync(hits_out, scene->apiHits.p, (size_t)n * sizeof(xrt_hit), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return XRT_OK;
+}
+
+int xrt_render(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights, int32_t n_lights, const xrt_render_opts *opts,
+               uint32_t *rgba_out, float *rgb_f32_out, xrt_stats *stats_out) {
+    int rc = need_device(scene, "xrt_render");
+    if (rc != XRT_OK) return rc;
+    if (!camera || !opts || !rgba_out) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
+    if (opts->shard_count > 1) return fail(XRT_E_INVALID_ARG, "xrt_render writes a whole frame; use xrt_render_device for shards");
+    BusyGuard guard(scene);
+    if (!guard.owned) return fail(XRT_E_BUSY, "Current render operation not finished.");   // RT:62-63
+    const size_t px = (size_t)camera->vp_width * (size_t)camera->vp_height;
+    if (camera->vp_width <= 0 || camera->vp_height <= 0) return fail(XRT_E_INVALID_ARG, "viewport must be positive");
+    if ((rc = scene->outRGBA.ensure(px))) return rc;
+    if (rgb_f32_out && (rc = scene->outF32.ensure(px * 3))) return rc;
+    hipStream_t st = scene->stream;
+    rc = render_impl(scene, camera, lights, n_lights, opts, scene->outRGBA.p, rgb_f32_out ? scene->outF32.p : nullptr, st, stats_out);
+    if (rc != XRT_OK) return rc;
+    HIPCHECK(hipMemcpy(rgba_out, scene->outRGBA.p, px * sizeof(uint32_t), hipMemcpyDeviceToHost));   // CurrentTarget.SetData (RT:123)
+    if (rgb_f32_out) HIPCHECK(hipMemcpy(rgb_f32_out, scene->outF32.p, px * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return XRT_OK;
+}
+
+int xrt_render_device(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights, int32_t n_lights, const xrt_render_opts *opts,
+                      void *d_rgba_out, void *stream, xrt_stats *stats_out) {
+    int rc = need_device(scene, "xrt_render_device");
+    if (rc != XRT_OK) return rc;
+    if (!camera || !opts || !d_rgba_out) return fail(XRT_E_INVALID_ARG, "xrt_render_device: null argument");
+    BusyGuard guard(scene);
+    if (!guard.owned) return fail(XRT_E_BUSY, "Current render operation not finished.");
+    hipStream_t st = stream ? (hipStream_t)stream : scene->stream;
+    return render_impl(scene, camera, lights, n_lights, opts, (uint32_t *)d_rgba_out, nullptr, st, stats_out);
+}
+
+int xrt_shard_layout(int32_t width, int32_t height, int32_t shard_count, int32_t *tiles_x_out, int32_t *tiles_y_out, int32_t *tiles_per_rank_out) {
+    if (width <= 0 || height <= 0 || shard_count <= 0) return fail(XRT_E_INVALID_ARG, "xrt_shard_layout: bad argument");
+    int tx = (width + XRT_TILE_W - 1) / XRT_TILE_W, ty = (height + XRT_TILE_H - 1) / XRT_TILE_H;
+    if (tiles_x_out) *tiles_x_out = tx;
+    if (tiles_y_out) *tiles_y_out = ty;
+    if (tiles_per_rank_out) *tiles_per_rank_out = (int)(((long long)tx * ty + shard_count - 1) / shard_count);
+    return XRT_OK;
+}
+
+int xrt_detile_device(int32_t width, int32_t height, int32_t shard_count, const void *d_gathered, void *d_rgba_out, void *stream) {
+    if (width <= 0 || height <= 0 || shard_count <= 0 || !d_gathered || !d_rgba_out) return fail(XRT_E_INVALID_ARG, "xrt_detile_device: bad argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(XRT_E_NO_DEVICE, "no HIP device visible"); }
+    int tpr = 0;
+    xrt_shard_layout(width, height, shard_count, nullptr, nullptr, &tpr);
+    launch_detile(width, height, shard_count, tpr, (const uint32_t *)d_gathered, (uint32_t *)d_rgba_out, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+    return XRT_OK;
+}
+
+float xrt_progress(const xrt_scene *scene) { return scene ? scene->progress.load() : 0.0f; }
+
+int xrt_generate_primary_rays(xrt_scene *scene, const xrt_camera *camera, xrt_ray *rays_out) {
+    int rc = need_device(scene, "xrt_generate_primary_rays");
+    if (rc != XRT_OK) return rc;
+    if (!camera || !rays_out) return fail(XRT_E_INVALID_ARG, "xrt_generate_primary_rays: null argument");
+    xrt_render_opts o;
+    std::memset(&o, 0, sizeof(o));
+    RayGenParams g;
+    if ((rc = make_raygen(camera, &o, g))) return rc;
+    const long long slots = (long long)g.tilesX * g.tilesY * 512;
+    if (slots > MAX_CHUNK_PATHS * 8LL) return fail(XRT_E_INVALID_ARG, "frame too large");
+    if ((rc = scene->apiRays.ensure((size_t)slots))) return rc;
+    hipStream_t st = scene->stream;
+    launch_raygen(g, scene->apiRays.p, (int)slots, 0, st);
+    HIPCHECK(hipGetLastError());
+    std::vector<xrt_ray> tmp((size_t)slots);
+    HIPCHECK(hipMemcpyAsync(tmp.data(), scene->apiRays.p, (size_t)slots * sizeof(xrt_ray), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    for (long long i = 0; i < slots; i++) {   // tile order -> row-major
+        long long t = i >> 9;
+        int within = (int)(i & 511);
+        int x = (int)(t % g.tilesX) * XRT_TILE_W + (within & 63), y = (int)(t / g.tilesX) * XRT_TILE_H + (within >> 6);
+        if (x < g.width && y < g.height) rays_out[(size_t)y * g.width + x] = tmp[(size_t)i];
+    }
+    return XRT_OK;
+}
+
+}  // extern "C"

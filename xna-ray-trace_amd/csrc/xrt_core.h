@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define XRT_HD __host__ __device__ __forceinline__
+#define XRT_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define XRT_HD inline
 #endif

@@ -1,0 +1,75 @@
+"""Multi-GPU plumbing: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+
+The path shards by image tiles: the scene is replicated, tile t (64x8 pixels, row-major
+numbering) belongs to rank t % world and lands in slot t // world of that rank's contiguous buffer.  The
+only exchange step of a frame is the gather of those buffers on rank 0, followed by a de-tile kernel.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi as abi
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_layout(width, height, world):
+    """(tiles_x, tiles_y, tiles_per_rank) — pure arithmetic, mirrors xrt_shard_layout."""
+    tx = (width + abi.TILE_W - 1) // abi.TILE_W
+    ty = (height + abi.TILE_H - 1) // abi.TILE_H
+    return tx, ty, (tx * ty + world - 1) // world
+
+
+def pack_shard(frame, width, height, rank, world):
+    """Host mirror of what xrt_render_device writes for a shard: frame (H*W uint32) -> this rank's
+    tile-contiguous buffer (tiles_per_rank*512).  Used by the CPU (gloo) tests."""
+    tx, ty, tpr = shard_layout(width, height, world)
+    img = np.asarray(frame, dtype=np.uint32).reshape(height, width)
+    out = np.zeros(tpr * 512, dtype=np.uint32)
+    for slot in range(tpr):
+        t = slot * world + rank
+        if t >= tx * ty:
+            break
+        x0, y0 = (t % tx) * abi.TILE_W, (t // tx) * abi.TILE_H
+        tile = np.zeros((abi.TILE_H, abi.TILE_W), dtype=np.uint32)
+        h, w = min(abi.TILE_H, height - y0), min(abi.TILE_W, width - x0)
+        tile[:h, :w] = img[y0:y0 + h, x0:x0 + w]
+        out[slot * 512:(slot + 1) * 512] = tile.reshape(-1)
+    return out
+
+
+def detile_host(gathered, width, height, world):
+    """Host mirror of xrt_detile_device (k_detile): rank-major gathered buffers -> H*W frame."""
+    tx, ty, tpr = shard_layout(width, height, world)
+    g = np.asarray(gathered, dtype=np.uint32).reshape(world, tpr, abi.TILE_H, abi.TILE_W)
+    img = np.zeros((height, width), dtype=np.uint32)
+    for rank in range(world):
+        for slot in range(tpr):
+            t = slot * world + rank
+            if t >= tx * ty:
+                break
+            x0, y0 = (t % tx) * abi.TILE_W, (t // tx) * abi.TILE_H
+            h, w = min(abi.TILE_H, height - y0), min(abi.TILE_W, width - x0)
+            img[y0:y0 + h, x0:x0 + w] = g[rank, slot, :h, :w]
+    return img.reshape(-1)
+
+
+def gather_frame(local, width, height, group=None, dst=0):
+    """torch.distributed.gather of the per-rank tile buffers (int32 tensors, CPU/gloo or GPU/RCCL).
+    Returns the rank-major gathered tensor on `dst`, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    dist.gather(local, bufs, dst=dst, group=group)
+    return torch.cat(bufs) if rank == dst else None
+
+
+def detile_device(gathered, width, height, world, out, stream=None):
+    """xrt_detile_device on HBM-resident tensors."""
+    abi.check(abi.lib().xrt_detile_device(width, height, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(stream or 0)))
+    return out
