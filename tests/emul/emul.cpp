@@ -38,9 +38,11 @@ int emu_get_tree(emu_scene *s, int mesh, xrt_node_info *nodes, int64_t *nn, int 
 }
 void emu_tree_stats(emu_scene *s, int mesh, int *out) {
     const FlatTree &t = s->hs.meshTrees[mesh];
-    out[0] = t.nodeCount; out[1] = t.leafCount; out[2] = t.emptyLeaves; out[3] = t.maxDepth; out[4] = t.ownTests; out[5] = t.interiors;
+    out[0] = t.nodeCount; out[1] = t.leafCount; out[2] = t.emptyLeaves; out[3] = t.maxDepth; out[4] = t.unsafeNodes; out[5] = t.interiors;
 }
 // mode 0: scene query, mode 1: mesh query.  steps_out (nullable, 3 per ray): scene / node / leaf steps.
+static int fast_mode = 1;
+void emu_set_fast(int f) { fast_mode = f; }
 int emu_intersect(emu_scene *s, int mode, int mesh, const xrt_ray *rays, int64_t n, xrt_hit *hits, int64_t *steps_out) {
     if (!s->hs.built) return -1;
     SceneView S = s->hs.host_view();
@@ -54,7 +56,7 @@ int emu_intersect(emu_scene *s, int mode, int mesh, const xrt_ray *rays, int64_t
         int64_t st[3] = {0, 0, 0};
         while (L.state != ST_FINISH) {
             if (L.state == ST_SCENE) { advance_scene(L, S, stk); st[0]++; }
-            else if (L.state == ST_NODE) { advance_node(L, S, stk, mode); st[1]++; }
+            else if (L.state == ST_NODE) { advance_node(L, S, stk, mode, fast_mode != 0 && L.r.par == 0 && !L.weird); st[1]++; }
             else if (L.state == ST_LEAF) { advance_leaf(L, S); st[2]++; }
         }
         HitOut h = lane_result(L, S, mode);

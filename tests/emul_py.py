@@ -89,7 +89,7 @@ class EmulScene:
     def tree_stats(self, mesh_id):
         out = (C.c_int * 6)()
         lib().emu_tree_stats(self.h, mesh_id, out)
-        return dict(zip(("nodes", "leaves", "empty_leaves", "max_depth", "own_tests", "interiors"), list(out)))
+        return dict(zip(("nodes", "leaves", "empty_leaves", "max_depth", "unsafe_nodes", "interiors"), list(out)))
 
     def intersect(self, rays, mode=0, mesh=0, steps=False):
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)

@@ -21,11 +21,13 @@ struct ShadeView {
 struct IntersectArgs {
     const xrt_ray *rays;
     xrt_hit *hits;
+    const int *index;   // optional compact list of ray indices to trace (others were answered already)
     const int *nDev;    // when non-null the ray count is (*nDev) * nMul, else n
     int nMul;
     int n;
     unsigned *queue;    // zeroed work-queue head of this launch
     int mode, meshId;
+    int refillMin, nodeBurst, leafBurst;   // scheduling knobs of the persistent loop (defaults in xrt_api.cpp; XRT_TUNE overrides)
 };
 
 // reference-work counters accumulated on the device (same order as the head of xrt_stats)
@@ -52,7 +54,7 @@ int  intersect_stack_capacity(int needed);   // smallest compiled capacity >= ne
 void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeeded, int gridBlocks, hipStream_t st);
 int  intersect_blocks_per_cu(int stackNeeded);
 void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long *counters, hipStream_t st);
-void launch_raygen(const RayGenParams &g, xrt_ray *rays, int P, long long pathBase, hipStream_t st);
+void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, xrt_hit *hits, int *index, int *count, int P, long long pathBase, hipStream_t st);
 void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
                     const int *rayPath, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level, hipStream_t st);
 void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath,

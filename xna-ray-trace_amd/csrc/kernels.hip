@@ -52,7 +52,6 @@ constexpr int DEAD_RAY = -2;   // ignore_mesh marker of a path without a pixel (
 
 // ---- the hot kernel ------------------------------------------------------------------------------------------
 constexpr int RAY_BATCH = 256;     // rays a wave takes per queue atomic
-constexpr int REFILL_MIN = 24;     // refill as soon as this many lanes are idle
 
 template <int T>
 __global__ __launch_bounds__(256) void k_intersect(SceneView S, IntersectArgs A) {
@@ -62,17 +61,21 @@ __global__ __launch_bounds__(256) void k_intersect(SceneView S, IntersectArgs A)
     const int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
     Lane L;
     L.state = ST_IDLE;
-    int batchNext = 0, batchEnd = 0;
-    bool exhausted = false;
+    // the first batch of every wave is static (a grid-wide burst of atomics on one word costs ~11 ns each);
+    // further batches come from the queue
+    const int nWaves = (int)gridDim.x * 4;
+    int batchNext = ((int)blockIdx.x * 4 + wave) * RAY_BATCH;
+    int batchEnd = min(batchNext + RAY_BATCH, n);
+    bool exhausted = batchNext >= n;
     for (;;) {
         const unsigned long long idle = __ballot(L.state == ST_IDLE);
         if (idle != 0ull) {
             const int nIdle = __popcll(idle);
-            if (!exhausted && (nIdle >= REFILL_MIN || idle == ~0ull)) {
+            if (!exhausted && (nIdle >= A.refillMin || idle == ~0ull)) {
                 if (batchNext >= batchEnd) {
                     unsigned base = 0;
                     if (lane == 0) base = atomicAdd(A.queue, (unsigned)RAY_BATCH);
-                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + (unsigned)(nWaves * RAY_BATCH);
                     batchNext = (int)base;
                     batchEnd = min((int)base + RAY_BATCH, n);
                     if ((int)base >= n || (int)base < 0) exhausted = true;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void k_intersect(SceneView S, IntersectArgs A)
                     const int take = min(nIdle, batchEnd - batchNext);
                     const int rank = lanes_below(idle);
                     if (L.state == ST_IDLE && rank < take) {
-                        const int idx = batchNext + rank;
+                        const int idx = A.index ? A.index[batchNext + rank] : batchNext + rank;
                         v3 o, d; int im, it;
                         load_ray(A.rays + idx, o, d, im, it);
                         if (im == DEAD_RAY) { L.rayIndex = idx; L.sfound = 0; L.state = ST_FINISH; }
@@ -92,9 +95,19 @@ __global__ __launch_bounds__(256) void k_intersect(SceneView S, IntersectArgs A)
             }
             if (exhausted && idle == ~0ull) break;
         }
-        if (L.state == ST_SCENE) advance_scene(L, S, st);
-        if (L.state == ST_NODE) advance_node(L, S, st, A.mode);
-        if (L.state == ST_LEAF) advance_leaf(L, S);
+        // while-while: lanes gather in the same phase before the wave pays for that phase's code
+        while (__any(L.state == ST_SCENE)) {
+            if (L.state == ST_SCENE) advance_scene(L, S, st);
+        }
+        {   // the NaN-free box test is valid for the whole wave unless some live lane has a parallel axis or a non-finite ray
+            const bool fast = !__any(L.state != ST_IDLE && (L.r.par != 0 || L.weird != 0));
+            for (int it = 0; it < A.nodeBurst && __any(L.state == ST_NODE); it++) {
+                if (L.state == ST_NODE) advance_node(L, S, st, A.mode, fast);
+            }
+        }
+        for (int it = 0; it < A.leafBurst && __any(L.state == ST_LEAF); it++) {
+            if (L.state == ST_LEAF) advance_leaf(L, S);
+        }
         if (L.state == ST_FINISH) {
             store_hit(A.hits + L.rayIndex, lane_result(L, S, A.mode));
             L.state = ST_IDLE;
@@ -148,37 +161,47 @@ struct LocalStack {
 
 __device__ void count_mesh(const SceneView &S, const RayPre &r, int mesh, int ignoreId, bool mfound, float mKey,
                            unsigned long long *c, LocalStack &stk) {
-    int sp = 0;
-    int blk = S.meshes[mesh].rootNode >> 3, mask = 1;
-    for (;;) {
-        if (mask == 0) {
-            if (sp == 0) break;
-            unsigned wv = stk.get(--sp);
-            blk = (int)(wv >> 8); mask = (int)(wv & 0xffu);
-            continue;
+    const MeshRec &mr = S.meshes[mesh];
+    float key;
+    c[C_NODES]++;   // the root's own box (MO:331)
+    if (!slab(r, mr.rmin[0], mr.rmin[1], mr.rmin[2], mr.rmax[0], mr.rmax[1], mr.rmax[2], key)) return;
+    auto count_leaf = [&](int start, int cnt, float k) {
+        if (!mfound || k <= mKey) {
+            c[C_REFS] += (unsigned long long)cnt;
+            int ign = 0;
+            if (ignoreId >= 0) for (int i = 0; i < cnt; i++) ign += (S.refTri[start + i] == ignoreId) ? 1 : 0;
+            c[C_TRIS] += (unsigned long long)(cnt - ign);
         }
-        int ch = ctz32((unsigned)mask);
-        mask &= mask - 1;
-        int node = blk * 8 + ch;
-        f4 lo = S.nodes[2 * node], hi = S.nodes[2 * node + 1];
-        int a = f2i(lo.w), b = f2i(hi.w);
+    };
+    if (mr.rootBlock < 0) { count_leaf(mr.rootRef, mr.rootCount, key); return; }
+    // explicit DFS over every child of every hit interior node (the reference does not prune): stack of
+    // (block, pending mask) words plus the parent box per level
+    struct Frame { int blk, mask; v3 bmin, half; };
+    Frame fr[24];
+    int sp = 0;
+    fr[0].blk = mr.rootBlock; fr[0].mask = 0xff;
+    fr[0].bmin = mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]); fr[0].half = half_of(fr[0].bmin, mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]));
+    (void)stk;
+    while (sp >= 0) {
+        Frame &f = fr[sp];
+        if (f.mask == 0) { sp--; continue; }
+        int ch = ctz32((unsigned)f.mask);
+        f.mask &= f.mask - 1;
+        f4 lo = S.blocks[2 * (size_t)f.blk], hi = S.blocks[2 * (size_t)f.blk + 1];
+        int d0 = f2i(lo.x), d1 = f2i(lo.y), d2 = f2i(lo.z), d3 = f2i(lo.w);
+        int offw[4] = {f2i(hi.x), f2i(hi.y), f2i(hi.z), f2i(hi.w)};
+        v3 cmin, cmax;
+        child_box(f.bmin, f.half, ch, cmin, cmax);
         c[C_NODES]++;
-        float key;
-        if (b < 0) {
-            if (!slab(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, key)) continue;
-            int cnt = b & 0x0fffffff;
-            if (!mfound || key <= mKey) {
-                c[C_REFS] += (unsigned long long)cnt;
-                int ign = 0;
-                if (ignoreId >= 0) for (int i = 0; i < cnt; i++) ign += (S.refTri[a + i] == ignoreId) ? 1 : 0;
-                c[C_TRIS] += (unsigned long long)(cnt - ign);
-            }
+        if (!slab(r, cmin.x, cmin.y, cmin.z, cmax.x, cmax.y, cmax.z, key)) continue;
+        if ((d2 >> ch) & 1) {
+            int nb = d0 + __builtin_popcount((unsigned)(d2 & 0xff) & ((1u << ch) - 1u));
+            sp++;
+            fr[sp].blk = nb; fr[sp].mask = 0xff; fr[sp].bmin = cmin; fr[sp].half = half_of(cmin, cmax);
         } else {
-            int side = b & NODE_SIDE_MASK;
-            f4 olo = S.ownBox[2 * side], ohi = S.ownBox[2 * side + 1];
-            if (!slab(r, olo.x, olo.y, olo.z, ohi.x, ohi.y, ohi.z, key)) continue;
-            if (mask) stk.set(sp++, ((unsigned)blk << 8) | (unsigned)mask);
-            blk = a >> 3; mask = 0xff;
+            auto off = [&](int q) { int w = offw[q >> 1]; return (q & 1) ? (int)((unsigned)w >> 16) : (w & 0xffff); };
+            int start = d1 + off(ch), end = d1 + (ch == 7 ? d3 : off(ch + 1));
+            count_leaf(start, end - start, key);
         }
     }
 }
@@ -186,7 +209,7 @@ __device__ void count_mesh(const SceneView &S, const RayPre &r, int mesh, int ig
 __device__ void run_query(Lane &L, const SceneView &S, LocalStack &stk, int mode) {
     while (L.state != ST_FINISH) {
         if (L.state == ST_SCENE) advance_scene(L, S, stk);
-        else if (L.state == ST_NODE) advance_node(L, S, stk, mode);
+        else if (L.state == ST_NODE) advance_node(L, S, stk, mode, false);
         else advance_leaf(L, S);
     }
 }
@@ -284,29 +307,62 @@ __device__ __forceinline__ bool path_pixel(const RayGenParams &g, long long pix,
     return x < g.width && y < g.height;
 }
 
-__global__ __launch_bounds__(256) void k_raygen(RayGenParams g, xrt_ray *rays, int P, long long pathBase) {
-    for (int p = (int)(blockIdx.x * blockDim.x + threadIdx.x); p < P; p += (int)(gridDim.x * blockDim.x)) {
-        long long gp = pathBase + p;
-        int s = (int)(gp % g.samples);
-        int x, y;
-        if (!path_pixel(g, gp / g.samples, x, y)) { store_ray(rays + p, mk(0, 0, 0), mk(0, 0, 0), DEAD_RAY, -1); continue; }
-        float sx = (float)x, sy = (float)y;
-        if (g.samples == 16) {   // XRT_MS_FIXED16: corner q = s/4 at +-0.25, sub-sample s%4 at +-0.125 (RT:218-305)
-            int q = s >> 2, r = s & 3;
-            sx = (sx + ((q & 1) ? 0.25f : -0.25f)) + ((r & 1) ? 0.125f : -0.125f);
-            sy = (sy + ((q & 2) ? 0.25f : -0.25f)) + ((r & 2) ? 0.125f : -0.125f);
+// Rays that miss the scene octree's root box are answered here (OSM:318-320: no cuboid collected -> return
+// false) and the others are appended, wave by wave, to a compact index list for the traversal kernel.
+__global__ __launch_bounds__(256) void k_raygen(RayGenParams g, SceneView S, xrt_ray *rays, xrt_hit *hits, int *index, int *count, int P,
+                                                long long pathBase) {
+    const f4 rlo = S.snodes[0], rhi = S.snodes[1];
+    const int stride = (int)(gridDim.x * blockDim.x);
+    const int rounds = (P + stride - 1) / stride;
+    for (int it = 0; it < rounds; it++) {
+        const int p = it * stride + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        bool live = false;
+        if (p < P) {
+            long long gp = pathBase + p;
+            int s = (int)(gp % g.samples);
+            int x, y;
+            if (!path_pixel(g, gp / g.samples, x, y)) {
+                store_ray(rays + p, mk(0, 0, 0), mk(0, 0, 0), DEAD_RAY, -1);
+            } else {
+                float sx = (float)x, sy = (float)y;
+                if (g.samples == 16) {   // XRT_MS_FIXED16: corner q = s/4 at +-0.25, sub-sample s%4 at +-0.125 (RT:218-305)
+                    int q = s >> 2, r = s & 3;
+                    sx = (sx + ((q & 1) ? 0.25f : -0.25f)) + ((r & 1) ? 0.125f : -0.125f);
+                    sy = (sy + ((q & 2) ? 0.25f : -0.25f)) + ((r & 2) ? 0.125f : -0.125f);
+                }
+                v3 nearP = unproject(g, sx, sy, 0.0f);   // RT:415
+                v3 farP = unproject(g, sx, sy, 1.0f);    // RT:419
+                v3 dir = normalize(sub(farP, nearP));    // RT:420-421
+                store_ray(rays + p, nearP, dir, -1, -1);
+                if (index) {
+                    RayPre w = make_ray(nearP, dir);
+                    float key;
+                    live = slab(w, rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, key);   // OSM:460 on the root
+                }
+            }
+            if (index && !live) {
+                HitOut h;
+                h.hit = 0; h.object = -1; h.mesh = -1; h.tri = -1; h.leaf = -1; h.u = 0; h.v = 0; h.d = 0; h.wx = 0; h.wy = 0; h.wz = 0;
+                store_hit(hits + p, h);
+            }
         }
-        v3 nearP = unproject(g, sx, sy, 0.0f);   // RT:415
-        v3 farP = unproject(g, sx, sy, 1.0f);    // RT:419
-        v3 dir = normalize(sub(farP, nearP));    // RT:420-421
-        store_ray(rays + p, nearP, dir, -1, -1);
+        if (index) {
+            const unsigned long long m = __ballot(live);
+            if (m == 0ull) continue;
+            int base = 0;
+            const int leader = (int)__builtin_ctzll(m);
+            if (lane_id() == leader) base = atomicAdd(count, (int)__popcll(m));
+            base = __shfl(base, leader);
+            if (live) index[base + lanes_below(m)] = p;
+        }
     }
 }
-void launch_raygen(const RayGenParams &g, xrt_ray *rays, int P, long long pathBase, hipStream_t st) {
+void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, xrt_hit *hits, int *index, int *count, int P, long long pathBase,
+                   hipStream_t st) {
     int blocks = (P + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, g, rays, P, pathBase);
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, g, S, rays, hits, index, count, P, pathBase);
 }
 
 // ---- shading ----------------------------------------------------------------------------------------------------------

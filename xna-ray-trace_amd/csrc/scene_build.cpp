@@ -53,40 +53,30 @@ struct MeshBuilder {
     FlatTree &t;
     std::string &err;
     int dfs = 0;
-    static constexpr int kMaxLevel = 64;
+    static constexpr int kMaxLevel = 20;          // 3 path bits per level in one 64-bit word (traverse.h)
     static constexpr int kMaxNodes = 1 << 24;
 
     bool tri_in(const Box &b, int tri) const {   // MO:226-228: any of the three vertices inside-or-on
         const float *p = &m.v[(size_t)tri * 9];
         return contains_point(b, p) || contains_point(b, p + 3) || contains_point(b, p + 6);
     }
+    int alloc_blocks(int n) {
+        int first = (int)(t.blocks.size() / 2);
+        t.blocks.resize(t.blocks.size() + 2 * (size_t)n, f4{0, 0, 0, 0});
+        t.childDfs.resize(t.childDfs.size() + 8 * (size_t)n, -1);
+        return first;
+    }
 
-    // Builds the subtree of record `rec`.  uni/uniValid: union of the boxes of its non-empty leaves.
-    bool build(int rec, const Box &box, const std::vector<int> &list, int level, Box &uni, bool &uniValid) {
-        const int myDfs = dfs++;
-        t.nodeDfs[rec] = myDfs;
-        t.nodeCount++;
-        if (level > t.maxDepth) t.maxDepth = level;
-        if ((int)list.size() <= threshold) {   // MO:86: leaf
-            int start = (int)t.leafRefs.size();
-            push_info(t, box, true, (int)list.size(), myDfs, level, (int)t.infoRefs.size());
-            t.leafRefs.insert(t.leafRefs.end(), list.begin(), list.end());
-            t.infoRefs.insert(t.infoRefs.end(), list.begin(), list.end());
-            put_node(t, rec, box, start, NODE_LEAF | (int)list.size());
-            t.leafCount++;
-            if (list.empty()) t.emptyLeaves++;
-            uni = box;
-            uniValid = !list.empty();
-            return true;
-        }
-        if (level >= kMaxLevel || t.nodeCount > kMaxNodes) {
-            err = "MeshOctree.BuildTree would not terminate: more than the item threshold triangles share a vertex (MO:84-96 has no depth limit)";
+    // Fills block `blk` = the eight children of the interior node (box, list) at depth `level`
+    // (MO:204-236 SplitCuboid, then MO:91-94 recursion in index order).  `myDfs` is the node's own DFS index,
+    // already pushed to `info`.  uni/uniValid: union of the boxes of the non-empty leaves below the node.
+    bool build_interior(int blk, const Box &box, const std::vector<int> &list, int level, Box &uni, bool &uniValid) {
+        if (level + 1 > kMaxLevel || t.nodeCount > kMaxNodes) {
+            err = "MeshOctree.BuildTree would not terminate or is deeper than 20 levels: more than the item threshold triangles share a vertex (MO:84-96 has no depth limit)";
             return false;
         }
-        push_info(t, box, false, (int)list.size(), myDfs, level, -1);
+        if (level + 1 > t.maxDepth) t.maxDepth = level + 1;
         t.interiors++;
-        const int first = alloc_block(t);
-        // MO:204-236 SplitCuboid: all 8 children and their lists first, then recurse in index order.
         Box cb[8];
         std::vector<int> cl[8];
         int index = 0;
@@ -99,38 +89,62 @@ struct MeshBuilder {
                         if (tri_in(cb[index], tri)) l.push_back(tri);
                     index++;
                 }
-        bool any = false;
-        Box u{};
-        for (int c = 0; c < 8; c++) {
-            Box cu; bool cv = false;
-            if (!build(first + c, cb[c], cl[c], level + 1, cu, cv)) return false;
-            std::vector<int>().swap(cl[c]);
-            if (cv) {
-                if (!any) { u = cu; any = true; }
-                else for (int a = 0; a < 3; a++) { if (cu.mn[a] < u.mn[a]) u.mn[a] = cu.mn[a]; if (cu.mx[a] > u.mx[a]) u.mx[a] = cu.mx[a]; }
+        unsigned interiorMask = 0, emptyMask = 0, safeMask = 0;
+        int nInterior = 0;
+        for (int c = 0; c < 8; c++)
+            if ((int)cl[c].size() > threshold) { interiorMask |= 1u << c; nInterior++; }   // MO:86
+            else if (cl[c].empty()) emptyMask |= 1u << c;
+        const int childBlockBase = nInterior ? alloc_blocks(nInterior) : 0;
+        const int refBase = (int)t.leafRefs.size();
+        unsigned offs[8];
+        unsigned total = 0;
+        for (int c = 0; c < 8; c++) {   // this block's leaf lists, contiguous, child order
+            offs[c] = total;
+            if (!(interiorMask & (1u << c))) {
+                t.leafRefs.insert(t.leafRefs.end(), cl[c].begin(), cl[c].end());
+                total += (unsigned)cl[c].size();
             }
         }
-        // the reference's own box of every interior node is kept in the side array (the counting pass
-        // that reproduces the reference's work counters walks own boxes only)
-        const int side = (int)(t.ownBox.size() / 2);
-        t.ownBox.push_back(f4{box.mn[0], box.mn[1], box.mn[2], 0});
-        t.ownBox.push_back(f4{box.mx[0], box.mx[1], box.mx[2], 0});
-        if (!any) {
-            put_node(t, rec, box, first, NODE_EMPTY | side);
-            uniValid = false;
-            uni = box;
-            return true;
+        if (total > 0xffffu) { err = "more than 65535 triangle references in the leaves of one octree node (item threshold too large for the block descriptor)"; return false; }
+        bool any = false;
+        Box u{};
+        auto merge = [&](const Box &cu) {
+            if (!any) { u = cu; any = true; }
+            else for (int a = 0; a < 3; a++) { if (cu.mn[a] < u.mn[a]) u.mn[a] = cu.mn[a]; if (cu.mx[a] > u.mx[a]) u.mx[a] = cu.mx[a]; }
+        };
+        int rank = 0;
+        for (int c = 0; c < 8; c++) {   // DFS pre-order: child c and its whole subtree before child c+1
+            const int myDfs = dfs++;
+            t.childDfs[(size_t)blk * 8 + c] = myDfs;
+            t.nodeCount++;
+            if (interiorMask & (1u << c)) {
+                push_info(t, cb[c], false, (int)cl[c].size(), myDfs, level + 1, -1);
+                Box cu; bool cv = false;
+                if (!build_interior(childBlockBase + rank, cb[c], cl[c], level + 1, cu, cv)) return false;
+                rank++;
+                bool inside = true;
+                if (cv) {
+                    merge(cu);
+                    for (int a = 0; a < 3; a++) inside = inside && cu.mn[a] >= cb[c].mn[a] && cu.mx[a] <= cb[c].mx[a];
+                }
+                if (inside) safeMask |= 1u << c; else t.unsafeNodes++;
+            } else {
+                push_info(t, cb[c], true, (int)cl[c].size(), myDfs, level + 1, (int)t.infoRefs.size());
+                t.infoRefs.insert(t.infoRefs.end(), cl[c].begin(), cl[c].end());
+                t.leafCount++;
+                if (cl[c].empty()) t.emptyLeaves++; else merge(cb[c]);
+            }
+            std::vector<int>().swap(cl[c]);
         }
-        // The reference visits a leaf only if every ancestor's OWN box is hit.  When the union lies
-        // inside the own box that is implied by the union test (slab monotonicity);
-        // otherwise the own box is kept in the side array and tested too.
-        bool inside = true;
-        for (int a = 0; a < 3; a++) inside = inside && u.mn[a] >= box.mn[a] && u.mx[a] <= box.mx[a];
-        int flags = side;
-        if (!inside) { flags |= NODE_OWN_TEST; t.ownTests++; }
-        put_node(t, rec, u, first, flags);
+        int w[8];
+        w[0] = childBlockBase; w[1] = refBase;
+        w[2] = (int)(interiorMask | (emptyMask << 8) | (safeMask << 16));
+        w[3] = (int)total;
+        for (int q = 0; q < 4; q++) w[4 + q] = (int)(offs[2 * q] | (offs[2 * q + 1] << 16));
+        t.blocks[2 * (size_t)blk] = f4{i2f(w[0]), i2f(w[1]), i2f(w[2]), i2f(w[3])};
+        t.blocks[2 * (size_t)blk + 1] = f4{i2f(w[4]), i2f(w[5]), i2f(w[6]), i2f(w[7])};
         uni = u;
-        uniValid = true;
+        uniValid = any;
         return true;
     }
 };
@@ -139,25 +153,39 @@ struct MeshBuilder {
 
 bool build_mesh_tree(const HostMesh &m, int threshold, FlatTree &t, std::string &err) {
     t = FlatTree();
+    if (threshold > 8000) { err = "mesh item threshold above 8000 is not supported by the block descriptor"; return false; }
     // MO:56-82: root box from all vertices, starting at (+MaxValue, -MaxValue); Vector3.Min/Max.
     Box root;
     for (int a = 0; a < 3; a++) { root.mn[a] = FLT_MAX; root.mx[a] = -FLT_MAX; }
     for (int i = 0; i < m.ntri; i++)
         for (int vtx = 0; vtx < 3; vtx++) {
             const float *p = &m.v[(size_t)i * 9 + vtx * 3];
-            for (int a = 0; a < 3; a++) root.mn[a] = (root.mn[a] < p[a]) ? root.mn[a] : p[a];
+            for (int a = 0; a < 3; a++) {
+                root.mn[a] = (root.mn[a] < p[a]) ? root.mn[a] : p[a];
+                root.mx[a] = (root.mx[a] > p[a]) ? root.mx[a] : p[a];
+            }
         }
-    for (int i = 0; i < m.ntri; i++)
-        for (int vtx = 0; vtx < 3; vtx++) {
-            const float *p = &m.v[(size_t)i * 9 + vtx * 3];
-            for (int a = 0; a < 3; a++) root.mx[a] = (root.mx[a] > p[a]) ? root.mx[a] : p[a];
-        }
+    for (int a = 0; a < 3; a++) { t.rootBox[a] = root.mn[a]; t.rootBox[3 + a] = root.mx[a]; }
     std::vector<int> all(m.ntri);
     for (int i = 0; i < m.ntri; i++) all[i] = i;
-    alloc_block(t);
     MeshBuilder b{m, threshold, t, err};
+    b.dfs = 1;   // the root is DFS index 0
+    t.nodeCount = 1;
+    if (m.ntri <= threshold) {   // MO:86: the root is a leaf
+        push_info(t, root, true, m.ntri, 0, 0, 0);
+        t.rootIsLeaf = true;
+        t.rootCount = m.ntri;
+        t.leafRefs = all;
+        t.infoRefs = all;
+        t.leafCount = 1;
+        if (m.ntri == 0) t.emptyLeaves = 1;
+        return true;
+    }
+    t.rootIsLeaf = false;
+    push_info(t, root, false, m.ntri, 0, 0, -1);
+    const int blk = b.alloc_blocks(1);
     Box u; bool uv = false;
-    return b.build(0, root, all, 0, u, uv);
+    return b.build_interior(blk, root, all, 0, u, uv);
 }
 
 namespace {

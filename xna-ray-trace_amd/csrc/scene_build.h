@@ -25,16 +25,24 @@ struct HostObject {
     float world[16], invWorld[16], bbox[6], worldBbox[6];
 };
 
-// One flattened tree.  `nodes` holds 2 f4 per record, indices local to the tree (root = record 0 of
-// block 0); `info`/`refs` are the DFS pre-order inspection view (xrt_scene_get_tree).
+// One flattened tree, indices local to the tree.  Mesh trees use the implicit-box block layout of
+// xrt_core.h (`blocks`, `childDfs`, root fields); the scene tree uses explicit records (`nodes`, root =
+// record 0 of block 0).  `info`/`infoRefs` are the DFS pre-order inspection view (xrt_scene_get_tree).
 struct FlatTree {
+    // mesh trees
+    std::vector<f4> blocks;         // 2 per block descriptor
+    std::vector<int> childDfs;      // 8 per block: DFS pre-order index of child c
+    float rootBox[6] = {0, 0, 0, 0, 0, 0};
+    bool rootIsLeaf = true;
+    int rootCount = 0;
+    // scene tree
     std::vector<f4> nodes;          // 2 per record
-    std::vector<f4> ownBox;         // 2 per interior record (mesh trees)
     std::vector<int> nodeDfs;       // per record: DFS pre-order index (-1 for padding records)
-    std::vector<int> leafRefs;      // leaf order: local triangle index (mesh trees) or object id (scene tree)
+    // both
+    std::vector<int> leafRefs;      // storage order: local triangle index (mesh trees) or object id (scene tree)
     std::vector<xrt_node_info> info;   // DFS order
-    std::vector<int> infoRefs;         // DFS order (same content as leafRefs, concatenated in DFS order)
-    int nodeCount = 0, leafCount = 0, emptyLeaves = 0, maxDepth = 0, ownTests = 0, interiors = 0;
+    std::vector<int> infoRefs;         // DFS order
+    int nodeCount = 0, leafCount = 0, emptyLeaves = 0, maxDepth = 0, unsafeNodes = 0, interiors = 0;
 };
 
 // Returns false (and sets err) when the reference's recursion would not terminate.

@@ -6,8 +6,8 @@
 namespace xrt {
 
 size_t SceneArrays::bytes() const {
-    return (nodes.size() + ownBox.size() + triRec.size() + snodes.size() + shade.size()) * sizeof(f4) +
-           (nodeDfs.size() + refTri.size() + srefs.size() + objMesh.size()) * sizeof(int) + meshes.size() * sizeof(MeshRec) +
+    return (blocks.size() + triRec.size() + snodes.size() + shade.size()) * sizeof(f4) +
+           (childDfs.size() + refTri.size() + srefs.size() + objMesh.size()) * sizeof(int) + meshes.size() * sizeof(MeshRec) +
            objects.size() * sizeof(ObjRec) + materials.size() * sizeof(MaterialRec) + texels.size() * sizeof(uint32_t);
 }
 
@@ -65,21 +65,15 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
         const HostMesh &m = meshes[mi];
         FlatTree &t = meshTrees[mi];
         if (!build_mesh_tree(m, meshThreshold, t, err)) return false;   // Mesh.Init (MESH:27-32)
-        const int nodeBase = (int)(A.nodes.size() / 2);   // multiple of 8
-        const int sideBase = (int)(A.ownBox.size() / 2);
+        const int blockBase = (int)(A.blocks.size() / 2);
         const int refBase = (int)A.refTri.size();
-        for (size_t r = 0; r < t.nodes.size() / 2; r++) {
-            f4 lo = t.nodes[2 * r], hi = t.nodes[2 * r + 1];
-            int a = f2i(lo.w), b = f2i(hi.w);
-            if (t.nodeDfs[r] >= 0) {
-                if (b < 0) a += refBase;
-                else { a += nodeBase; b = (b & ~NODE_SIDE_MASK) | ((b & NODE_SIDE_MASK) + sideBase); }
-            }
-            lo.w = i2f(a); hi.w = i2f(b);
-            A.nodes.push_back(lo); A.nodes.push_back(hi);
+        for (size_t bi = 0; bi < t.blocks.size() / 2; bi++) {   // local -> global indices
+            f4 lo = t.blocks[2 * bi], hi = t.blocks[2 * bi + 1];
+            lo.x = i2f(f2i(lo.x) + blockBase);
+            lo.y = i2f(f2i(lo.y) + refBase);
+            A.blocks.push_back(lo); A.blocks.push_back(hi);
         }
-        A.ownBox.insert(A.ownBox.end(), t.ownBox.begin(), t.ownBox.end());
-        A.nodeDfs.insert(A.nodeDfs.end(), t.nodeDfs.begin(), t.nodeDfs.end());
+        A.childDfs.insert(A.childDfs.end(), t.childDfs.begin(), t.childDfs.end());
         for (int tri : t.leafRefs) {   // leaf references in leaf order: (v1,N.x) (E1,N.y) (E2,N.z)
             const float *p = &m.v[(size_t)tri * 9];
             const float *sn = &m.sn[(size_t)tri * 3];
@@ -111,7 +105,10 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
         MeshRec mr;
         std::memset(&mr, 0, sizeof(mr));
         for (int a = 0; a < 3; a++) { mr.bmin[a] = m.bbox[a]; mr.bmax[a] = m.bbox[3 + a]; }
-        mr.rootNode = nodeBase; mr.triBase = triBase; mr.ntri = m.ntri; mr.material = (int)mi; mr.maxDepth = t.maxDepth;
+        for (int a = 0; a < 3; a++) { mr.rmin[a] = t.rootBox[a]; mr.rmax[a] = t.rootBox[3 + a]; }
+        mr.rootBlock = t.rootIsLeaf ? -1 : blockBase;
+        mr.rootRef = refBase; mr.rootCount = t.rootIsLeaf ? t.rootCount : 0;
+        mr.triBase = triBase; mr.ntri = m.ntri; mr.material = (int)mi; mr.maxDepth = t.maxDepth; mr.dfsBase = blockBase * 8;
         A.meshes.push_back(mr);
         if (t.maxDepth > A.meshDepth) A.meshDepth = t.maxDepth;
         triBase += m.ntri;
@@ -130,7 +127,6 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
         A.objects.push_back(r);
     }
     // never hand out empty arrays (a zero-size allocation has no address)
-    if (A.ownBox.empty()) A.ownBox.assign(2, f4{0, 0, 0, 0});
     if (A.triRec.empty()) A.triRec.assign(3, f4{0, 0, 0, 0});
     if (A.refTri.empty()) A.refTri.assign(1, -1);
     if (A.srefs.empty()) A.srefs.assign(1, -1);
@@ -140,8 +136,8 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
     if (A.meshes.empty()) { MeshRec z; std::memset(&z, 0, sizeof(z)); A.meshes.push_back(z); }
     if (A.objects.empty()) { ObjRec z; std::memset(&z, 0, sizeof(z)); A.objects.push_back(z); }
     if (A.materials.empty()) { MaterialRec z; std::memset(&z, 0, sizeof(z)); A.materials.push_back(z); }
-    if (A.nodes.empty()) A.nodes.assign(16, f4{0, 0, 0, 0});
-    if (A.nodeDfs.empty()) A.nodeDfs.assign(8, -1);
+    if (A.blocks.empty()) A.blocks.assign(2, f4{0, 0, 0, 0});
+    if (A.childDfs.empty()) A.childDfs.assign(8, -1);
     built = true;
     return true;
 }
@@ -149,7 +145,7 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
 SceneView HostScene::host_view() const {
     SceneView S;
     const SceneArrays &A = arrays;
-    S.nodes = A.nodes.data(); S.ownBox = A.ownBox.data(); S.nodeDfs = A.nodeDfs.data();
+    S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data();
     S.triRec = A.triRec.data(); S.refTri = A.refTri.data(); S.meshes = A.meshes.data();
     S.snodes = A.snodes.data(); S.srefs = A.srefs.data(); S.objects = A.objects.data(); S.objMesh = A.objMesh.data();
     S.nMeshes = (int)meshes.size(); S.nObjects = (int)objects.size();

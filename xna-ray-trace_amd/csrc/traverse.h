@@ -18,9 +18,8 @@
 namespace xrt {
 
 struct SceneView {
-    const f4 *nodes;        // mesh octrees, 2 per record
-    const f4 *ownBox;       // 2 per interior record (reference's own box)
-    const int *nodeDfs;     // per record
+    const f4 *blocks;       // mesh octrees: 2 per block descriptor (implicit boxes, xrt_core.h)
+    const int *childDfs;    // 8 per block: DFS pre-order index of child c
     const f4 *triRec;       // 3 per leaf reference
     const int *refTri;      // global triangle id per leaf reference
     const MeshRec *meshes;
@@ -39,6 +38,7 @@ struct Lane {
     RayPre w;            // world ray (scene mode)
     RayPre r;            // object-space ray
     int ignoreId;        // global triangle id, -1 = none
+    int weird;           // a non-finite ray component: only the NaN-exact box test may be used
     int rayIndex;
     int state;
     // scene cursor
@@ -46,9 +46,13 @@ struct Lane {
     int sRef, sRefEnd;
     float sKey;
     int obj, mPtr, mEnd;
-    // mesh query
+    // mesh query: current block (children of the node whose own box is bmin..bmax)
     int mesh, dmask;
-    int blk, mask, sp;
+    int blk, mask, sp;       // mask: children still to test, bit p <-> child (p ^ dmask), front to back
+    unsigned long long path; // child index taken at each level (3 bits per level) to recompute boxes on pop
+    v3 bmin, half;           // own box of the current block's parent: min corner and (max - min) / 2 (MO:207)
+    int d0, d1, d2, d3;      // block descriptor words 0..3
+    unsigned long long offLo, offHi;   // 16-bit reference offsets of children 0..3 / 4..7
     int mfound;
     float mKey, mDist, mU, mV;
     int mRef, mLeaf;
@@ -62,19 +66,83 @@ struct Lane {
 };
 
 XRT_HD int ctz32(unsigned x) { return __builtin_ctz(x); }
+XRT_HD int node_dfs(const SceneView &S, int node) { return node < 0 ? 0 : S.childDfs[node]; }
+
+XRT_HD void finish_mesh_query(Lane &L, int mode);
+
+// The eight children of block `blk`: descriptor into registers, every non-empty child pending.
+XRT_HD void load_block(Lane &L, const SceneView &S, int blk) {
+    f4 lo = S.blocks[2 * (size_t)blk], hi = S.blocks[2 * (size_t)blk + 1];
+    L.blk = blk;
+    L.d0 = f2i(lo.x); L.d1 = f2i(lo.y); L.d2 = f2i(lo.z); L.d3 = f2i(lo.w);
+    L.offLo = (unsigned long long)(unsigned)f2i(hi.x) | ((unsigned long long)(unsigned)f2i(hi.y) << 32);
+    L.offHi = (unsigned long long)(unsigned)f2i(hi.z) | ((unsigned long long)(unsigned)f2i(hi.w) << 32);
+}
+// pending-children mask in front-to-back bit order for the children set `childSet` (bit c = child c)
+XRT_HD int permute_mask(int childSet, int dmask) {
+    int m = 0;
+#pragma unroll
+    for (int p = 0; p < 8; p++) m |= ((childSet >> (p ^ dmask)) & 1) << p;
+    return m;
+}
+// MO:217-218 (cubePosition = parent.Min + cubeSize * (i,j,k); box = [cubePosition, cubePosition + cubeSize])
+XRT_HD v3 half_of(v3 pmin, v3 pmax) {   // cubeSize = (Max - Min) / 2f = (Max - Min) * (1f / 2f)   (MO:207)
+    return mk((pmax.x - pmin.x) * 0.5f, (pmax.y - pmin.y) * 0.5f, (pmax.z - pmin.z) * 0.5f);
+}
+XRT_HD void child_box(v3 pmin, v3 half, int c, v3 &cmin, v3 &cmax) {
+    float fi = (c & 4) ? 1.0f : 0.0f, fj = (c & 2) ? 1.0f : 0.0f, fk = (c & 1) ? 1.0f : 0.0f;
+    cmin = mk(pmin.x + half.x * fi, pmin.y + half.y * fj, pmin.z + half.z * fk);
+    cmax = mk(cmin.x + half.x, cmin.y + half.y, cmin.z + half.z);
+}
+// The same box test for an octree child when the ray has no parallel axis and no non-finite component
+// (`fast`): the swap of BoundingBox.Intersects is decided by the sign of the direction, Math.Max/Min
+// reduce to max/min (no NaN can occur), and the per-axis early-outs collapse into the final comparison
+// because tmin only grows and tmax only shrinks.  Same key, same hit/miss (DESIGN.md §box test).
+XRT_HD bool slab_fast(const RayPre &r, int dmask, v3 cmin, v3 cmax, float &key) {
+    float nx = (dmask & 4) ? cmax.x : cmin.x, fx = (dmask & 4) ? cmin.x : cmax.x;
+    float ny = (dmask & 2) ? cmax.y : cmin.y, fy = (dmask & 2) ? cmin.y : cmax.y;
+    float nz = (dmask & 1) ? cmax.z : cmin.z, fz = (dmask & 1) ? cmin.z : cmax.z;
+    float t1x = (nx - r.o.x) * r.inv.x, t2x = (fx - r.o.x) * r.inv.x;
+    float t1y = (ny - r.o.y) * r.inv.y, t2y = (fy - r.o.y) * r.inv.y;
+    float t1z = (nz - r.o.z) * r.inv.z, t2z = (fz - r.o.z) * r.inv.z;
+    float num = fmaxf(fmaxf(fmaxf(t1x, 0.0f), t1y), t1z);
+    float num2 = fminf(fminf(fminf(t2x, FLT_MAX), t2y), t2z);
+    key = num;
+    return !(num > num2);
+}
+XRT_HD bool is_finite(float x) { return fabsf(x) <= FLT_MAX; }
+XRT_HD int child_ref_offset(unsigned long long offLo, unsigned long long offHi, int c) {
+    unsigned long long w = (c & 4) ? offHi : offLo;
+    return (int)((w >> (16 * (c & 3))) & 0xffffull);
+}
 
 XRT_HD void begin_mesh_query(Lane &L, const SceneView &S, int mesh) {
+    const MeshRec &mr = S.meshes[mesh];
     L.mesh = mesh;
-    L.blk = S.meshes[mesh].rootNode >> 3;
-    L.mask = 1 << L.dmask;   // only slot 0 (the root) of the root block: p ^ dmask == 0
     L.sp = 0;
     L.mfound = 0;
+    L.path = 0ull;
+    L.mask = 0;
     L.state = ST_NODE;
+    float key;
+    if (!slab(L.r, mr.rmin[0], mr.rmin[1], mr.rmin[2], mr.rmax[0], mr.rmax[1], mr.rmax[2], key)) return;   // MO:265 on the root (MO:331)
+    if (mr.rootBlock < 0) {   // the root is a leaf: one bucket
+        if (mr.rootCount > 0) {
+            L.ref = mr.rootRef; L.refEnd = mr.rootRef + mr.rootCount; L.leafKey = key; L.leafNode = ROOT_NODE;
+            L.state = ST_LEAF;
+        }
+        return;
+    }
+    L.bmin = mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]);
+    L.half = half_of(L.bmin, mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]));
+    load_block(L, S, mr.rootBlock);
+    L.mask = permute_mask(0xff & ~((L.d2 >> 8) & 0xff), L.dmask);
 }
 
 // Start of a query.  ignore (mesh, tri) is the `ignoreTriangle` identity (MO:290).
 XRT_HD void lane_begin(Lane &L, const SceneView &S, v3 o, v3 d, int ignoreMesh, int ignoreTri, int rayIndex, int mode, int meshId) {
     L.rayIndex = rayIndex;
+    L.weird = (is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(d.x) && is_finite(d.y) && is_finite(d.z)) ? 0 : 1;
     L.ignoreId = -1;
     if (ignoreTri >= 0 && ignoreMesh >= 0 && ignoreMesh < S.nMeshes && ignoreTri < S.meshes[ignoreMesh].ntri)
         L.ignoreId = S.meshes[ignoreMesh].triBase + ignoreTri;
@@ -90,6 +158,7 @@ XRT_HD void lane_begin(Lane &L, const SceneView &S, v3 o, v3 d, int ignoreMesh, 
         L.r = L.w;
         L.dmask = dir_mask(d);
         L.sblk = 0; L.smask = 0;
+        L.obj = -1;
         begin_mesh_query(L, S, meshId);
     }
 }
@@ -115,6 +184,7 @@ XRT_HD void advance_scene(Lane &L, const SceneView &S, Stack &stk) {
         v3 dir = normalize(sub(v2, v1));                        // OSM:362-364
         L.r = make_ray(v1, dir);
         L.dmask = dir_mask(dir);
+        if (!(is_finite(v1.x) && is_finite(v1.y) && is_finite(v1.z) && is_finite(dir.x) && is_finite(dir.y) && is_finite(dir.z))) L.weird = 1;
         L.mPtr = ob.meshStart;
         L.mEnd = ob.meshStart + ob.meshCount;
         return;
@@ -158,58 +228,73 @@ XRT_HD void finish_mesh_query(Lane &L, int mode) {
     L.state = (mode == MODE_SCENE) ? ST_SCENE : ST_FINISH;
 }
 
-// ---- mesh level: pop one octree node (MO:328-353), front to back, with key pruning --------------------------
+// ---- mesh level: one child of the current block (MO:328-353), front to back, with key pruning ------------------
+// Memory is touched only when a block is entered (descend) or re-entered (pop): 32 bytes of descriptor.
 template <class Stack>
-XRT_HD void advance_node(Lane &L, const SceneView &S, Stack &stk, int mode) {
-    if (L.mask == 0) {
-        if (L.sp == 0) { finish_mesh_query(L, mode); return; }
-        unsigned wv = stk.get(S.sceneDepth + (--L.sp));
-        L.blk = (int)(wv >> 8);
-        L.mask = (int)(wv & 0xffu);
+XRT_HD void advance_node(Lane &L, const SceneView &S, Stack &stk, int mode, bool fast) {
+    if (L.mask == 0) {   // block exhausted: pop the deepest level that still has pending children
+        int m = 0;
+        unsigned wv = 0;
+        while (L.sp > 0) {
+            wv = stk.get(S.sceneDepth + (--L.sp));
+            m = (int)(wv & 0xffu);
+            if (m) break;
+        }
+        if (m == 0) { finish_mesh_query(L, mode); return; }
+        // re-enter block wv>>8 whose parent node sits at depth L.sp: recompute that node's own box from the
+        // root with the child indices recorded in `path` (same binary32 operations as the builder, MO:207-218)
+        const MeshRec &mr = S.meshes[L.mesh];
+        v3 bmin = mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]);
+        v3 half = half_of(bmin, mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]));
+        for (int i = 0; i < L.sp; i++) {
+            v3 cmin, cmax;
+            child_box(bmin, half, (int)((L.path >> (3 * i)) & 7ull), cmin, cmax);
+            bmin = cmin; half = half_of(cmin, cmax);
+        }
+        L.bmin = bmin; L.half = half;
+        load_block(L, S, (int)(wv >> 8));
+        L.mask = m;
         return;
     }
     int p = ctz32((unsigned)L.mask);
     L.mask &= L.mask - 1;
-    int node = L.blk * 8 + (p ^ L.dmask);
-    f4 lo = S.nodes[2 * node], hi = S.nodes[2 * node + 1];
-    int a = f2i(lo.w), b = f2i(hi.w);
-    if (b < 0) {   // leaf: the record holds the reference's own box, whose entry distance is the bucket key
-        int cnt = b & 0x0fffffff;
-        if (cnt == 0) return;   // empty leaves are bucketed by the reference but cannot produce a hit (Q4)
-        float key;
-        if (!slab(L.r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, key)) return;
+    int c = p ^ L.dmask;
+    v3 cmin, cmax;
+    child_box(L.bmin, L.half, c, cmin, cmax);
+    float key;
+    bool hitBox = fast ? slab_fast(L.r, L.dmask, cmin, cmax, key)
+                       : slab(L.r, cmin.x, cmin.y, cmin.z, cmax.x, cmax.y, cmax.z, key);   // MO:331
+    if (!hitBox) return;
+    if (!((L.d2 >> c) & 1)) {   // leaf child (non-empty by construction of the mask): its entry key is the bucket key
         if (L.mfound && key > L.mKey) return;
-        L.ref = a; L.refEnd = a + cnt; L.leafKey = key; L.leafNode = node;
+        // offs[] is a running total over all eight children, so the list ends where the next child's starts
+        const unsigned long long offLo = L.offLo, offHi = L.offHi;
+        L.ref = L.d1 + child_ref_offset(offLo, offHi, c);
+        L.refEnd = L.d1 + ((c == 7) ? L.d3 : child_ref_offset(offLo, offHi, c + 1));
+        L.leafKey = key; L.leafNode = L.blk * 8 + c;
         L.state = ST_LEAF;
         return;
     }
-    if (b & NODE_EMPTY) return;
-    float key;   // lower bound of every bucket key below this node (union of its non-empty leaf boxes)
-    if (!slab(L.r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, key)) return;
-    if (L.mfound && key > L.mKey) return;
-    if (b & NODE_OWN_TEST) {   // a descendant protrudes from the own box: the reference's own test decides (MO:331-334)
-        int side = b & NODE_SIDE_MASK;
-        f4 olo = S.ownBox[2 * side], ohi = S.ownBox[2 * side + 1];
-        float k2;
-        if (!slab(L.r, olo.x, olo.y, olo.z, ohi.x, ohi.y, ohi.z, k2)) return;
-    }
-    if (L.mask) stk.set(S.sceneDepth + (L.sp++), ((unsigned)L.blk << 8) | (unsigned)L.mask);
-    L.blk = a >> 3;
-    L.mask = 0xff;
+    // interior child: prune by its own entry key only when that is a proven lower bound (safe bit)
+    if (L.mfound && ((L.d2 >> (16 + c)) & 1) && key > L.mKey) return;
+    stk.set(S.sceneDepth + L.sp, ((unsigned)L.blk << 8) | (unsigned)L.mask);
+    L.path = (L.path & ~(7ull << (3 * L.sp))) | ((unsigned long long)c << (3 * L.sp));
+    L.sp++;
+    int nb = L.d0 + __builtin_popcount((unsigned)(L.d2 & 0xff) & ((1u << c) - 1u));
+    L.bmin = cmin; L.half = half_of(cmin, cmax);
+    load_block(L, S, nb);
+    L.mask = permute_mask(0xff & ~((L.d2 >> 8) & 0xff), L.dmask);
 }
 
-// ---- leaf: one triangle of MO:288-304 -------------------------------------------------------------------------
-XRT_HD void advance_leaf(Lane &L, const SceneView &S) {
-    int r = L.ref++;
-    f4 a = S.triRec[3 * r], b = S.triRec[3 * r + 1], c = S.triRec[3 * r + 2];
-    float u, v, dist;
-    if (tri_test(L.r.o, L.r.d, a, b, c, u, v, dist) && dist < FLT_MAX) {   // MO:293-294 (minDistance starts at float.MaxValue)
+// ---- leaf: triangles of MO:288-304 --------------------------------------------------------------------------------
+XRT_HD void leaf_candidate(Lane &L, const SceneView &S, int r, bool pass, float u, float v, float dist) {
+    if (pass && dist < FLT_MAX) {   // MO:293-294 (minDistance starts at float.MaxValue)
         if (S.refTri[r] != L.ignoreId) {   // MO:290
             bool better;
             if (!L.mfound || L.leafKey < L.mKey) better = true;
             else if (L.leafKey == L.mKey) {
                 if (dist < L.mDist) better = true;
-                else if (dist == L.mDist) better = (L.leafNode != L.mLeaf) && (S.nodeDfs[L.leafNode] < S.nodeDfs[L.mLeaf]);
+                else if (dist == L.mDist) better = (L.leafNode != L.mLeaf) && (node_dfs(S, L.leafNode) < node_dfs(S, L.mLeaf));
                 else better = false;
             } else better = false;
             if (better) {
@@ -218,6 +303,20 @@ XRT_HD void advance_leaf(Lane &L, const SceneView &S) {
             }
         }
     }
+}
+// Two references per step: six 16-byte loads in flight per lane.
+XRT_HD void advance_leaf(Lane &L, const SceneView &S) {
+    const int r0 = L.ref;
+    const bool two = (r0 + 1) < L.refEnd;
+    const int r1 = two ? r0 + 1 : r0;
+    f4 a0 = S.triRec[3 * (size_t)r0], b0 = S.triRec[3 * (size_t)r0 + 1], c0 = S.triRec[3 * (size_t)r0 + 2];
+    f4 a1 = S.triRec[3 * (size_t)r1], b1 = S.triRec[3 * (size_t)r1 + 1], c1 = S.triRec[3 * (size_t)r1 + 2];
+    float u0, v0, t0, u1, v1, t1;
+    bool p0 = tri_test(L.r.o, L.r.d, a0, b0, c0, u0, v0, t0);
+    bool p1 = tri_test(L.r.o, L.r.d, a1, b1, c1, u1, v1, t1);
+    leaf_candidate(L, S, r0, p0, u0, v0, t0);
+    if (two) leaf_candidate(L, S, r1, p1, u1, v1, t1);
+    L.ref = r0 + 2;
     if (L.ref >= L.refEnd) L.state = ST_NODE;
 }
 
@@ -237,7 +336,7 @@ XRT_HD HitOut lane_result(const Lane &L, const SceneView &S, int mode) {
     h.hit = 1;
     h.mesh = L.sbMesh;
     h.tri = S.refTri[L.sbRef] - S.meshes[L.sbMesh].triBase;
-    h.leaf = S.nodeDfs[L.sbLeaf];
+    h.leaf = node_dfs(S, L.sbLeaf);
     h.u = L.sbU; h.v = L.sbV; h.d = L.sbD;
     if (mode == MODE_SCENE) {
         h.object = L.sbObj;

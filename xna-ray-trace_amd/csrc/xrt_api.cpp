@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -68,8 +69,8 @@ struct xrt_scene {
     int device = -1;   // -1: host-only scene (inspection of the built trees; every compute call fails)
     HostScene hs;
     // HBM-resident scene
-    DevBuf<f4> nodes, ownBox, triRec, snodes, shade;
-    DevBuf<int> nodeDfs, refTri, srefs, objMesh;
+    DevBuf<f4> blocks, triRec, snodes, shade;
+    DevBuf<int> childDfs, refTri, srefs, objMesh;
     DevBuf<MeshRec> meshes;
     DevBuf<ObjRec> objects;
     DevBuf<MaterialRec> materials;
@@ -91,6 +92,7 @@ struct xrt_scene {
     DevBuf<LightRec> lights;
     DevBuf<unsigned long long> counters;
     std::vector<hipEvent_t> events;
+    int tune[3] = {24, 16, 8};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
     std::atomic<bool> busy{false};
     std::atomic<float> progress{0.0f};
 
@@ -99,8 +101,8 @@ struct xrt_scene {
             (void)hipSetDevice(device);
             for (auto e : events) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
-            nodes.release(); ownBox.release(); triRec.release(); snodes.release(); shade.release();
-            nodeDfs.release(); refTri.release(); srefs.release(); objMesh.release(); meshes.release();
+            blocks.release(); triRec.release(); snodes.release(); shade.release();
+            childDfs.release(); refTri.release(); srefs.release(); objMesh.release(); meshes.release();
             objects.release(); materials.release(); texels.release();
             rays0.release(); rays1.release(); shadowRays.release(); apiRays.release(); hits.release();
             shadowHits.release(); apiHits.release(); path0.release(); path1.release(); shadowSrc.release();
@@ -268,25 +270,32 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
         const int Pc = (int)((totalPaths - pathBase) < chunkPaths ? (totalPaths - pathBase) : chunkPaths);
         int *cnt = s->cnts.p + (size_t)c * cntStride, *scnt = cnt + (R + 2);
         unsigned *q = s->queues.p + (size_t)c * qStride;
-        launch_raygen(g, rays[0], Pc, pathBase, st);
+        // cnt[0] counts the primary rays that reach the scene's root box; paths[1] doubles as their index list
+        launch_raygen(g, S, rays[0], s->hits.p, paths[1], cnt, Pc, pathBase, st);
         for (int k = 0; k <= R; k++) {
             const int cur = k & 1, nxt = cur ^ 1;
             IntersectArgs A;
-            A.rays = rays[cur]; A.hits = s->hits.p; A.nDev = k == 0 ? nullptr : cnt + k; A.nMul = 1; A.n = Pc;
+            A.rays = rays[cur]; A.hits = s->hits.p; A.index = k == 0 ? paths[1] : nullptr; A.nDev = cnt + k; A.nMul = 1; A.n = Pc;
             A.queue = q + 2 * k; A.mode = MODE_SCENE; A.meshId = 0;
+            A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2];
             hipEvent_t a0 = get_event(s, ev), a1 = get_event(s, ev + 1);
             if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
             pairs.push_back({ev, ev + 1}); ev += 2;
             HIPCHECK(hipEventRecord(a0, st));
             launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st);
             HIPCHECK(hipEventRecord(a1, st));
-            if (opts->collect_stats) launch_count(S, A, s->counters.p, st);
+            if (opts->collect_stats) {   // the reference tests the root box for every ray: count over all of them
+                IntersectArgs Ac = A;
+                if (k == 0) { Ac.index = nullptr; Ac.nDev = nullptr; }
+                launch_count(S, Ac, s->counters.p, st);
+            }
             launch_shade_a(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : cnt + k, Pc, k == 0 ? nullptr : paths[cur], s->lvlB.p,
                            s->shadowRays.p, s->shadowSrc.p, scnt + k, P, k, st);
             if (nL > 0) {
                 IntersectArgs B;
-                B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.nDev = scnt + k; B.nMul = nL; B.n = 0;
+                B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.index = nullptr; B.nDev = scnt + k; B.nMul = nL; B.n = 0;
                 B.queue = q + 2 * k + 1; B.mode = MODE_SCENE; B.meshId = 0;
+                B.refillMin = s->tune[0]; B.nodeBurst = s->tune[1]; B.leafBurst = s->tune[2];
                 hipEvent_t b0 = get_event(s, ev), b1 = get_event(s, ev + 1);
                 if (!b0 || !b1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 pairs.push_back({ev, ev + 1}); ev += 2;
@@ -359,7 +368,8 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
     if ((rc = s->queues.ensure(8)) || (rc = s->counters.ensure(2 * C_COUNT))) return rc;
     HIPCHECK(hipMemsetAsync(s->queues.p, 0, sizeof(unsigned), st));
     IntersectArgs A;
-    A.rays = d_rays; A.hits = d_hits; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.queue = s->queues.p; A.mode = mode; A.meshId = meshId;
+    A.rays = d_rays; A.hits = d_hits; A.index = nullptr; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.queue = s->queues.p; A.mode = mode; A.meshId = meshId;
+    A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2];
     hipEvent_t a0 = nullptr, a1 = nullptr;
     if (stats) {
         a0 = get_event(s, 0); a1 = get_event(s, 1);
@@ -414,6 +424,10 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     }
     xrt_scene *s = new xrt_scene();
     s->device = device;
+    if (const char *t = getenv("XRT_TUNE")) {   // "refill,nodeBurst,leafBurst" — scheduling only, never results
+        int v[3];
+        if (sscanf(t, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3 && v[0] >= 1 && v[0] <= 64 && v[1] >= 1 && v[2] >= 1) { s->tune[0] = v[0]; s->tune[1] = v[1]; s->tune[2] = v[2]; }
+    }
     if (device >= 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -467,14 +481,14 @@ int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_thre
     if (scene->device < 0) return XRT_OK;   // host-only scene: trees can be inspected, nothing can be traced
     HIPCHECK(hipSetDevice(scene->device));
     int rc;
-    if ((rc = upload(scene->nodes, A.nodes)) || (rc = upload(scene->ownBox, A.ownBox)) || (rc = upload(scene->triRec, A.triRec)) ||
-        (rc = upload(scene->snodes, A.snodes)) || (rc = upload(scene->shade, A.shade)) || (rc = upload(scene->nodeDfs, A.nodeDfs)) ||
+    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->triRec, A.triRec)) ||
+        (rc = upload(scene->snodes, A.snodes)) || (rc = upload(scene->shade, A.shade)) || (rc = upload(scene->childDfs, A.childDfs)) ||
         (rc = upload(scene->refTri, A.refTri)) || (rc = upload(scene->srefs, A.srefs)) || (rc = upload(scene->objMesh, A.objMesh)) ||
         (rc = upload(scene->meshes, A.meshes)) || (rc = upload(scene->objects, A.objects)) || (rc = upload(scene->materials, A.materials)) ||
         (rc = upload(scene->texels, A.texels)))
         return rc;
     SceneView &S = scene->view;
-    S.nodes = scene->nodes.p; S.ownBox = scene->ownBox.p; S.nodeDfs = scene->nodeDfs.p; S.triRec = scene->triRec.p;
+    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.triRec = scene->triRec.p;
     S.refTri = scene->refTri.p; S.meshes = scene->meshes.p; S.snodes = scene->snodes.p; S.srefs = scene->srefs.p;
     S.objects = scene->objects.p; S.objMesh = scene->objMesh.p;
     S.nMeshes = (int)scene->hs.meshes.size(); S.nObjects = (int)scene->hs.objects.size();
@@ -604,7 +618,7 @@ int xrt_generate_primary_rays(xrt_scene *scene, const xrt_camera *camera, xrt_ra
     if (slots > MAX_CHUNK_PATHS * 8LL) return fail(XRT_E_INVALID_ARG, "frame too large");
     if ((rc = scene->apiRays.ensure((size_t)slots))) return rc;
     hipStream_t st = scene->stream;
-    launch_raygen(g, scene->apiRays.p, (int)slots, 0, st);
+    launch_raygen(g, scene->view, scene->apiRays.p, nullptr, nullptr, nullptr, (int)slots, 0, st);
     HIPCHECK(hipGetLastError());
     std::vector<xrt_ray> tmp((size_t)slots);
     HIPCHECK(hipMemcpyAsync(tmp.data(), scene->apiRays.p, (size_t)slots * sizeof(xrt_ray), hipMemcpyDeviceToHost, st));

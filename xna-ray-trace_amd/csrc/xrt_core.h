@@ -28,35 +28,47 @@ XRT_HD int   f2i(float f) { return __builtin_bit_cast(int, f); }
 XRT_HD float i2f(int i)   { return __builtin_bit_cast(float, i); }
 
 // ---- HBM records ------------------------------------------------------------------------------------
-// Octree node, 32 B = two f4.  Children of an interior node are 8 consecutive records starting at an
-// index that is a multiple of 8 (child c = 4i+2j+k, MO:210-222); each tree's root sits in slot 0 of a
-// block of its own.
-//   lo = (box.min.xyz, a)   hi = (box.max.xyz, b)
-//   leaf:     a = first leaf reference (index into triRec / refTri), b = NODE_LEAF | count
-//   interior: a = index of child 0, b = flags | side index of its own box
-// For an INTERIOR node the box stored is the union of the boxes of its non-empty descendant leaves
-// (the exact lower bound of their bucket keys); the reference's own box lives
-// in the side array ownBox[2*side .. 2*side+1] and the traversal needs it only when a descendant
-// protrudes from it (NODE_OWN_TEST).
-constexpr int NODE_LEAF     = (int)0x80000000;
-constexpr int NODE_EMPTY    = 0x40000000;   // interior without any triangle below it
-constexpr int NODE_OWN_TEST = 0x20000000;
-constexpr int NODE_SIDE_MASK = 0x1fffffff;
+// MESH OCTREES use IMPLICIT boxes.  The reference derives the eight child boxes of a node from the
+// parent box alone (MO:207,217-218: half = (max-min)/2; min_c = min + half*(i,j,k); max_c = min_c + half),
+// so the traversal recomputes them with the same binary32 operations instead of loading them: a node
+// costs ALU only, and the only memory touched per interior node is its 32-byte block descriptor.
+//
+// Block descriptor = the 8 children (c = 4i+2j+k) of one interior node, two f4:
+//   w0 childBlockBase : interior child c owns block  childBlockBase + popcount(interiorMask & ((1<<c)-1))
+//   w1 refBase        : first leaf reference of this block's leaf children (stored contiguously, child order)
+//   w2 masks          : interiorMask | emptyMask << 8 | safeMask << 16
+//                       empty: leaf child without triangles (bucketed by the reference, can never hit, Q4)
+//                       safe : interior child whose non-empty descendant leaf boxes all lie inside its own
+//                              box, so its own entry key is a lower bound of every bucket key below it
+//                              (slab monotonicity) and it may be pruned by key
+//   w3 total          : leaf references of the block
+//   w4..w7 offs[8]    : 16-bit start offset of child c's references relative to refBase
+// Node id (for leaf ids / ties) = block * 8 + c, root = -1; childDfs[node id] = DFS pre-order index.
+//
+// The SCENE OCTREE (few nodes, DFS order matters) keeps explicit 32-byte records:
+//   lo = (box.min.xyz, a)  hi = (box.max.xyz, b);  leaf: a = first ref, b = NODE_LEAF | count;
+//   interior: a = index of child 0 (multiple of 8), b = 0.
+constexpr int NODE_LEAF = (int)0x80000000;
+constexpr int ROOT_NODE = -1;
 
 // Leaf reference, 48 B = three f4, stored in leaf order so a leaf is one contiguous run:
 //   a = (v1.xyz, N.x)  b = (E1.xyz, N.y)  c = (E2.xyz, N.z),  E1 = v2 - v1, E2 = v3 - v1 (RE:54-55,
 //   the same single binary32 subtraction the reference performs per test).  refTri[] holds the
 //   scene-global triangle id of each reference.
 
-struct MeshRec {        // 48 B
-    float bmin[3];      // Mesh.MeshBoundingBox (MESH:14)
-    int   rootNode;     // index of the root record (multiple of 8)
+struct MeshRec {        // 80 B = five f4
+    float bmin[3];      // Mesh.MeshBoundingBox (MESH:14, TMP:244-307)
+    int   rootBlock;    // block of the root's children, or -1 when the root is a leaf
     float bmax[3];
     int   triBase;      // global id of Triangles[0]
+    float rmin[3];      // MeshOctree root box (MO:59-80)
+    int   rootRef;      // root-is-leaf: first leaf reference
+    float rmax[3];
+    int   rootCount;    // root-is-leaf: triangle count
     int   ntri;
     int   material;
     int   maxDepth;
-    int   pad;
+    int   dfsBase;      // offset of this mesh's entries in childDfs (= rootBlock * 8 for interior roots)
 };
 
 struct ObjRec {         // 144 B
