@@ -40,7 +40,7 @@ void emu_tree_stats(emu_scene *s, int mesh, int *out) {
     const FlatTree &t = s->hs.meshTrees[mesh];
     out[0] = t.nodeCount; out[1] = t.leafCount; out[2] = t.emptyLeaves; out[3] = t.maxDepth; out[4] = t.unsafeNodes; out[5] = t.interiors;
 }
-// mode 0: scene query, mode 1: mesh query.  steps_out (nullable, 3 per ray): scene / node / leaf steps.
+// mode 0: scene query, mode 1: mesh query, mode 2: single-object scene prologue.  steps_out (nullable, 3 per ray): scene / node / leaf steps.
 static int fast_mode = 1;
 void emu_set_fast(int f) { fast_mode = f; }
 int emu_intersect(emu_scene *s, int mode, int mesh, const xrt_ray *rays, int64_t n, xrt_hit *hits, int64_t *steps_out) {

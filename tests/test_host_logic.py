@@ -122,6 +122,11 @@ def test_pruned_traversal_equals_reference_answer(xrt, orc, emul, name):
         assert hits_equal(o.intersect(sec), e.intersect(sec)) == {}
     # mesh-level query (MO:259) in object space
     assert hits_equal(o.mesh_intersect(0, rays[::5]), e.intersect(rays[::5], mode=1, mesh=0)) == {}
+    # single-object scenes also run through the collapsed prologue the GPU uses for them (MODE_SINGLE)
+    if len(spec.objects) == 1:
+        assert hits_equal(ho, e.intersect(rays, mode=2)) == {}
+        if len(sec):
+            assert hits_equal(o.intersect(sec), e.intersect(sec, mode=2)) == {}
 
 
 def soup_spec(xrt, n, seed, threshold, size):

@@ -52,7 +52,7 @@ struct FrameBuffers {
 
 int  intersect_stack_capacity(int needed);   // smallest compiled capacity >= needed, or -1
 void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeeded, int gridBlocks, hipStream_t st);
-int  intersect_blocks_per_cu(int stackNeeded);
+int  intersect_blocks_per_cu(int stackNeeded, int mode);
 void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long *counters, hipStream_t st);
 void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, xrt_hit *hits, int *index, int *count, int P, long long pathBase, hipStream_t st);
 void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,

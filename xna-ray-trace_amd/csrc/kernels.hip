@@ -53,7 +53,7 @@ constexpr int DEAD_RAY = -2;   // ignore_mesh marker of a path without a pixel (
 // ---- the hot kernel ------------------------------------------------------------------------------------------
 constexpr int RAY_BATCH = 256;     // rays a wave takes per queue atomic
 
-template <int T>
+template <int T, int M>
 __global__ __launch_bounds__(256) void k_intersect(SceneView S, IntersectArgs A) {
     __shared__ unsigned stk[4 * T * 64];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_intersect(SceneView S, IntersectArgs A)
                         v3 o, d; int im, it;
                         load_ray(A.rays + idx, o, d, im, it);
                         if (im == DEAD_RAY) { L.rayIndex = idx; L.sfound = 0; L.state = ST_FINISH; }
-                        else lane_begin(L, S, o, d, im, it, idx, A.mode, A.meshId);
+                        else lane_begin(L, S, o, d, im, it, idx, M, A.meshId);
                     }
                     batchNext += take;
                 }
@@ -96,56 +96,68 @@ __global__ __launch_bounds__(256) void k_intersect(SceneView S, IntersectArgs A)
             if (exhausted && idle == ~0ull) break;
         }
         // while-while: lanes gather in the same phase before the wave pays for that phase's code
-        while (__any(L.state == ST_SCENE)) {
-            if (L.state == ST_SCENE) advance_scene(L, S, st);
+        if (M == MODE_SCENE) {
+            while (__any(L.state == ST_SCENE)) {
+                if (L.state == ST_SCENE) advance_scene(L, S, st);
+            }
         }
         {   // the NaN-free box test is valid for the whole wave unless some live lane has a parallel axis or a non-finite ray
             const bool fast = !__any(L.state != ST_IDLE && (L.r.par != 0 || L.weird != 0));
             for (int it = 0; it < A.nodeBurst && __any(L.state == ST_NODE); it++) {
-                if (L.state == ST_NODE) advance_node(L, S, st, A.mode, fast);
+                if (L.state == ST_NODE) advance_node(L, S, st, M, fast);
             }
         }
         for (int it = 0; it < A.leafBurst && __any(L.state == ST_LEAF); it++) {
             if (L.state == ST_LEAF) advance_leaf(L, S);
         }
         if (L.state == ST_FINISH) {
-            store_hit(A.hits + L.rayIndex, lane_result(L, S, A.mode));
+            store_hit(A.hits + L.rayIndex, lane_result(L, S, M));
             L.state = ST_IDLE;
         }
     }
 }
 
 int intersect_stack_capacity(int needed) {
-    const int caps[] = {8, 12, 16, 24, 40, 72};
+    const int caps[] = {8, 12, 16, 24, 40};
     for (int c : caps) if (needed <= c) return c;
     return -1;
 }
-template <int T> static int bpc() {
+template <int T, int M> static int bpc() {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_intersect<T>, 256, 0) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_intersect<T, M>, 256, 0) != hipSuccess || nb < 1) nb = 1;
     return nb > 8 ? 8 : nb;
 }
-int intersect_blocks_per_cu(int stackNeeded) {
-    switch (intersect_stack_capacity(stackNeeded)) {
-        case 8: return bpc<8>();
-        case 12: return bpc<12>();
-        case 16: return bpc<16>();
-        case 24: return bpc<24>();
-        case 40: return bpc<40>();
-        case 72: return bpc<72>();
+template <int M> static int bpc_mode(int cap) {
+    switch (cap) {
+        case 8: return bpc<8, M>();
+        case 12: return bpc<12, M>();
+        case 16: return bpc<16, M>();
+        case 24: return bpc<24, M>();
+        default: return bpc<40, M>();
     }
-    return 1;
+}
+int intersect_blocks_per_cu(int stackNeeded, int mode) {
+    const int cap = intersect_stack_capacity(stackNeeded);
+    if (mode == MODE_SINGLE) return bpc_mode<MODE_SINGLE>(cap);
+    if (mode == MODE_MESH) return bpc_mode<MODE_MESH>(cap);
+    return bpc_mode<MODE_SCENE>(cap);
+}
+template <int M> static void launch_mode(int cap, dim3 g, const SceneView &S, const IntersectArgs &A, hipStream_t st) {
+    dim3 b(256);
+    switch (cap) {
+        case 8: hipLaunchKernelGGL((k_intersect<8, M>), g, b, 0, st, S, A); break;
+        case 12: hipLaunchKernelGGL((k_intersect<12, M>), g, b, 0, st, S, A); break;
+        case 16: hipLaunchKernelGGL((k_intersect<16, M>), g, b, 0, st, S, A); break;
+        case 24: hipLaunchKernelGGL((k_intersect<24, M>), g, b, 0, st, S, A); break;
+        default: hipLaunchKernelGGL((k_intersect<40, M>), g, b, 0, st, S, A); break;
+    }
 }
 void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeeded, int gridBlocks, hipStream_t st) {
-    dim3 g((unsigned)gridBlocks), b(256);
-    switch (intersect_stack_capacity(stackNeeded)) {
-        case 8: hipLaunchKernelGGL(k_intersect<8>, g, b, 0, st, S, A); break;
-        case 12: hipLaunchKernelGGL(k_intersect<12>, g, b, 0, st, S, A); break;
-        case 16: hipLaunchKernelGGL(k_intersect<16>, g, b, 0, st, S, A); break;
-        case 24: hipLaunchKernelGGL(k_intersect<24>, g, b, 0, st, S, A); break;
-        case 40: hipLaunchKernelGGL(k_intersect<40>, g, b, 0, st, S, A); break;
-        default: hipLaunchKernelGGL(k_intersect<72>, g, b, 0, st, S, A); break;
-    }
+    const int cap = intersect_stack_capacity(stackNeeded);
+    dim3 g((unsigned)gridBlocks);
+    if (A.mode == MODE_SINGLE) launch_mode<MODE_SINGLE>(cap, g, S, A, st);
+    else if (A.mode == MODE_MESH) launch_mode<MODE_MESH>(cap, g, S, A, st);
+    else launch_mode<MODE_SCENE>(cap, g, S, A, st);
 }
 
 // ---- reference work counters (untimed) ---------------------------------------------------------------------------
@@ -169,7 +181,7 @@ __device__ void count_mesh(const SceneView &S, const RayPre &r, int mesh, int ig
         if (!mfound || k <= mKey) {
             c[C_REFS] += (unsigned long long)cnt;
             int ign = 0;
-            if (ignoreId >= 0) for (int i = 0; i < cnt; i++) ign += (S.refTri[start + i] == ignoreId) ? 1 : 0;
+            if (ignoreId >= 0) for (int i = 0; i < cnt; i++) ign += (f2i(S.refN[start + i].w) == ignoreId) ? 1 : 0;
             c[C_TRIS] += (unsigned long long)(cnt - ign);
         }
     };
@@ -225,8 +237,9 @@ __global__ __launch_bounds__(256) void k_count(SceneView S, IntersectArgs A, uns
         if (im == DEAD_RAY) continue;
         c[C_RAYS]++;
         Lane L;
-        lane_begin(L, S, o, d, im, it, idx, A.mode, A.meshId);
-        run_query(L, S, stk, A.mode);
+        const int cmode = (A.mode == MODE_MESH) ? MODE_MESH : MODE_SCENE;   // the counting pass always walks the general machine
+        lane_begin(L, S, o, d, im, it, idx, cmode, A.meshId);
+        run_query(L, S, stk, cmode);
         if (L.sfound) c[C_HITS]++;
         if (A.mode == MODE_MESH) {
             c[C_MESH_QUERIES]++;

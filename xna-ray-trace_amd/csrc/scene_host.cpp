@@ -6,8 +6,8 @@
 namespace xrt {
 
 size_t SceneArrays::bytes() const {
-    return (blocks.size() + triRec.size() + snodes.size() + shade.size()) * sizeof(f4) +
-           (childDfs.size() + refTri.size() + srefs.size() + objMesh.size()) * sizeof(int) + meshes.size() * sizeof(MeshRec) +
+    return (blocks.size() + refN.size() + snodes.size() + shade.size()) * sizeof(f4) + refG.size() * sizeof(g3) +
+           (childDfs.size() + srefs.size() + objMesh.size()) * sizeof(int) + meshes.size() * sizeof(MeshRec) +
            objects.size() * sizeof(ObjRec) + materials.size() * sizeof(MaterialRec) + texels.size() * sizeof(uint32_t);
 }
 
@@ -66,7 +66,7 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
         FlatTree &t = meshTrees[mi];
         if (!build_mesh_tree(m, meshThreshold, t, err)) return false;   // Mesh.Init (MESH:27-32)
         const int blockBase = (int)(A.blocks.size() / 2);
-        const int refBase = (int)A.refTri.size();
+        const int refBase = (int)A.refN.size();
         for (size_t bi = 0; bi < t.blocks.size() / 2; bi++) {   // local -> global indices
             f4 lo = t.blocks[2 * bi], hi = t.blocks[2 * bi + 1];
             lo.x = i2f(f2i(lo.x) + blockBase);
@@ -74,13 +74,13 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
             A.blocks.push_back(lo); A.blocks.push_back(hi);
         }
         A.childDfs.insert(A.childDfs.end(), t.childDfs.begin(), t.childDfs.end());
-        for (int tri : t.leafRefs) {   // leaf references in leaf order: (v1,N.x) (E1,N.y) (E2,N.z)
+        for (int tri : t.leafRefs) {   // leaf references in leaf order: normal stream + geometry stream
             const float *p = &m.v[(size_t)tri * 9];
             const float *sn = &m.sn[(size_t)tri * 3];
-            A.triRec.push_back(f4{p[0], p[1], p[2], sn[0]});
-            A.triRec.push_back(f4{p[3] - p[0], p[4] - p[1], p[5] - p[2], sn[1]});   // Edge1 = v2 - v1 (RE:54)
-            A.triRec.push_back(f4{p[6] - p[0], p[7] - p[1], p[8] - p[2], sn[2]});   // Edge2 = v3 - v1 (RE:55)
-            A.refTri.push_back(triBase + tri);
+            A.refN.push_back(f4{sn[0], sn[1], sn[2], i2f(triBase + tri)});
+            A.refG.push_back(g3{p[0], p[1], p[2]});
+            A.refG.push_back(g3{p[3] - p[0], p[4] - p[1], p[5] - p[2]});   // Edge1 = v2 - v1 (RE:54)
+            A.refG.push_back(g3{p[6] - p[0], p[7] - p[1], p[8] - p[2]});   // Edge2 = v3 - v1 (RE:55)
         }
         MaterialRec mat;
         std::memset(&mat, 0, sizeof(mat));
@@ -127,8 +127,8 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
         A.objects.push_back(r);
     }
     // never hand out empty arrays (a zero-size allocation has no address)
-    if (A.triRec.empty()) A.triRec.assign(3, f4{0, 0, 0, 0});
-    if (A.refTri.empty()) A.refTri.assign(1, -1);
+    if (A.refN.empty()) A.refN.assign(1, f4{0, 0, 0, i2f(-1)});
+    if (A.refG.empty()) A.refG.assign(3, g3{0, 0, 0});
     if (A.srefs.empty()) A.srefs.assign(1, -1);
     if (A.objMesh.empty()) A.objMesh.assign(1, -1);
     if (A.shade.empty()) A.shade.assign(SHADE_F4, f4{0, 0, 0, 0});
@@ -146,7 +146,7 @@ SceneView HostScene::host_view() const {
     SceneView S;
     const SceneArrays &A = arrays;
     S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data();
-    S.triRec = A.triRec.data(); S.refTri = A.refTri.data(); S.meshes = A.meshes.data();
+    S.refN = A.refN.data(); S.refG = A.refG.data(); S.meshes = A.meshes.data();
     S.snodes = A.snodes.data(); S.srefs = A.srefs.data(); S.objects = A.objects.data(); S.objMesh = A.objMesh.data();
     S.nMeshes = (int)meshes.size(); S.nObjects = (int)objects.size();
     S.sceneDepth = A.sceneDepth + 1; S.meshDepth = A.meshDepth + 1;

@@ -20,8 +20,8 @@ namespace xrt {
 struct SceneView {
     const f4 *blocks;       // mesh octrees: 2 per block descriptor (implicit boxes, xrt_core.h)
     const int *childDfs;    // 8 per block: DFS pre-order index of child c
-    const f4 *triRec;       // 3 per leaf reference
-    const int *refTri;      // global triangle id per leaf reference
+    const f4 *refN;         // per leaf reference: (surfaceNormal.xyz, global triangle id)
+    const g3 *refG;         // 3 per leaf reference: v1, E1, E2
     const MeshRec *meshes;
     const f4 *snodes;       // scene octree, 2 per record
     const int *srefs;       // object id per scene leaf reference
@@ -32,7 +32,9 @@ struct SceneView {
 };
 
 enum : int { ST_IDLE = 0, ST_SCENE = 1, ST_NODE = 2, ST_LEAF = 3, ST_FINISH = 4 };
-enum : int { MODE_SCENE = 0, MODE_MESH = 1 };
+// MODE_SINGLE: a scene of one SceneObject with one Mesh (C1, C2, C5): the scene-level walk collapses into
+// the query's prologue and its registers disappear from the traversal loop.
+enum : int { MODE_SCENE = 0, MODE_MESH = 1, MODE_SINGLE = 2 };
 
 struct Lane {
     RayPre w;            // world ray (scene mode)
@@ -59,6 +61,7 @@ struct Lane {
     // leaf scan
     int ref, refEnd, leafNode;
     float leafKey;
+    int spec;            // the last leaf step met a front-facing triangle: fetch geometry together with the normals
     // scene best
     int sfound;
     float sbKey, sbD, sbU, sbV;
@@ -149,10 +152,32 @@ XRT_HD void lane_begin(Lane &L, const SceneView &S, v3 o, v3 d, int ignoreMesh, 
     L.sfound = 0;
     L.sbKey = 0; L.sbD = 0; L.sbU = 0; L.sbV = 0; L.sbRef = 0; L.sbLeaf = 0; L.sbObj = -1; L.sbMesh = -1;
     L.sRef = 0; L.sRefEnd = 0; L.mPtr = 0; L.mEnd = 0; L.ssp = 0; L.sKey = 0; L.obj = -1;
+    L.spec = 1;
     if (mode == MODE_SCENE) {
         L.w = make_ray(o, d);
         L.sblk = 0; L.smask = 1;   // root = slot 0 of block 0
         L.state = ST_SCENE;
+    } else if (mode == MODE_SINGLE) {
+        // OSM:318 root box (a leaf holding the one body), OSM:349-364 ray transform, MESH:34-39, then MO:259
+        RayPre w = make_ray(o, d);
+        L.state = ST_FINISH;
+        f4 lo = S.snodes[0], hi = S.snodes[1];
+        float key;
+        if (!slab(w, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, key)) return;
+        if ((f2i(hi.w) & 0x0fffffff) == 0) return;
+        const ObjRec &ob = S.objects[0];
+        v3 v1 = transform(o, ob.invWorld);
+        v3 v2 = transform(add(o, d), ob.invWorld);
+        v3 dir = normalize(sub(v2, v1));
+        L.r = make_ray(v1, dir);
+        L.dmask = dir_mask(dir);
+        if (!(is_finite(v1.x) && is_finite(v1.y) && is_finite(v1.z) && is_finite(dir.x) && is_finite(dir.y) && is_finite(dir.z))) L.weird = 1;
+        L.obj = 0;
+        L.sKey = key;
+        const MeshRec &mr = S.meshes[0];
+        float k;
+        if (!slab(L.r, mr.bmin[0], mr.bmin[1], mr.bmin[2], mr.bmax[0], mr.bmax[1], mr.bmax[2], k)) return;
+        begin_mesh_query(L, S, 0);
     } else {
         L.w = make_ray(o, d);
         L.r = L.w;
@@ -225,7 +250,7 @@ XRT_HD void finish_mesh_query(Lane &L, int mode) {
             L.sbRef = L.mRef; L.sbLeaf = L.mLeaf; L.sbObj = L.obj; L.sbMesh = L.mesh;
         }
     }
-    L.state = (mode == MODE_SCENE) ? ST_SCENE : ST_FINISH;
+    L.state = (mode == MODE_SCENE) ? ST_SCENE : ST_FINISH;   // MODE_SINGLE: the one body's one mesh was the whole scene
 }
 
 // ---- mesh level: one child of the current block (MO:328-353), front to back, with key pruning ------------------
@@ -287,9 +312,9 @@ XRT_HD void advance_node(Lane &L, const SceneView &S, Stack &stk, int mode, bool
 }
 
 // ---- leaf: triangles of MO:288-304 --------------------------------------------------------------------------------
-XRT_HD void leaf_candidate(Lane &L, const SceneView &S, int r, bool pass, float u, float v, float dist) {
+XRT_HD void leaf_candidate(Lane &L, const SceneView &S, int r, int triId, bool pass, float u, float v, float dist) {
     if (pass && dist < FLT_MAX) {   // MO:293-294 (minDistance starts at float.MaxValue)
-        if (S.refTri[r] != L.ignoreId) {   // MO:290
+        if (triId != L.ignoreId) {   // MO:290
             bool better;
             if (!L.mfound || L.leafKey < L.mKey) better = true;
             else if (L.leafKey == L.mKey) {
@@ -304,18 +329,35 @@ XRT_HD void leaf_candidate(Lane &L, const SceneView &S, int r, bool pass, float 
         }
     }
 }
-// Two references per step: six 16-byte loads in flight per lane.
+// Two references per step.  The 16-byte normal records decide the back-face test; the 36-byte geometry is
+// fetched only for front-facing references — together with the normals when the lane's previous step met a
+// front-facing triangle (`spec`), one round trip later otherwise.  Rays leaving a surface see almost only
+// back faces around their origin, so most of their references cost 16 bytes and five multiply-adds.
 XRT_HD void advance_leaf(Lane &L, const SceneView &S) {
     const int r0 = L.ref;
     const bool two = (r0 + 1) < L.refEnd;
     const int r1 = two ? r0 + 1 : r0;
-    f4 a0 = S.triRec[3 * (size_t)r0], b0 = S.triRec[3 * (size_t)r0 + 1], c0 = S.triRec[3 * (size_t)r0 + 2];
-    f4 a1 = S.triRec[3 * (size_t)r1], b1 = S.triRec[3 * (size_t)r1 + 1], c1 = S.triRec[3 * (size_t)r1 + 2];
-    float u0, v0, t0, u1, v1, t1;
-    bool p0 = tri_test(L.r.o, L.r.d, a0, b0, c0, u0, v0, t0);
-    bool p1 = tri_test(L.r.o, L.r.d, a1, b1, c1, u1, v1, t1);
-    leaf_candidate(L, S, r0, p0, u0, v0, t0);
-    if (two) leaf_candidate(L, S, r1, p1, u1, v1, t1);
+    const f4 n0 = S.refN[r0], n1 = S.refN[r1];
+    g3 a0 = {0, 0, 0}, b0 = {0, 0, 0}, c0 = {0, 0, 0}, a1 = {0, 0, 0}, b1 = {0, 0, 0}, c1 = {0, 0, 0};
+    const bool spec = L.spec != 0;
+    if (spec) {
+        a0 = S.refG[3 * (size_t)r0]; b0 = S.refG[3 * (size_t)r0 + 1]; c0 = S.refG[3 * (size_t)r0 + 2];
+        a1 = S.refG[3 * (size_t)r1]; b1 = S.refG[3 * (size_t)r1 + 1]; c1 = S.refG[3 * (size_t)r1 + 2];
+    }
+    const bool f0 = !(facing(mk(n0.x, n0.y, n0.z), L.r.d) > 0.0f);            // RE:48-51
+    const bool f1 = two && !(facing(mk(n1.x, n1.y, n1.z), L.r.d) > 0.0f);
+    if ((f0 || f1) && !spec) {
+        a0 = S.refG[3 * (size_t)r0]; b0 = S.refG[3 * (size_t)r0 + 1]; c0 = S.refG[3 * (size_t)r0 + 2];
+        a1 = S.refG[3 * (size_t)r1]; b1 = S.refG[3 * (size_t)r1 + 1]; c1 = S.refG[3 * (size_t)r1 + 2];
+    }
+    if (f0 || f1) {
+        float u0, v0, t0, u1, v1, t1;
+        bool p0 = tri_test_front(L.r.o, L.r.d, mk(a0.x, a0.y, a0.z), mk(b0.x, b0.y, b0.z), mk(c0.x, c0.y, c0.z), u0, v0, t0);
+        bool p1 = tri_test_front(L.r.o, L.r.d, mk(a1.x, a1.y, a1.z), mk(b1.x, b1.y, b1.z), mk(c1.x, c1.y, c1.z), u1, v1, t1);
+        leaf_candidate(L, S, r0, f2i(n0.w), f0 && p0, u0, v0, t0);
+        leaf_candidate(L, S, r1, f2i(n1.w), f1 && p1, u1, v1, t1);
+    }
+    L.spec = (f0 || f1) ? 1 : 0;
     L.ref = r0 + 2;
     if (L.ref >= L.refEnd) L.state = ST_NODE;
 }
@@ -330,15 +372,15 @@ XRT_HD HitOut lane_result(const Lane &L, const SceneView &S, int mode) {
     h.hit = 0; h.object = -1; h.mesh = -1; h.tri = -1; h.leaf = -1;
     h.u = 0; h.v = 0; h.d = 0; h.wx = 0; h.wy = 0; h.wz = 0;
     if (!L.sfound) return h;
-    f4 a = S.triRec[3 * L.sbRef], b = S.triRec[3 * L.sbRef + 1], c = S.triRec[3 * L.sbRef + 2];
+    g3 a = S.refG[3 * (size_t)L.sbRef], b = S.refG[3 * (size_t)L.sbRef + 1], c = S.refG[3 * (size_t)L.sbRef + 2];
     v3 v1 = mk(a.x, a.y, a.z), p1 = mk(b.x, b.y, b.z), p2 = mk(c.x, c.y, c.z);
     v3 pos = add(add(v1, scale(p1, L.sbU)), scale(p2, L.sbV));   // MO:310-312
     h.hit = 1;
     h.mesh = L.sbMesh;
-    h.tri = S.refTri[L.sbRef] - S.meshes[L.sbMesh].triBase;
+    h.tri = f2i(S.refN[L.sbRef].w) - S.meshes[L.sbMesh].triBase;
     h.leaf = node_dfs(S, L.sbLeaf);
     h.u = L.sbU; h.v = L.sbV; h.d = L.sbD;
-    if (mode == MODE_SCENE) {
+    if (mode != MODE_MESH) {
         h.object = L.sbObj;
         pos = transform(pos, S.objects[L.sbObj].world);   // OSM:441-443
     }

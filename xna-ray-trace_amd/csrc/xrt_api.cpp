@@ -69,8 +69,9 @@ struct xrt_scene {
     int device = -1;   // -1: host-only scene (inspection of the built trees; every compute call fails)
     HostScene hs;
     // HBM-resident scene
-    DevBuf<f4> blocks, triRec, snodes, shade;
-    DevBuf<int> childDfs, refTri, srefs, objMesh;
+    DevBuf<f4> blocks, refN, snodes, shade;
+    DevBuf<g3> refG;
+    DevBuf<int> childDfs, srefs, objMesh;
     DevBuf<MeshRec> meshes;
     DevBuf<ObjRec> objects;
     DevBuf<MaterialRec> materials;
@@ -79,7 +80,8 @@ struct xrt_scene {
     bool resident = false;
     int numCUs = 256;
     int stackNeeded = 2;
-    int blocksPerCU = 1;
+    int blocksPerCU = 1, blocksPerCUMesh = 1;
+    int sceneMode = MODE_SCENE;   // MODE_SINGLE when the scene is one SceneObject with one Mesh
     hipStream_t stream = nullptr;
     // per-frame work buffers
     DevBuf<xrt_ray> rays0, rays1, shadowRays, apiRays;
@@ -101,8 +103,8 @@ struct xrt_scene {
             (void)hipSetDevice(device);
             for (auto e : events) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
-            blocks.release(); triRec.release(); snodes.release(); shade.release();
-            childDfs.release(); refTri.release(); srefs.release(); objMesh.release(); meshes.release();
+            blocks.release(); refN.release(); refG.release(); snodes.release(); shade.release();
+            childDfs.release(); srefs.release(); objMesh.release(); meshes.release();
             objects.release(); materials.release(); texels.release();
             rays0.release(); rays1.release(); shadowRays.release(); apiRays.release(); hits.release();
             shadowHits.release(); apiHits.release(); path0.release(); path1.release(); shadowSrc.release();
@@ -276,7 +278,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
             const int cur = k & 1, nxt = cur ^ 1;
             IntersectArgs A;
             A.rays = rays[cur]; A.hits = s->hits.p; A.index = k == 0 ? paths[1] : nullptr; A.nDev = cnt + k; A.nMul = 1; A.n = Pc;
-            A.queue = q + 2 * k; A.mode = MODE_SCENE; A.meshId = 0;
+            A.queue = q + 2 * k; A.mode = s->sceneMode; A.meshId = 0;
             A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2];
             hipEvent_t a0 = get_event(s, ev), a1 = get_event(s, ev + 1);
             if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
@@ -294,7 +296,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
             if (nL > 0) {
                 IntersectArgs B;
                 B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.index = nullptr; B.nDev = scnt + k; B.nMul = nL; B.n = 0;
-                B.queue = q + 2 * k + 1; B.mode = MODE_SCENE; B.meshId = 0;
+                B.queue = q + 2 * k + 1; B.mode = s->sceneMode; B.meshId = 0;
                 B.refillMin = s->tune[0]; B.nodeBurst = s->tune[1]; B.leafBurst = s->tune[2];
                 hipEvent_t b0 = get_event(s, ev), b1 = get_event(s, ev + 1);
                 if (!b0 || !b1) return fail(XRT_E_HIP, "hipEventCreate failed");
@@ -481,19 +483,23 @@ int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_thre
     if (scene->device < 0) return XRT_OK;   // host-only scene: trees can be inspected, nothing can be traced
     HIPCHECK(hipSetDevice(scene->device));
     int rc;
-    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->triRec, A.triRec)) ||
+    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->refN, A.refN)) || (rc = upload(scene->refG, A.refG)) ||
         (rc = upload(scene->snodes, A.snodes)) || (rc = upload(scene->shade, A.shade)) || (rc = upload(scene->childDfs, A.childDfs)) ||
-        (rc = upload(scene->refTri, A.refTri)) || (rc = upload(scene->srefs, A.srefs)) || (rc = upload(scene->objMesh, A.objMesh)) ||
+        (rc = upload(scene->srefs, A.srefs)) || (rc = upload(scene->objMesh, A.objMesh)) ||
         (rc = upload(scene->meshes, A.meshes)) || (rc = upload(scene->objects, A.objects)) || (rc = upload(scene->materials, A.materials)) ||
         (rc = upload(scene->texels, A.texels)))
         return rc;
     SceneView &S = scene->view;
-    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.triRec = scene->triRec.p;
-    S.refTri = scene->refTri.p; S.meshes = scene->meshes.p; S.snodes = scene->snodes.p; S.srefs = scene->srefs.p;
+    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.refN = scene->refN.p; S.refG = scene->refG.p;
+    S.meshes = scene->meshes.p; S.snodes = scene->snodes.p; S.srefs = scene->srefs.p;
     S.objects = scene->objects.p; S.objMesh = scene->objMesh.p;
     S.nMeshes = (int)scene->hs.meshes.size(); S.nObjects = (int)scene->hs.objects.size();
     S.sceneDepth = A.sceneDepth + 1; S.meshDepth = A.meshDepth + 1;
-    scene->blocksPerCU = intersect_blocks_per_cu(scene->stackNeeded);
+    scene->sceneMode = (scene->hs.objects.size() == 1 && scene->hs.objects[0].meshes.size() == 1 && scene->hs.meshes.size() == 1 &&
+                        scene->hs.sceneTree.nodeCount == 1) ? MODE_SINGLE : MODE_SCENE;
+    if (getenv("XRT_NO_SINGLE")) scene->sceneMode = MODE_SCENE;
+    scene->blocksPerCU = intersect_blocks_per_cu(scene->stackNeeded, scene->sceneMode);
+    scene->blocksPerCUMesh = intersect_blocks_per_cu(scene->stackNeeded, MODE_MESH);
     scene->resident = true;
     return XRT_OK;
 }
@@ -525,7 +531,7 @@ int xrt_scene_intersect(xrt_scene *scene, const xrt_ray *rays, const int32_t *ig
     if ((rc = scene->apiRays.ensure((size_t)n)) || (rc = scene->apiHits.ensure((size_t)n))) return rc;
     hipStream_t st = scene->stream;
     if (n > 0) HIPCHECK(hipMemcpyAsync(scene->apiRays.p, rays, (size_t)n * sizeof(xrt_ray), hipMemcpyHostToDevice, st));
-    if ((rc = run_intersect(scene, scene->apiRays.p, n, scene->apiHits.p, MODE_SCENE, 0, st, stats_out, false))) return rc;
+    if ((rc = run_intersect(scene, scene->apiRays.p, n, scene->apiHits.p, scene->sceneMode, 0, st, stats_out, false))) return rc;
     if (n > 0) HIPCHECK(hipMemcpyAsync(hits_out, scene->apiHits.p, (size_t)n * sizeof(xrt_hit), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
     return XRT_OK;
@@ -536,7 +542,7 @@ int xrt_scene_intersect_device(xrt_scene *scene, const void *d_rays, int64_t n, 
     if (rc != XRT_OK) return rc;
     if (n < 0 || (n > 0 && (!d_rays || !d_hits_out))) return fail(XRT_E_INVALID_ARG, "xrt_scene_intersect_device: null argument");
     if (((uintptr_t)d_rays & 15) || ((uintptr_t)d_hits_out & 15)) return fail(XRT_E_INVALID_ARG, "device buffers must be 16-byte aligned");
-    return run_intersect(scene, (const xrt_ray *)d_rays, n, (xrt_hit *)d_hits_out, MODE_SCENE, 0, (hipStream_t)stream, nullptr, false);
+    return run_intersect(scene, (const xrt_ray *)d_rays, n, (xrt_hit *)d_hits_out, scene->sceneMode, 0, (hipStream_t)stream, nullptr, false);
 }
 
 int xrt_mesh_intersect(xrt_scene *scene, int32_t mesh_id, const xrt_ray *rays, int64_t n, xrt_hit *hits_out) {

@@ -51,10 +51,13 @@ XRT_HD float i2f(int i)   { return __builtin_bit_cast(float, i); }
 constexpr int NODE_LEAF = (int)0x80000000;
 constexpr int ROOT_NODE = -1;
 
-// Leaf reference, 48 B = three f4, stored in leaf order so a leaf is one contiguous run:
-//   a = (v1.xyz, N.x)  b = (E1.xyz, N.y)  c = (E2.xyz, N.z),  E1 = v2 - v1, E2 = v3 - v1 (RE:54-55,
-//   the same single binary32 subtraction the reference performs per test).  refTri[] holds the
-//   scene-global triangle id of each reference.
+// Leaf reference, stored in leaf order so a leaf is one contiguous run, split in two streams:
+//   refN[r] = (surfaceNormal.xyz, as_float(scene-global triangle id))      16 B — enough for the back-face
+//             test RE:48-51 and the ignoreTriangle test MO:290; most references end here
+//   refG[r] = v1.xyz, E1.xyz, E2.xyz                                        36 B — only for front-facing ones;
+//             E1 = v2 - v1, E2 = v3 - v1 (RE:54-55, the same single binary32 subtraction the reference
+//             performs per test)
+struct g3 { float x, y, z; };
 
 struct MeshRec {        // 80 B = five f4
     float bmin[3];      // Mesh.MeshBoundingBox (MESH:14, TMP:244-307)
@@ -187,17 +190,16 @@ XRT_HD bool slab(const RayPre &r, float mnx, float mny, float mnz, float mxx, fl
     return ok;
 }
 
-// RayExtensions.IntersectsTriangleBackfaceCulling (RE:42-75) on a leaf reference (a,b,c).
-XRT_HD bool tri_test(v3 O, v3 D, f4 a, f4 b, f4 c, float &u, float &v, float &dist) {
-    float nd = (a.w * D.x + b.w * D.y) + c.w * D.z;   // RE:49
-    v3 T = mk(O.x - a.x, O.y - a.y, O.z - a.z);       // RE:46
-    v3 E1 = mk(b.x, b.y, b.z), E2 = mk(c.x, c.y, c.z);
+// RayExtensions.IntersectsTriangleBackfaceCulling (RE:42-75), split at the back-face test.
+XRT_HD float facing(v3 N, v3 D) { return (N.x * D.x + N.y * D.y) + N.z * D.z; }   // RE:49; culled when > 0 (RE:50)
+XRT_HD bool tri_test_front(v3 O, v3 D, v3 v1, v3 E1, v3 E2, float &u, float &v, float &dist) {
+    v3 T = mk(O.x - v1.x, O.y - v1.y, O.z - v1.z);    // RE:46
     v3 P = cross(D, E2);                              // RE:58
     v3 Q = cross(T, E1);                              // RE:59
     float row1 = dot(Q, E2), row2 = dot(P, T), row3 = dot(Q, D);   // RE:62-64
     float inv = 1.0f / dot(P, E1);                    // RE:66
     dist = row1 * inv; u = row2 * inv; v = row3 * inv;
-    return !(nd > 0.0f) && u >= 0.0f && v >= 0.0f && dist >= 0.0f && (u + v) <= 1.0f;   // RE:50,71-74
+    return u >= 0.0f && v >= 0.0f && dist >= 0.0f && (u + v) <= 1.0f;   // RE:71-74
 }
 
 // ---- Color (RT:584,705,726,732) ---------------------------------------------------------------------------
