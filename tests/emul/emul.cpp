@@ -2,6 +2,7 @@
 // xna-ray-trace_amd/csrc/traverse.h on the CPU, one lane at a time, so the pruned front-to-back walk can
 // be checked against the oracle without a GPU (`-m "not gpu"` host-logic tests).  libxrt never links
 // this file and has no CPU execution path.
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -65,6 +66,71 @@ int emu_intersect(emu_scene *s, int mode, int mesh, const xrt_ray *rays, int64_t
         o.hit = h.hit; o.object = h.object; o.mesh = h.mesh; o.tri = h.tri; o.leaf = h.leaf;
         o.u = h.u; o.v = h.v; o.d = h.d; o.wx = h.wx; o.wy = h.wy; o.wz = h.wz;
         if (steps_out) { steps_out[3 * i] = st[0]; steps_out[3 * i + 1] = st[1]; steps_out[3 * i + 2] = st[2]; }
+    }
+    return 0;
+}
+
+// Wave-level model of k_intersect's scheduling (development aid): 64 lanes, the same refill rule and phase
+// bursts as kernels.hip; reports how many wave-steps each phase takes and how many lanes were active in them.
+// out[0..]: refills, refilled lanes, scene steps, scene lanes, node steps, node lanes, leaf steps, leaf lanes,
+//           node-pop lanes, node-descend lanes, leaf-geometry lanes, outer iterations
+int emu_wave_sim(emu_scene *s, int mode, int mesh, const xrt_ray *rays, int64_t n, int nWaves, int refillMin, int nodeBurst, int leafBurst, int64_t *out) {
+    if (!s->hs.built) return -1;
+    SceneView S = s->hs.host_view();
+    for (int i = 0; i < 12; i++) out[i] = 0;
+    const int BATCH = 256;
+    std::vector<Lane> L(64);
+    std::vector<EmuStack> stk(64);
+    int64_t queue = (int64_t)nWaves * BATCH;
+    for (int w = 0; w < nWaves; w++) {
+        for (auto &l : L) { std::memset(&l, 0, sizeof(Lane)); l.state = ST_IDLE; }
+        int64_t batchNext = (int64_t)w * BATCH, batchEnd = std::min<int64_t>(batchNext + BATCH, n);
+        bool exhausted = batchNext >= n;
+        for (;;) {
+            int nIdle = 0;
+            for (auto &l : L) nIdle += l.state == ST_IDLE;
+            if (nIdle) {
+                if (!exhausted && (nIdle >= refillMin || nIdle == 64)) {
+                    if (batchNext >= batchEnd) {
+                        // dynamic batches: emulate the queue as round-robin over waves
+                        batchNext = queue + (int64_t)0; queue += BATCH;
+                        batchEnd = std::min<int64_t>(batchNext + BATCH, n);
+                        if (batchNext >= n) exhausted = true;
+                    }
+                    if (!exhausted) {
+                        int take = (int)std::min<int64_t>(nIdle, batchEnd - batchNext);
+                        int rank = 0;
+                        for (auto &l : L) if (l.state == ST_IDLE) {
+                            if (rank < take) {
+                                const xrt_ray &r = rays[batchNext + rank];
+                                lane_begin(l, S, mk(r.o[0], r.o[1], r.o[2]), mk(r.d[0], r.d[1], r.d[2]), r.ignore_mesh, r.ignore_tri, (int)(batchNext + rank), mode, mesh);
+                            }
+                            rank++;
+                        }
+                        out[0]++; out[1] += take;
+                        batchNext += take;
+                    }
+                }
+                if (exhausted && nIdle == 64) break;
+            }
+            out[11]++;
+            auto any = [&](int st) { for (auto &l : L) if (l.state == st) return true; return false; };
+            if (mode == MODE_SCENE) while (any(ST_SCENE)) { out[2]++; for (size_t i = 0; i < 64; i++) if (L[i].state == ST_SCENE) { out[3]++; advance_scene(L[i], S, stk[i]); } }
+            for (int it = 0; it < nodeBurst && any(ST_NODE); it++) {
+                out[4]++;
+                for (size_t i = 0; i < 64; i++) if (L[i].state == ST_NODE) {
+                    out[5]++;
+                    int sp0 = L[i].sp; bool wasEmpty = L[i].mask == 0;
+                    advance_node(L[i], S, stk[i], mode, L[i].r.par == 0 && !L[i].weird);
+                    if (wasEmpty) out[8]++; else if (L[i].sp > sp0) out[9]++;
+                }
+            }
+            for (int it = 0; it < leafBurst && any(ST_LEAF); it++) {
+                out[6]++;
+                for (size_t i = 0; i < 64; i++) if (L[i].state == ST_LEAF) { out[7]++; int sp = L[i].spec; advance_leaf(L[i], S); if (L[i].spec || sp) out[10]++; }
+            }
+            for (auto &l : L) if (l.state == ST_FINISH) l.state = ST_IDLE;
+        }
     }
     return 0;
 }

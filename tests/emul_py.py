@@ -42,6 +42,7 @@ def lib():
         l.emu_get_tree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64)]
         l.emu_tree_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         l.emu_intersect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        l.emu_wave_sim.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _lib = l
     return _lib
 
@@ -98,3 +99,11 @@ class EmulScene:
         rc = lib().emu_intersect(self.h, mode, mesh, rays.ctypes.data, rays.shape[0], hits.ctypes.data, st.ctypes.data if steps else None)
         assert rc == 0, rc
         return (hits, st) if steps else hits
+
+    def wave_sim(self, rays, mode=0, mesh=0, n_waves=64, tune=(24, 64, 32)):
+        """Wave-level scheduling model of the traversal kernel: step and active-lane counts per phase."""
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        out = np.zeros(12, dtype=np.int64)
+        assert lib().emu_wave_sim(self.h, mode, mesh, rays.ctypes.data, rays.shape[0], n_waves, tune[0], tune[1], tune[2], out.ctypes.data) == 0
+        names = ("refills", "refilled", "scene_steps", "scene_lanes", "node_steps", "node_lanes", "leaf_steps", "leaf_lanes", "pop_lanes", "descend_lanes", "geom_lanes", "outer")
+        return dict(zip(names, out.tolist()))

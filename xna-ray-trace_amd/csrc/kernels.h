@@ -27,6 +27,7 @@ struct IntersectArgs {
     int n;
     unsigned *queue;    // zeroed work-queue head of this launch
     int mode, meshId;
+    int firstBatch;     // rays of the static first batch of every wave
     int refillMin, nodeBurst, leafBurst;   // scheduling knobs of the persistent loop (defaults in xrt_api.cpp; XRT_TUNE overrides)
 };
 

@@ -50,8 +50,29 @@ __device__ __forceinline__ void store_ray(xrt_ray *dst, v3 o, v3 d, int im, int 
 }
 constexpr int DEAD_RAY = -2;   // ignore_mesh marker of a path without a pixel (edge tiles)
 
+// Stream compaction with ONE global atomic per 1024-thread block and round (atomics on one word serialise at
+// ~11 ns each, MI355X_MICROARCH.md "dequeue"): waves post their ballot counts to LDS, thread 0 reserves the
+// block's range, every flagged lane gets base + (lanes of earlier waves) + (earlier lanes of its wave).
+// Must be called by all threads of the block.
+constexpr int APPEND_BLOCK = 1024;
+__device__ __forceinline__ int block_append(int *counter, bool flag, int *ldsCounts /* [17] */) {
+    const unsigned long long m = __ballot(flag);
+    const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+    if (lane_id() == 0) ldsCounts[wave] = (int)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int w = 0; w < nw; w++) { int c = ldsCounts[w]; ldsCounts[w] = total; total += c; }
+        ldsCounts[16] = total ? atomicAdd(counter, total) : 0;
+    }
+    __syncthreads();
+    const int slot = ldsCounts[16] + ldsCounts[wave] + lanes_below(m);
+    __syncthreads();   // ldsCounts is reused by the next round
+    return slot;
+}
+
 // ---- the hot kernel ------------------------------------------------------------------------------------------
-constexpr int RAY_BATCH = 256;     // rays a wave takes per queue atomic
+constexpr int RAY_BATCH_MAX = 512; // largest guided batch a wave takes per queue atomic
 
 template <int T, int M>
 __global__ __launch_bounds__(256) void k_intersect(SceneView S, IntersectArgs A) {
@@ -61,24 +82,38 @@ __global__ __launch_bounds__(256) void k_intersect(SceneView S, IntersectArgs A)
     const int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
     Lane L;
     L.state = ST_IDLE;
-    // the first batch of every wave is static (a grid-wide burst of atomics on one word costs ~11 ns each);
-    // further batches come from the queue
+    // Work distribution.  The first 64 rays of every wave are static (no atomic: a grid-wide burst on one word
+    // costs ~11 ns each); consecutive static batches go to different workgroups, hence different CUs, because
+    // image regions with expensive rays are contiguous in the ray stream and must not pile up on one CU.
+    // Further batches come from the queue, guided (large while much work remains, 64 rays near the end), and
+    // the next one is requested while the current one is being traced so the atomic's latency is hidden.
     const int nWaves = (int)gridDim.x * 4;
-    int batchNext = ((int)blockIdx.x * 4 + wave) * RAY_BATCH;
-    int batchEnd = min(batchNext + RAY_BATCH, n);
+    const int first = A.firstBatch;   // 64 for deep octrees (dynamic balance matters), 256 for trivial scenes (fixed costs matter)
+    const unsigned qOffset = (unsigned)(nWaves * first);
+    int batchNext = (wave * (int)gridDim.x + (int)blockIdx.x) * first;
+    int batchEnd = min(batchNext + first, n);
     bool exhausted = batchNext >= n;
+    auto guided = [&](int done) { int c = (n - done) / (nWaves * 2); c &= ~63; return c < 64 ? 64 : (c > RAY_BATCH_MAX ? RAY_BATCH_MAX : c); };
+    unsigned pfBase = 0;
+    int pfChunk = 0;
+    if (!exhausted && (int)qOffset < n) {   // there is dynamic work beyond the static batches
+        pfChunk = guided((int)qOffset);
+        if (lane == 0) pfBase = atomicAdd(A.queue, (unsigned)pfChunk);
+    }
     for (;;) {
         const unsigned long long idle = __ballot(L.state == ST_IDLE);
         if (idle != 0ull) {
             const int nIdle = __popcll(idle);
             if (!exhausted && (nIdle >= A.refillMin || idle == ~0ull)) {
                 if (batchNext >= batchEnd) {
-                    unsigned base = 0;
-                    if (lane == 0) base = atomicAdd(A.queue, (unsigned)RAY_BATCH);
-                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + (unsigned)(nWaves * RAY_BATCH);
+                    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pfBase) + qOffset;
                     batchNext = (int)base;
-                    batchEnd = min((int)base + RAY_BATCH, n);
-                    if ((int)base >= n || (int)base < 0) exhausted = true;
+                    batchEnd = min((int)base + pfChunk, n);
+                    if (pfChunk == 0 || (int)base >= n || (int)base < 0) exhausted = true;
+                    else {
+                        pfChunk = guided(batchEnd);
+                        if (lane == 0) pfBase = atomicAdd(A.queue, (unsigned)pfChunk);
+                    }
                 }
                 if (!exhausted) {
                     const int take = min(nIdle, batchEnd - batchNext);
@@ -322,8 +357,9 @@ __device__ __forceinline__ bool path_pixel(const RayGenParams &g, long long pix,
 
 // Rays that miss the scene octree's root box are answered here (OSM:318-320: no cuboid collected -> return
 // false) and the others are appended, wave by wave, to a compact index list for the traversal kernel.
-__global__ __launch_bounds__(256) void k_raygen(RayGenParams g, SceneView S, xrt_ray *rays, xrt_hit *hits, int *index, int *count, int P,
-                                                long long pathBase) {
+__global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneView S, xrt_ray *rays, xrt_hit *hits, int *index, int *count, int P,
+                                                         long long pathBase) {
+    __shared__ int ldsCounts[17];
     const f4 rlo = S.snodes[0], rhi = S.snodes[1];
     const int stride = (int)(gridDim.x * blockDim.x);
     const int rounds = (P + stride - 1) / stride;
@@ -359,23 +395,18 @@ __global__ __launch_bounds__(256) void k_raygen(RayGenParams g, SceneView S, xrt
                 store_hit(hits + p, h);
             }
         }
-        if (index) {
-            const unsigned long long m = __ballot(live);
-            if (m == 0ull) continue;
-            int base = 0;
-            const int leader = (int)__builtin_ctzll(m);
-            if (lane_id() == leader) base = atomicAdd(count, (int)__popcll(m));
-            base = __shfl(base, leader);
-            if (live) index[base + lanes_below(m)] = p;
+        if (index) {   // block-uniform
+            const int slot = block_append(count, live, ldsCounts);
+            if (live) index[slot] = p;
         }
     }
 }
 void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, xrt_hit *hits, int *index, int *count, int P, long long pathBase,
                    hipStream_t st) {
-    int blocks = (P + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    int blocks = (P + APPEND_BLOCK - 1) / APPEND_BLOCK;
+    if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, g, S, rays, hits, index, count, P, pathBase);
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(APPEND_BLOCK), 0, st, g, S, rays, hits, index, count, P, pathBase);
 }
 
 // ---- shading ----------------------------------------------------------------------------------------------------------
@@ -416,9 +447,10 @@ __device__ __forceinline__ void light_dir(const LightRec &L, v3 world, v3 &dir, 
 
 // Stage A of CastRay for one generation of rays: misses terminate their path (RT:729-733); every hit
 // emits one shadow ray per light (RT:535-537 -> RT:482-485), compacted with one atomic per wave.
-__global__ __launch_bounds__(256) void k_shade_a(SceneView S, ShadeView V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev,
+__global__ __launch_bounds__(APPEND_BLOCK) void k_shade_a(SceneView S, ShadeView V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev,
                                                  int nHost, const int *rayPath, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc,
                                                  int *scnt, int P, int level) {
+    __shared__ int ldsCounts[17];
     const int n = nDev ? *nDev : nHost;
     const int stride = (int)(gridDim.x * blockDim.x);
     const int rounds = (n + stride - 1) / stride;
@@ -433,14 +465,8 @@ __global__ __launch_bounds__(256) void k_shade_a(SceneView S, ShadeView V, const
             p = rayPath ? rayPath[i] : i;
             if (!hit) lvlB[(size_t)level * P + p] = f4{0, 0, 0, i2f(FLAG_MISS)};
         }
-        const unsigned long long m = __ballot(hit != 0);
-        if (m == 0ull) continue;
-        int base = 0;
-        const int leader = (int)__builtin_ctzll(m);
-        if (lane_id() == leader) base = atomicAdd(scnt, (int)__popcll(m));
-        base = __shfl(base, leader);
+        const int slot = block_append(scnt, hit != 0, ldsCounts);
         if (hit) {
-            const int slot = base + lanes_below(m);
             shadowSrc[slot] = i;
             for (int l = 0; l < V.nLights; l++) {
                 v3 dir; float dist;
@@ -452,7 +478,7 @@ __global__ __launch_bounds__(256) void k_shade_a(SceneView S, ShadeView V, const
 }
 void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
                     const int *rayPath, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level, hipStream_t st) {
-    hipLaunchKernelGGL(k_shade_a, dim3(2048), dim3(256), 0, st, S, V, rays, hits, nDev, nHost, rayPath, lvlB, shadowRays, shadowSrc, scnt, P, level);
+    hipLaunchKernelGGL(k_shade_a, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, rays, hits, nDev, nHost, rayPath, lvlB, shadowRays, shadowSrc, scnt, P, level);
 }
 
 // MAT:71-160 LookupUV: address mode + point sample
@@ -485,9 +511,10 @@ __device__ __forceinline__ v3 lookup_uv(const ShadeView &V, const MaterialRec &M
 
 // Stage B: light accumulation with the shadow answers (RT:534-542), surface colour (RT:568-581 / 711-724),
 // the level record the return path needs, and the reflection ray of the next generation (RT:545-559).
-__global__ __launch_bounds__(256) void k_shade_b(SceneView S, ShadeView V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath,
+__global__ __launch_bounds__(APPEND_BLOCK) void k_shade_b(SceneView S, ShadeView V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath,
                                                  const int *scnt, const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB,
                                                  xrt_ray *nextRays, int *nextPath, int *nextCnt, int P, int level, int maxReflections) {
+    __shared__ int ldsCounts[17];
     const int n = *scnt;
     const int stride = (int)(gridDim.x * blockDim.x);
     const int rounds = (n + stride - 1) / stride;
@@ -539,15 +566,9 @@ __global__ __launch_bounds__(256) void k_shade_b(SceneView S, ShadeView V, const
                 rdir = normalize(reflect(d, normal));   // RT:549-550
             }
         }
-        if (level < maxReflections) {   // wave-uniform
-            const unsigned long long m = __ballot(valid);
-            if (m == 0ull) continue;
-            int base = 0;
-            const int leader = (int)__builtin_ctzll(m);
-            if (lane_id() == leader) base = atomicAdd(nextCnt, (int)__popcll(m));
-            base = __shfl(base, leader);
+        if (level < maxReflections) {   // grid-uniform
+            const int slot = block_append(nextCnt, valid, ldsCounts);
             if (valid) {
-                const int slot = base + lanes_below(m);
                 store_ray(nextRays + slot, w, rdir, mesh, tri);   // origin = result.triangle (RT:559)
                 nextPath[slot] = p;
             }
@@ -557,7 +578,7 @@ __global__ __launch_bounds__(256) void k_shade_b(SceneView S, ShadeView V, const
 void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath, const int *scnt,
                     const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB, xrt_ray *nextRays, int *nextPath, int *nextCnt,
                     int P, int level, int maxReflections, hipStream_t st) {
-    hipLaunchKernelGGL(k_shade_b, dim3(2048), dim3(256), 0, st, S, V, rays, hits, rayPath, scnt, shadowSrc, shadowHits, lvlA, lvlB, nextRays,
+    hipLaunchKernelGGL(k_shade_b, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, rays, hits, rayPath, scnt, shadowSrc, shadowHits, lvlA, lvlB, nextRays,
                        nextPath, nextCnt, P, level, maxReflections);
 }
 

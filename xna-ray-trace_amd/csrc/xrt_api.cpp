@@ -94,7 +94,8 @@ struct xrt_scene {
     DevBuf<LightRec> lights;
     DevBuf<unsigned long long> counters;
     std::vector<hipEvent_t> events;
-    int tune[3] = {24, 16, 8};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
+    int firstBatch = 64;
+    int tune[3] = {24, 64, 32};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
     std::atomic<bool> busy{false};
     std::atomic<float> progress{0.0f};
 
@@ -279,7 +280,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
             IntersectArgs A;
             A.rays = rays[cur]; A.hits = s->hits.p; A.index = k == 0 ? paths[1] : nullptr; A.nDev = cnt + k; A.nMul = 1; A.n = Pc;
             A.queue = q + 2 * k; A.mode = s->sceneMode; A.meshId = 0;
-            A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2];
+            A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.firstBatch = s->firstBatch;
             hipEvent_t a0 = get_event(s, ev), a1 = get_event(s, ev + 1);
             if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
             pairs.push_back({ev, ev + 1}); ev += 2;
@@ -297,7 +298,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
                 IntersectArgs B;
                 B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.index = nullptr; B.nDev = scnt + k; B.nMul = nL; B.n = 0;
                 B.queue = q + 2 * k + 1; B.mode = s->sceneMode; B.meshId = 0;
-                B.refillMin = s->tune[0]; B.nodeBurst = s->tune[1]; B.leafBurst = s->tune[2];
+                B.refillMin = s->tune[0]; B.nodeBurst = s->tune[1]; B.leafBurst = s->tune[2]; B.firstBatch = s->firstBatch;
                 hipEvent_t b0 = get_event(s, ev), b1 = get_event(s, ev + 1);
                 if (!b0 || !b1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 pairs.push_back({ev, ev + 1}); ev += 2;
@@ -371,7 +372,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
     HIPCHECK(hipMemsetAsync(s->queues.p, 0, sizeof(unsigned), st));
     IntersectArgs A;
     A.rays = d_rays; A.hits = d_hits; A.index = nullptr; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.queue = s->queues.p; A.mode = mode; A.meshId = meshId;
-    A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2];
+    A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.firstBatch = s->firstBatch;
     hipEvent_t a0 = nullptr, a1 = nullptr;
     if (stats) {
         a0 = get_event(s, 0); a1 = get_event(s, 1);
@@ -500,6 +501,7 @@ int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_thre
     if (getenv("XRT_NO_SINGLE")) scene->sceneMode = MODE_SCENE;
     scene->blocksPerCU = intersect_blocks_per_cu(scene->stackNeeded, scene->sceneMode);
     scene->blocksPerCUMesh = intersect_blocks_per_cu(scene->stackNeeded, MODE_MESH);
+    scene->firstBatch = (A.meshDepth == 0) ? 256 : 64;   // every mesh is a single leaf: rays are cheap, avoid queue traffic
     scene->resident = true;
     return XRT_OK;
 }
