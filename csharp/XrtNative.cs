@@ -1,0 +1,83 @@
+// XrtNative.cs — P/Invoke binding of include/xrt.h for the xna-ray-trace C# host.
+// NOT COMPILED HERE: the build image has no .NET toolchain (dotnet / mono / csc absent).  Style follows the
+// reference's own native binding precedent (aviFileWrapper_src/Avi.cs:41-185: [StructLayout(Sequential)],
+// [DllImport] returning int, wrapper throws on non-zero).
+using System;
+using System.Runtime.InteropServices;
+
+namespace RayTraceProject.Native
+{
+    [StructLayout(LayoutKind.Sequential)]
+    public struct XrtRay { public float ox, oy, oz, dx, dy, dz; public int ignoreMesh, ignoreTri; }          // 32 B
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct XrtHit { public int hit, obj, mesh, tri, leaf; public float u, v, d, wx, wy, wz; public int reserved; }   // 48 B
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct XrtMaterial
+    {
+        public float reflectiveness; public int transparent; public float refractionIndex;
+        public int interpolateNormals, useTexture, texWidth, texHeight, reserved;
+        public IntPtr texArgb;   // BitmapData.Scan0 of the Format32bppArgb lock (Material.cs:65)
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public unsafe struct XrtCamera
+    {
+        public fixed float view[16]; public fixed float proj[16];
+        public int vpX, vpY, vpWidth, vpHeight; public float vpMinDepth, vpMaxDepth;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public unsafe struct XrtLight
+    {
+        public int kind; public fixed float position[3]; public fixed float direction[3]; public fixed float color[3];
+        public float intensity, spotAngle, decayExponent;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct XrtRenderOpts
+    {
+        public int maxReflections, useMultisampling, multisampleQuality, addressMode, filtering, shardRank, shardCount, collectStats;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct XrtStats
+    {
+        public ulong raysClosest, raysShadow, hitsClosest, hitsShadow, sceneNodeTests, instanceVisits, meshAabbTests, meshQueries,
+                     nodeTests, leafRefs, triTests, shadedHits, pixels, algorithmicBytes;
+        public double msTotal, msIntersect; public uint intersectLaunches, reserved;
+    }
+
+    public static class Xrt
+    {
+        const string Lib = "xrt";   // libxrt.so / xrt.dll
+        public const int OK = 0, E_INVALID_ARG = -1, E_BUSY = -2, E_NO_DEVICE = -3;
+
+        [DllImport(Lib)] public static extern int xrt_version();
+        [DllImport(Lib)] public static extern IntPtr xrt_last_error();
+        [DllImport(Lib)] public static extern int xrt_scene_create(int device, out IntPtr scene);
+        [DllImport(Lib)] public static extern int xrt_scene_destroy(IntPtr scene);
+        [DllImport(Lib)] public static extern int xrt_scene_add_mesh(IntPtr scene, float[] v, float[] n, float[] uv, float[] surfN, float[] color,
+                                                                    int ntri, ref XrtMaterial material, float[] bbox, out int meshId);
+        [DllImport(Lib)] public static extern int xrt_scene_add_object(IntPtr scene, int[] meshIds, int nMeshes, float[] world, float[] invWorld,
+                                                                      float[] bbox, float[] worldBbox, out int objectId);
+        [DllImport(Lib)] public static extern int xrt_scene_build(IntPtr scene, int meshThreshold, int sceneThreshold);
+        [DllImport(Lib)] public static extern int xrt_scene_intersect(IntPtr scene, [In] XrtRay[] rays, int[] ignoreObject, long n,
+                                                                     [Out] XrtHit[] hits, IntPtr stats);
+        [DllImport(Lib)] public static extern unsafe int xrt_render(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,
+                                                                   ref XrtRenderOpts opts, uint* rgbaOut, float* rgbF32Out, IntPtr stats);
+        [DllImport(Lib)] public static extern float xrt_progress(IntPtr scene);
+
+        // error convention of the reference: InvalidOperationException when busy (RayTracer.cs:26-27,62-63),
+        // ArgumentException for bad arguments (SceneObject.cs:123-124, Material.cs:85,97)
+        public static void Check(int rc)
+        {
+            if (rc == OK) return;
+            string msg = Marshal.PtrToStringAnsi(xrt_last_error());
+            if (rc == E_BUSY) throw new InvalidOperationException(msg);
+            if (rc == E_INVALID_ARG) throw new ArgumentException(msg);
+            throw new Exception("Exception in libxrt: " + rc + " " + msg);
+        }
+    }
+}
