@@ -214,6 +214,40 @@ def test_directional_light_and_transparent_blocker(xrt, orc):
     assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
 
 
+def glass_scene(xrt, w, h, R):
+    """The shape of the reference's default scene (Game1.cs:98-138): a 2x2 block of Transparent objects
+    (alpha 100/255, refraction index 1.32, reflectiveness 0.7; contentproj:87-96) over an opaque floor."""
+    s = xrt.configs.SceneSpec("glass")
+    glass = xrt.fixtures.crate(2)
+    glass.color[:, 3] = np.float32(100.0) / np.float32(255.0)
+    glass.color[:, :3] = np.array([0.9, 0.95, 1.0], dtype=np.float32)
+    s.meshes.append((glass, xrt.configs.material(0.7, transparent=True, refraction_index=1.32)))
+    s.meshes.append((xrt.fixtures.heightfield(24), xrt.configs.material(0.3)))
+    for x in range(2):
+        for y in range(2):
+            s.objects.append(([0], (-22.0 + 44.0 * x, 5.0, -22.0 + 44.0 * y), (0.0, 0.3 * x, 0.0), (1.0, 1.0, 1.0)))
+    s.objects.append(([1], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    s.camera = xrt.configs.camera((0, 60, 120), (0, 5, 0))
+    s.lights = [xrt.configs.spot((0, 90, 100))]
+    s.max_reflections = R
+    return s.with_size(w, h)
+
+
+@pytest.mark.parametrize("R", [1, 3, 5])
+def test_refraction_ray_tree(xrt, orc, R):
+    """RT:586-702: Transparent materials turn CastRay into a binary tree (reflection + refraction per hit),
+    with the double-precision Snell terms and the currentRefIndex bookkeeping."""
+    spec = glass_scene(xrt, 96, 54, R)
+    scene, tracer = xrt.configs.build_product(spec)
+    tracer.collect_stats = True
+    rgba, rgbf = tracer.Render(want_float=True)
+    o_rgba, o_rgbf, o_st = orc.OracleScene(spec).render(nthreads=8)
+    assert o_st["rays_closest"] > 96 * 54 + o_st["shaded_hits"] * 0.9, "fixture does not refract"
+    assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+    for k in ("rays_closest", "rays_shadow", "hits_closest", "hits_shadow", "shaded_hits", "tri_tests", "algorithmic_bytes"):
+        assert tracer.last_stats[k] == o_st[k], (k, tracer.last_stats[k], o_st[k])
+
+
 def test_error_conventions_on_gpu(xrt):
     spec = xrt.configs.config("C1")
     scene, tracer = xrt.configs.build_product(spec)

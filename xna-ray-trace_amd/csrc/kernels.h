@@ -34,7 +34,18 @@ struct IntersectArgs {
 // reference-work counters accumulated on the device (same order as the head of xrt_stats)
 enum { C_RAYS = 0, C_HITS, C_SCENE_NODES, C_INSTANCES, C_MESH_AABB, C_MESH_QUERIES, C_NODES, C_REFS, C_TRIS, C_COUNT };
 
-constexpr int FLAG_MISS = 0, FLAG_HIT = 1;
+constexpr int FLAG_MISS = 0, FLAG_HIT = 1, FLAG_TRANSPARENT = 2;
+
+// Ray-tree bookkeeping of scenes with Transparent materials (RT:586-702): heap node id and the refraction
+// index of the medium each ray travels in.  heap == 0: plain reflection chain, node == generation.
+struct TreeArgs {
+    int heap;
+    const int *rayNode;
+    const float *rayRef;
+    int *nextNode;
+    float *nextRef;
+    float *lvlAlpha;
+};
 
 struct FrameBuffers {
     xrt_ray *rays[2];
@@ -57,10 +68,13 @@ int  intersect_blocks_per_cu(int stackNeeded, int mode);
 void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long *counters, hipStream_t st);
 void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, xrt_hit *hits, int *index, int *count, int P, long long pathBase, hipStream_t st);
 void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
-                    const int *rayPath, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level, hipStream_t st);
+                    const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level,
+                    hipStream_t st);
 void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath,
                     const int *scnt, const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB, xrt_ray *nextRays,
-                    int *nextPath, int *nextCnt, int P, int level, int maxReflections, hipStream_t st);
+                    int *nextPath, int *nextCnt, int P, int level, int maxReflections, const TreeArgs &T, hipStream_t st);
+void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections, uint32_t *sampleColor,
+                         float *sampleF32, hipStream_t st);
 void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P /* level stride */, int maxReflections, uint32_t *sampleColor, float *sampleF32, hipStream_t st);
 void launch_resolve(const RayGenParams &g, const uint32_t *sampleColor, const float *sampleF32, int pixels, long long pixelBase,
                     uint32_t *out, float *outF32, hipStream_t st);

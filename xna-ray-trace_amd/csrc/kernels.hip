@@ -448,8 +448,8 @@ __device__ __forceinline__ void light_dir(const LightRec &L, v3 world, v3 &dir, 
 // Stage A of CastRay for one generation of rays: misses terminate their path (RT:729-733); every hit
 // emits one shadow ray per light (RT:535-537 -> RT:482-485), compacted with one atomic per wave.
 __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_a(SceneView S, ShadeView V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev,
-                                                 int nHost, const int *rayPath, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc,
-                                                 int *scnt, int P, int level) {
+                                                 int nHost, const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays,
+                                                 int *shadowSrc, int *scnt, int P, int level) {
     __shared__ int ldsCounts[17];
     const int n = nDev ? *nDev : nHost;
     const int stride = (int)(gridDim.x * blockDim.x);
@@ -463,7 +463,8 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_a(SceneView S, ShadeView
         if (i < n) {
             load_hit(hits + i, hit, object, mesh, tri, u, v, d, w);
             p = rayPath ? rayPath[i] : i;
-            if (!hit) lvlB[(size_t)level * P + p] = f4{0, 0, 0, i2f(FLAG_MISS)};
+            const int node = rayNode ? rayNode[i] : level;   // chain of reflections: node == generation; ray tree: heap index
+            if (!hit) lvlB[(size_t)node * P + p] = f4{0, 0, 0, i2f(FLAG_MISS)};
         }
         const int slot = block_append(scnt, hit != 0, ldsCounts);
         if (hit) {
@@ -477,8 +478,10 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_a(SceneView S, ShadeView
     }
 }
 void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
-                    const int *rayPath, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level, hipStream_t st) {
-    hipLaunchKernelGGL(k_shade_a, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, rays, hits, nDev, nHost, rayPath, lvlB, shadowRays, shadowSrc, scnt, P, level);
+                    const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level,
+                    hipStream_t st) {
+    hipLaunchKernelGGL(k_shade_a, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, rays, hits, nDev, nHost, rayPath, rayNode, lvlB, shadowRays, shadowSrc,
+                       scnt, P, level);
 }
 
 // MAT:71-160 LookupUV: address mode + point sample
@@ -513,7 +516,8 @@ __device__ __forceinline__ v3 lookup_uv(const ShadeView &V, const MaterialRec &M
 // the level record the return path needs, and the reflection ray of the next generation (RT:545-559).
 __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_b(SceneView S, ShadeView V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath,
                                                  const int *scnt, const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB,
-                                                 xrt_ray *nextRays, int *nextPath, int *nextCnt, int P, int level, int maxReflections) {
+                                                 xrt_ray *nextRays, int *nextPath, int *nextCnt, int P, int level, int maxReflections,
+                                                 TreeArgs T) {
     __shared__ int ldsCounts[17];
     const int n = *scnt;
     const int stride = (int)(gridDim.x * blockDim.x);
@@ -521,8 +525,10 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_b(SceneView S, ShadeView
     for (int it = 0; it < rounds; it++) {
         const int s = it * stride + (int)(blockIdx.x * blockDim.x + threadIdx.x);
         const bool valid = s < n;
-        v3 w = mk(0, 0, 0), normal = mk(0, 0, 0), rdir = mk(0, 0, 0);
-        int mesh = 0, tri = 0, p = 0;
+        v3 w = mk(0, 0, 0), normal = mk(0, 0, 0), rdir = mk(0, 0, 0), tdir = mk(0, 0, 0);
+        int mesh = 0, tri = 0, p = 0, node = level;
+        float curRef = 1.0f, n2 = 1.0f;
+        bool refracts = false;
         if (valid) {
             const int i = shadowSrc[s];
             int hit, object; float u, v, d;
@@ -558,12 +564,27 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_b(SceneView S, ShadeView
                 f4 c = sr[3];
                 surf = mk(c.x, c.y, c.z);
             }
-            lvlA[(size_t)level * P + p] = f4{lightResult.x, lightResult.y, lightResult.z, M.reflectiveness};
-            lvlB[(size_t)level * P + p] = f4{surf.x, surf.y, surf.z, i2f(FLAG_HIT)};
+            if (T.heap) { node = T.rayNode ? T.rayNode[i] : 0; curRef = T.rayRef ? T.rayRef[i] : 1.0f; }   // generation 0: root, in vacuum (RT:424)
+            const bool transparent = (M.flags & MAT_TRANSPARENT) != 0;
+            lvlA[(size_t)node * P + p] = f4{lightResult.x, lightResult.y, lightResult.z, M.reflectiveness};
+            lvlB[(size_t)node * P + p] = f4{surf.x, surf.y, surf.z, i2f(FLAG_HIT | (transparent ? FLAG_TRANSPARENT : 0))};
+            if (T.heap) T.lvlAlpha[(size_t)node * P + p] = sr[3].w;   // triangle.color.W (RT:699)
             if (level < maxReflections) {
                 v3 o, d; int im, itri;
                 load_ray(rays + i, o, d, im, itri);
                 rdir = normalize(reflect(d, normal));   // RT:549-550
+                if (T.heap && transparent) {   // RT:656-694: Snell refraction, the System.Math calls in double
+                    float n1;
+                    if (curRef == M.refractionIndex) { n1 = 1.0f; n2 = curRef; }
+                    else { n1 = M.refractionIndex; n2 = 1.0f; }
+                    const float cos1 = dot(normal, neg(d));
+                    const double ratio = (double)(n1 / n2), c1 = (double)cos1;
+                    const float cos2 = (float)sqrt(1 - (ratio * ratio) * (1 - (c1 * c1)));   // Math.Pow(x, 2.0) == x*x exactly here
+                    const float q = n1 / n2;
+                    const v3 a = scale(d, q), b = scale(normal, q * cos1 - cos2);
+                    tdir = normalize(cos1 >= 0 ? add(a, b) : sub(a, b));
+                    refracts = true;
+                }
             }
         }
         if (level < maxReflections) {   // grid-uniform
@@ -571,15 +592,24 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_b(SceneView S, ShadeView
             if (valid) {
                 store_ray(nextRays + slot, w, rdir, mesh, tri);   // origin = result.triangle (RT:559)
                 nextPath[slot] = p;
+                if (T.heap) { T.nextNode[slot] = 2 * node + 1; T.nextRef[slot] = curRef; }
+            }
+            if (T.heap) {   // the refracted ray of RT:698 continues in the medium with index n2
+                const int slot2 = block_append(nextCnt, refracts, ldsCounts);
+                if (refracts) {
+                    store_ray(nextRays + slot2, w, tdir, mesh, tri);
+                    nextPath[slot2] = p;
+                    T.nextNode[slot2] = 2 * node + 2; T.nextRef[slot2] = n2;
+                }
             }
         }
     }
 }
 void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath, const int *scnt,
                     const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB, xrt_ray *nextRays, int *nextPath, int *nextCnt,
-                    int P, int level, int maxReflections, hipStream_t st) {
+                    int P, int level, int maxReflections, const TreeArgs &T, hipStream_t st) {
     hipLaunchKernelGGL(k_shade_b, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, rays, hits, rayPath, scnt, shadowSrc, shadowHits, lvlA, lvlB, nextRays,
-                       nextPath, nextCnt, P, level, maxReflections);
+                       nextPath, nextCnt, P, level, maxReflections, T);
 }
 
 // The return path of the CastRay recursion: deepest generation first, one RGBA8 quantisation per level.
@@ -589,12 +619,12 @@ __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB,
         int flag;
         for (;;) {
             flag = f2i(lvlB[(size_t)kd * P + p].w);
-            if (flag == FLAG_MISS || kd == maxReflections) break;
+            if (!(flag & FLAG_HIT) || kd == maxReflections) break;
             kd++;
         }
         v3 cv = mk(0, 0, 0);
         uint32_t col;
-        if (flag == FLAG_MISS) col = pack_color(mk(0, 0, 0));   // RT:732
+        if (!(flag & FLAG_HIT)) col = pack_color(mk(0, 0, 0));   // RT:732
         else {   // RT:708-727: generation MaxReflections has no reflection term
             f4 a = lvlA[(size_t)kd * P + p], b = lvlB[(size_t)kd * P + p];
             cv = mul(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z));
@@ -608,6 +638,65 @@ __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB,
         sampleColor[p] = col;
         if (sampleF32) { sampleF32[3 * (size_t)p] = cv.x; sampleF32[3 * (size_t)p + 1] = cv.y; sampleF32[3 * (size_t)p + 2] = cv.z; }
     }
+}
+// The same return path over the binary ray tree of a scene with Transparent materials (RT:586-702): node i has
+// its reflection at 2i+1 and its refraction at 2i+2; evaluated depth first like the recursion itself.
+__global__ __launch_bounds__(256) void k_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections,
+                                                      uint32_t *sampleColor, float *sampleF32) {
+    constexpr int MAXD = 14;
+    for (int p = (int)(blockIdx.x * blockDim.x + threadIdx.x); p < count; p += (int)(gridDim.x * blockDim.x)) {
+        int stNode[MAXD], stPhase[MAXD];
+        uint32_t stRefl[MAXD];
+        int sp = 0;
+        stNode[0] = 0; stPhase[0] = 0; stRefl[0] = 0;
+        uint32_t ret = 0;
+        v3 retCv = mk(0, 0, 0);
+        while (sp >= 0) {
+            const int node = stNode[sp];
+            const f4 b = lvlB[(size_t)node * P + p];
+            const int flag = f2i(b.w);
+            if (stPhase[sp] == 0) {
+                if (!(flag & FLAG_HIT)) { ret = pack_color(mk(0, 0, 0)); retCv = mk(0, 0, 0); sp--; continue; }   // RT:732
+                if (sp == maxReflections) {   // RT:708-727
+                    const f4 a = lvlA[(size_t)node * P + p];
+                    retCv = mul(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z));
+                    ret = pack_color(retCv);
+                    sp--;
+                    continue;
+                }
+                stPhase[sp] = 1;   // RT:556-559: reflection first
+                sp++;
+                stNode[sp] = 2 * node + 1; stPhase[sp] = 0;
+                continue;
+            }
+            const f4 a = lvlA[(size_t)node * P + p];
+            if (stPhase[sp] == 1) {
+                stRefl[sp] = ret;
+                if (flag & FLAG_TRANSPARENT) {   // RT:698
+                    stPhase[sp] = 2;
+                    sp++;
+                    stNode[sp] = 2 * node + 2; stPhase[sp] = 0;
+                    continue;
+                }
+                retCv = mul(lerp(unpack_color(stRefl[sp]), mk(b.x, b.y, b.z), 1.0f - a.w), mk(a.x, a.y, a.z));   // RT:584
+                ret = pack_color(retCv);   // RT:705
+                sp--;
+                continue;
+            }
+            v3 cv = mul(lerp(unpack_color(stRefl[sp]), mk(b.x, b.y, b.z), 1.0f - a.w), mk(a.x, a.y, a.z));   // RT:584
+            retCv = lerp(unpack_color(ret), cv, lvlAlpha[(size_t)node * P + p]);                               // RT:699
+            ret = pack_color(retCv);
+            sp--;
+        }
+        sampleColor[p] = ret;
+        if (sampleF32) { sampleF32[3 * (size_t)p] = retCv.x; sampleF32[3 * (size_t)p + 1] = retCv.y; sampleF32[3 * (size_t)p + 2] = retCv.z; }
+    }
+}
+void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections, uint32_t *sampleColor,
+                         float *sampleF32, hipStream_t st) {
+    int blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_compose_tree, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, lvlA, lvlB, lvlAlpha, count, P, maxReflections, sampleColor, sampleF32);
 }
 void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32, hipStream_t st) {
     int blocks = (count + 255) / 256;

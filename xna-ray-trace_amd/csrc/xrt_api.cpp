@@ -86,7 +86,8 @@ struct xrt_scene {
     // per-frame work buffers
     DevBuf<xrt_ray> rays0, rays1, shadowRays, apiRays;
     DevBuf<xrt_hit> hits, shadowHits, apiHits;
-    DevBuf<int> path0, path1, shadowSrc, cnts;
+    DevBuf<int> path0, path1, node0, node1, shadowSrc, cnts;
+    DevBuf<float> ref0, ref1, lvlAlpha;
     DevBuf<unsigned> queues;
     DevBuf<f4> lvlA, lvlB;
     DevBuf<uint32_t> sampleColor, outRGBA;
@@ -109,6 +110,7 @@ struct xrt_scene {
             objects.release(); materials.release(); texels.release();
             rays0.release(); rays1.release(); shadowRays.release(); apiRays.release(); hits.release();
             shadowHits.release(); apiHits.release(); path0.release(); path1.release(); shadowSrc.release();
+            node0.release(); node1.release(); ref0.release(); ref1.release(); lvlAlpha.release();
             cnts.release(); queues.release(); lvlA.release(); lvlB.release(); sampleColor.release();
             outRGBA.release(); sampleF32.release(); outF32.release(); lights.release(); counters.release();
         }
@@ -218,8 +220,9 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
         return fail(XRT_E_INVALID_ARG, "Value does not fall within the expected range: filtering (MAT:97)");
     if (opts->filtering == XRT_FILTER_BILINEAR && s->hs.arrays.anyTexture)
         return fail(XRT_E_UNSUPPORTED, "bilinear texture filtering (MAT:162-232) is not implemented yet (SURVEY 8f N3)");
-    if (s->hs.arrays.anyTransparent && opts->max_reflections > 0)
-        return fail(XRT_E_UNSUPPORTED, "refraction through Transparent materials (RT:586-702) is not implemented yet (SURVEY 8f N2)");
+    const bool heap = s->hs.arrays.anyTransparent && opts->max_reflections > 0;   // RT:586-702: binary ray tree
+    if (heap && opts->max_reflections > 12)
+        return fail(XRT_E_UNSUPPORTED, "Transparent materials with MaxReflections > 12 (a ray tree of more than 8191 nodes per pixel)");
     if (opts->use_multisampling == XRT_MS_ADAPTIVE)
         return fail(XRT_E_UNSUPPORTED, "adaptive supersampling (RT:170-311) is not implemented yet (SURVEY 8f N1); use XRT_MS_FIXED16");
     if (opts->use_multisampling != XRT_MS_OFF && opts->use_multisampling != XRT_MS_FIXED16) return fail(XRT_E_INVALID_ARG, "use_multisampling");
@@ -232,16 +235,23 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     const long long myTiles = (totalTiles + g.shardCount - 1) / g.shardCount;   // tiles_per_rank (slots, some may be past the end)
     const long long totalPixels = myTiles * 512;
     const long long totalPaths = totalPixels * g.samples;
-    const long long chunkPaths = totalPaths < MAX_CHUNK_PATHS ? totalPaths : MAX_CHUNK_PATHS;
+    // a path owns up to 2^R rays of one generation when materials refract, one otherwise
+    const long long maxPaths = heap ? (MAX_CHUNK_PATHS >> R) : MAX_CHUNK_PATHS;
+    const long long chunkPaths = totalPaths < maxPaths ? totalPaths : maxPaths;
     const int P = (int)chunkPaths;
+    const size_t rayCap = heap ? ((size_t)P << R) : (size_t)P;
+    const size_t nodes = heap ? (((size_t)1 << (R + 1)) - 1) : (size_t)(R + 1);
     const int nChunks = (int)((totalPaths + chunkPaths - 1) / chunkPaths);
     const bool wantF32 = d_outF32 != nullptr;
     // buffers
-    if ((rc = s->rays0.ensure(P)) || (rc = s->rays1.ensure(P)) || (rc = s->hits.ensure(P)) || (rc = s->path0.ensure(P)) ||
-        (rc = s->path1.ensure(P)) || (rc = s->shadowSrc.ensure(P)) || (rc = s->shadowRays.ensure((size_t)P * (nL > 0 ? nL : 1))) ||
-        (rc = s->shadowHits.ensure((size_t)P * (nL > 0 ? nL : 1))) || (rc = s->lvlA.ensure((size_t)P * (R + 1))) ||
-        (rc = s->lvlB.ensure((size_t)P * (R + 1))) || (rc = s->sampleColor.ensure(P)) || (rc = s->lights.ensure(nL > 0 ? nL : 1)) ||
+    if ((rc = s->rays0.ensure(rayCap)) || (rc = s->rays1.ensure(rayCap)) || (rc = s->hits.ensure(rayCap)) || (rc = s->path0.ensure(rayCap)) ||
+        (rc = s->path1.ensure(rayCap)) || (rc = s->shadowSrc.ensure(rayCap)) || (rc = s->shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
+        (rc = s->shadowHits.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = s->lvlA.ensure((size_t)P * nodes)) ||
+        (rc = s->lvlB.ensure((size_t)P * nodes)) || (rc = s->sampleColor.ensure(P)) || (rc = s->lights.ensure(nL > 0 ? nL : 1)) ||
         (rc = s->counters.ensure(2 * C_COUNT)))
+        return rc;
+    if (heap && ((rc = s->node0.ensure(rayCap)) || (rc = s->node1.ensure(rayCap)) || (rc = s->ref0.ensure(rayCap)) || (rc = s->ref1.ensure(rayCap)) ||
+                 (rc = s->lvlAlpha.ensure((size_t)P * nodes))))
         return rc;
     if (wantF32 && (rc = s->sampleF32.ensure((size_t)P * 3))) return rc;
     const int cntStride = 2 * (R + 2);          // per chunk: cnt[R+2] then scnt[R+2]
@@ -262,6 +272,8 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     const SceneView &S = s->view;
     xrt_ray *rays[2] = {s->rays0.p, s->rays1.p};
     int *paths[2] = {s->path0.p, s->path1.p};
+    int *nodesOf[2] = {s->node0.p, s->node1.p};
+    float *refOf[2] = {s->ref0.p, s->ref1.p};
     size_t ev = 0;
     std::vector<std::pair<size_t, size_t>> pairs;
     hipEvent_t e0 = get_event(s, ev++), e1 = get_event(s, ev++);
@@ -292,8 +304,8 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
                 if (k == 0) { Ac.index = nullptr; Ac.nDev = nullptr; }
                 launch_count(S, Ac, s->counters.p, st);
             }
-            launch_shade_a(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : cnt + k, Pc, k == 0 ? nullptr : paths[cur], s->lvlB.p,
-                           s->shadowRays.p, s->shadowSrc.p, scnt + k, P, k, st);
+            launch_shade_a(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : cnt + k, Pc, k == 0 ? nullptr : paths[cur],
+                           (heap && k > 0) ? nodesOf[cur] : nullptr, s->lvlB.p, s->shadowRays.p, s->shadowSrc.p, scnt + k, P, k, st);
             if (nL > 0) {
                 IntersectArgs B;
                 B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.index = nullptr; B.nDev = scnt + k; B.nMul = nL; B.n = 0;
@@ -307,10 +319,15 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
                 HIPCHECK(hipEventRecord(b1, st));
                 if (opts->collect_stats) launch_count(S, B, s->counters.p + C_COUNT, st);
             }
+            TreeArgs T;
+            T.heap = heap ? 1 : 0;
+            T.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; T.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
+            T.nextNode = heap ? nodesOf[nxt] : nullptr; T.nextRef = heap ? refOf[nxt] : nullptr; T.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
             launch_shade_b(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : paths[cur], scnt + k, s->shadowSrc.p, s->shadowHits.p, s->lvlA.p,
-                           s->lvlB.p, rays[nxt], paths[nxt], cnt + k + 1, P, k, R, st);
+                           s->lvlB.p, rays[nxt], paths[nxt], cnt + k + 1, P, k, R, T, st);
         }
-        launch_compose(s->lvlA.p, s->lvlB.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
+        if (heap) launch_compose_tree(s->lvlA.p, s->lvlB.p, s->lvlAlpha.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
+        else launch_compose(s->lvlA.p, s->lvlB.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
         launch_resolve(g, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, Pc / g.samples, pathBase / g.samples, d_out, d_outF32, st);
         if (nChunks > 1) {
             HIPCHECK(hipStreamSynchronize(st));
