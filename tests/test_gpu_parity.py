@@ -248,6 +248,24 @@ def test_refraction_ray_tree(xrt, orc, R):
         assert tracer.last_stats[k] == o_st[k], (k, tracer.last_stats[k], o_st[k])
 
 
+@pytest.mark.parametrize("quality", [0, 1, 2])
+def test_adaptive_supersampling(xrt, orc, quality):
+    """RenderInternalWithMultisampling (RT:128-168, 170-311): four rays per quadrant, corners deviating by more
+    than 0.5 in colour length are subdivided down to MultisampleQuality, including the RT:305 slip that stores
+    the lower-right recursion in the upper-right colour."""
+    for spec in (xrt.configs.crate_grid_scene(96, 54), xrt.configs.heightfield_scene(80, 45, m=64), xrt.configs.crate_grid_scene(70, 33, n=2, grid=3)):
+        spec.multisampling, spec.multisample_quality = xrt.abi.MS_ADAPTIVE, quality
+        scene, tracer = xrt.configs.build_product(spec)
+        tracer.collect_stats = True
+        rgba, rgbf = tracer.Render(want_float=True)
+        o_rgba, o_rgbf, o_st = orc.OracleScene(spec).render(nthreads=8)
+        if quality > 0:
+            assert o_st["rays_closest"] > 4 * spec.width * spec.height + o_st["shaded_hits"] * 0.5, "no quadrant was subdivided"
+        assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+        for k in ("rays_closest", "rays_shadow", "shaded_hits", "tri_tests", "pixels", "algorithmic_bytes"):
+            assert tracer.last_stats[k] == o_st[k], (k, tracer.last_stats[k], o_st[k])
+
+
 def test_error_conventions_on_gpu(xrt):
     spec = xrt.configs.config("C1")
     scene, tracer = xrt.configs.build_product(spec)

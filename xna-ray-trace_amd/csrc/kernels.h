@@ -78,6 +78,9 @@ void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, 
 void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P /* level stride */, int maxReflections, uint32_t *sampleColor, float *sampleF32, hipStream_t st);
 void launch_resolve(const RayGenParams &g, const uint32_t *sampleColor, const float *sampleF32, int pixels, long long pixelBase,
                     uint32_t *out, float *outF32, hipStream_t st);
+void launch_ms_decide(const RayGenParams &g, const uint32_t *quadColor, const int *nQuadsDev, int nQuadsHost, long long pixelBase, int *childBase,
+                      int *childMask, float *nextCx, float *nextCy, int *nextCount, hipStream_t st);
+void launch_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *childBase, const int *childMask, int n, hipStream_t st);
 void launch_detile(int width, int height, int shardCount, int tilesPerRank, const uint32_t *gathered, uint32_t *out, hipStream_t st);
 
 }  // namespace xrt

@@ -369,12 +369,18 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
         if (p < P) {
             long long gp = pathBase + p;
             int s = (int)(gp % g.samples);
-            int x, y;
-            if (!path_pixel(g, gp / g.samples, x, y)) {
+            int x = 0, y = 0;
+            const bool listed = g.quadLevel > 0;   // quadrant centres come from a list, every entry is valid
+            if (!listed && !path_pixel(g, gp / g.samples, x, y)) {
                 store_ray(rays + p, mk(0, 0, 0), mk(0, 0, 0), DEAD_RAY, -1);
             } else {
                 float sx = (float)x, sy = (float)y;
-                if (g.samples == 16) {   // XRT_MS_FIXED16: corner q = s/4 at +-0.25, sub-sample s%4 at +-0.125 (RT:218-305)
+                if (g.quadLevel >= 0) {   // RT:218-276: four rays at centre -+ size/4, order UL, UR, LL, LR
+                    if (listed) { sx = g.quadCx[gp >> 2]; sy = g.quadCy[gp >> 2]; }
+                    const float quarter = g.quadSize * 0.25f;
+                    sx = (s & 1) ? sx + quarter : sx - quarter;
+                    sy = (s & 2) ? sy + quarter : sy - quarter;
+                } else if (g.samples == 16) {   // XRT_MS_FIXED16: corner q = s/4 at +-0.25, sub-sample s%4 at +-0.125 (RT:218-305)
                     int q = s >> 2, r = s & 3;
                     sx = (sx + ((q & 1) ? 0.25f : -0.25f)) + ((r & 1) ? 0.125f : -0.125f);
                     sy = (sy + ((q & 2) ? 0.25f : -0.25f)) + ((r & 2) ? 0.125f : -0.125f);
@@ -714,7 +720,12 @@ __global__ __launch_bounds__(256) void k_resolve(RayGenParams g, const uint32_t 
         bool ok = path_pixel(g, pix, x, y);
         uint32_t col;
         v3 cv;
-        if (g.samples == 1) {
+        if (g.quadLevel == 0) {   // adaptive: the pixel's level-0 quadrant after all folds (RT:309)
+            const uint32_t *s = sampleColor + (size_t)i * 4;
+            v3 sum = add(add(add(unpack_color(s[0]), unpack_color(s[1])), unpack_color(s[2])), unpack_color(s[3]));
+            col = pack_color(divf(sum, 4.0f));
+            cv = unpack_color(col);
+        } else if (g.samples == 1) {
             col = sampleColor[i];
             cv = sampleF32 ? mk(sampleF32[3 * (size_t)i], sampleF32[3 * (size_t)i + 1], sampleF32[3 * (size_t)i + 2]) : unpack_color(col);
         } else {
@@ -742,6 +753,98 @@ void launch_resolve(const RayGenParams &g, const uint32_t *sampleColor, const fl
     int blocks = (pixels + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_resolve, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, g, sampleColor, sampleF32, pixels, pixelBase, out, outF32);
+}
+
+// ---- adaptive supersampling (RT:170-311) ------------------------------------------------------------------------
+// Level l holds a list of quadrants; each got four CastRay colours (quadColor[4q..4q+3]).  k_ms_decide applies
+// RT:279-306: a corner whose colour-vector length differs from the length of the 4-mean by more than 0.5
+// (RT:340) is subdivided: its child quadrant (centre = the corner's sample position, half the size) is appended
+// to the next level.  Children of one quadrant are appended together, in corner order.
+__global__ __launch_bounds__(APPEND_BLOCK) void k_ms_decide(RayGenParams g, const uint32_t *quadColor, const int *nQuadsDev, int nQuadsHost,
+                                                            long long pixelBase, int *childBase, int *childMask, float *nextCx, float *nextCy,
+                                                            int *nextCount) {
+    __shared__ int ldsCounts[17];
+    const int n = nQuadsDev ? *nQuadsDev : nQuadsHost;
+    const int stride = (int)(gridDim.x * blockDim.x);
+    const int rounds = (n + stride - 1) / stride;
+    for (int it = 0; it < rounds; it++) {
+        const int q = it * stride + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        int mask = 0;
+        float cx = 0, cy = 0;
+        if (q < n) {
+            bool ok = true;
+            if (g.quadLevel == 0) { int x, y; ok = path_pixel(g, pixelBase + q, x, y); cx = (float)x; cy = (float)y; }
+            else { cx = g.quadCx[q]; cy = g.quadCy[q]; }
+            if (ok) {
+                v3 c0 = unpack_color(quadColor[4 * (size_t)q]), c1 = unpack_color(quadColor[4 * (size_t)q + 1]);
+                v3 c2 = unpack_color(quadColor[4 * (size_t)q + 2]), c3 = unpack_color(quadColor[4 * (size_t)q + 3]);
+                v3 average = divf(add(add(add(c0, c1), c2), c3), 4.0f);   // RT:285
+                float al = length(average);                               // RT:286
+                const float TRESHOLD = 0.5f;                              // RT:340
+                if (fabsf(al - length(c0)) > TRESHOLD) mask |= 1;         // RT:288
+                if (fabsf(al - length(c1)) > TRESHOLD) mask |= 2;         // RT:293
+                if (fabsf(al - length(c2)) > TRESHOLD) mask |= 4;         // RT:298
+                if (fabsf(al - length(c3)) > TRESHOLD) mask |= 8;         // RT:303
+            }
+        }
+        // variable-count append: one block_append per corner keeps a quadrant's children in corner order only if
+        // they are contiguous, so reserve them with a single call on the count
+        const int cnt = __builtin_popcount((unsigned)mask);
+        // exclusive scan of cnt over the block
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off); if (lane_id() >= off) incl += t; }
+        const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+        if (lane_id() == 63) ldsCounts[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int total = 0;
+            for (int w = 0; w < nw; w++) { int c = ldsCounts[w]; ldsCounts[w] = total; total += c; }
+            ldsCounts[16] = total ? atomicAdd(nextCount, total) : 0;
+        }
+        __syncthreads();
+        const int base = ldsCounts[16] + ldsCounts[wave] + (incl - cnt);
+        __syncthreads();
+        if (q < n) {
+            childBase[q] = base;
+            childMask[q] = mask;
+            const float quarter = g.quadSize * 0.25f;
+            int o = base;
+            for (int j = 0; j < 4; j++)
+                if (mask & (1 << j)) {
+                    nextCx[o] = (j & 1) ? cx + quarter : cx - quarter;   // RT:290-305: centre of the child = the corner's sample position
+                    nextCy[o] = (j & 2) ? cy + quarter : cy - quarter;
+                    o++;
+                }
+        }
+    }
+}
+void launch_ms_decide(const RayGenParams &g, const uint32_t *quadColor, const int *nQuadsDev, int nQuadsHost, long long pixelBase, int *childBase,
+                      int *childMask, float *nextCx, float *nextCy, int *nextCount, hipStream_t st) {
+    hipLaunchKernelGGL(k_ms_decide, dim3(1024), dim3(APPEND_BLOCK), 0, st, g, quadColor, nQuadsDev, nQuadsHost, pixelBase, childBase, childMask, nextCx,
+                       nextCy, nextCount);
+}
+// Fold the results of level l+1 into level l, in the order the recursion assigns them (RT:288-306): UL, UR, LL
+// replace their own corner; the LOWER-RIGHT recursion writes `out urColor` (RT:305), i.e. slot 1, after the
+// upper-right one, and the lower-right corner keeps its first-pass colour.
+__global__ __launch_bounds__(256) void k_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *childBase, const int *childMask, int n) {
+    for (int q = (int)(blockIdx.x * blockDim.x + threadIdx.x); q < n; q += (int)(gridDim.x * blockDim.x)) {
+        const int mask = childMask[q];
+        if (!mask) continue;
+        int o = childBase[q];
+        for (int j = 0; j < 4; j++)
+            if (mask & (1 << j)) {
+                const uint32_t *s = childColor + 4 * (size_t)o;
+                v3 sum = add(add(add(unpack_color(s[0]), unpack_color(s[1])), unpack_color(s[2])), unpack_color(s[3]));
+                const uint32_t col = pack_color(divf(sum, 4.0f));   // RT:309 of the child call
+                quadColor[4 * (size_t)q + (j == 3 ? 1 : j)] = col;
+                o++;
+            }
+    }
+}
+void launch_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *childBase, const int *childMask, int n, hipStream_t st) {
+    int blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_ms_fold, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, quadColor, childColor, childBase, childMask, n);
 }
 
 // rank-major gathered tiles -> W*H frame (rank 0 after the RCCL gather)

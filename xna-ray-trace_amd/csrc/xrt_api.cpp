@@ -204,12 +204,13 @@ int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g
     g.shardCount = o->shard_count > 1 ? o->shard_count : 1;
     g.shardRank = o->shard_count > 1 ? o->shard_rank : 0;
     g.samples = (o->use_multisampling == XRT_MS_FIXED16) ? 16 : 1;
-    g.pad = 0;
+    g.quadLevel = -1; g.quadCx = nullptr; g.quadCy = nullptr; g.quadSize = 1.0f;
     if (g.shardRank < 0 || g.shardRank >= g.shardCount) return fail(XRT_E_INVALID_ARG, "shard_rank out of range");
     return XRT_OK;
 }
 
-// The frame: for every chunk of paths  raygen -> [intersect -> shade_a -> intersect(shadow) -> shade_b] x (R+1) -> compose -> resolve.
+// The frame: for every chunk of paths  raygen -> [intersect -> shade_a -> intersect(shadow) -> shade_b] x (R+1) -> compose,
+// then resolve (pixel grid, fixed 16 sub-rays) or the quadrant levels of adaptive supersampling (RT:170-311).
 int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts, uint32_t *d_out,
                 float *d_outF32, hipStream_t st, xrt_stats *stats) {
     if (!cam || !opts || (!lights && nLights > 0) || nLights < 0) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
@@ -223,32 +224,35 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     const bool heap = s->hs.arrays.anyTransparent && opts->max_reflections > 0;   // RT:586-702: binary ray tree
     if (heap && opts->max_reflections > 12)
         return fail(XRT_E_UNSUPPORTED, "Transparent materials with MaxReflections > 12 (a ray tree of more than 8191 nodes per pixel)");
-    if (opts->use_multisampling == XRT_MS_ADAPTIVE)
-        return fail(XRT_E_UNSUPPORTED, "adaptive supersampling (RT:170-311) is not implemented yet (SURVEY 8f N1); use XRT_MS_FIXED16");
-    if (opts->use_multisampling != XRT_MS_OFF && opts->use_multisampling != XRT_MS_FIXED16) return fail(XRT_E_INVALID_ARG, "use_multisampling");
+    const int msMode = opts->use_multisampling;
+    if (msMode != XRT_MS_OFF && msMode != XRT_MS_FIXED16 && msMode != XRT_MS_ADAPTIVE) return fail(XRT_E_INVALID_ARG, "use_multisampling");
+    const bool adaptive = msMode == XRT_MS_ADAPTIVE;
+    const int quality = adaptive ? opts->multisample_quality : 0;
+    if (adaptive && (quality < 0 || quality > 6)) return fail(XRT_E_UNSUPPORTED, "MultisampleQuality above 6 (4^7 sub-quadrants per pixel)");
     RayGenParams g;
     int rc = make_raygen(cam, opts, g);
     if (rc != XRT_OK) return rc;
+    if (adaptive) g.samples = 4;
     const int R = opts->max_reflections;
     const int nL = nLights;
     const long long totalTiles = (long long)g.tilesX * g.tilesY;
     const long long myTiles = (totalTiles + g.shardCount - 1) / g.shardCount;   // tiles_per_rank (slots, some may be past the end)
     const long long totalPixels = myTiles * 512;
-    const long long totalPaths = totalPixels * g.samples;
+    if (adaptive && totalPixels * 4 > 0x7fffffffLL) return fail(XRT_E_UNSUPPORTED, "frame too large for adaptive supersampling");
+    const long long firstPaths = totalPixels * g.samples;
     // a path owns up to 2^R rays of one generation when materials refract, one otherwise
     const long long maxPaths = heap ? (MAX_CHUNK_PATHS >> R) : MAX_CHUNK_PATHS;
-    const long long chunkPaths = totalPaths < maxPaths ? totalPaths : maxPaths;
+    const long long chunkPaths = firstPaths < maxPaths ? firstPaths : maxPaths;
     const int P = (int)chunkPaths;
     const size_t rayCap = heap ? ((size_t)P << R) : (size_t)P;
     const size_t nodes = heap ? (((size_t)1 << (R + 1)) - 1) : (size_t)(R + 1);
-    const int nChunks = (int)((totalPaths + chunkPaths - 1) / chunkPaths);
-    const bool wantF32 = d_outF32 != nullptr;
+    const bool wantF32 = d_outF32 != nullptr && !adaptive && g.samples == 1;
     // buffers
     if ((rc = s->rays0.ensure(rayCap)) || (rc = s->rays1.ensure(rayCap)) || (rc = s->hits.ensure(rayCap)) || (rc = s->path0.ensure(rayCap)) ||
         (rc = s->path1.ensure(rayCap)) || (rc = s->shadowSrc.ensure(rayCap)) || (rc = s->shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
         (rc = s->shadowHits.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = s->lvlA.ensure((size_t)P * nodes)) ||
         (rc = s->lvlB.ensure((size_t)P * nodes)) || (rc = s->sampleColor.ensure(P)) || (rc = s->lights.ensure(nL > 0 ? nL : 1)) ||
-        (rc = s->counters.ensure(2 * C_COUNT)))
+        (rc = s->counters.ensure(2 * C_COUNT + 8)))
         return rc;
     if (heap && ((rc = s->node0.ensure(rayCap)) || (rc = s->node1.ensure(rayCap)) || (rc = s->ref0.ensure(rayCap)) || (rc = s->ref1.ensure(rayCap)) ||
                  (rc = s->lvlAlpha.ensure((size_t)P * nodes))))
@@ -256,10 +260,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     if (wantF32 && (rc = s->sampleF32.ensure((size_t)P * 3))) return rc;
     const int cntStride = 2 * (R + 2);          // per chunk: cnt[R+2] then scnt[R+2]
     const int qStride = 2 * (R + 1);
-    if ((rc = s->cnts.ensure((size_t)nChunks * cntStride)) || (rc = s->queues.ensure((size_t)nChunks * qStride))) return rc;
-    HIPCHECK(hipMemsetAsync(s->cnts.p, 0, (size_t)nChunks * cntStride * sizeof(int), st));
-    HIPCHECK(hipMemsetAsync(s->queues.p, 0, (size_t)nChunks * qStride * sizeof(unsigned), st));
-    HIPCHECK(hipMemsetAsync(s->counters.p, 0, 2 * C_COUNT * sizeof(unsigned long long), st));
+    HIPCHECK(hipMemsetAsync(s->counters.p, 0, (2 * C_COUNT + 8) * sizeof(unsigned long long), st));
     std::vector<LightRec> hl(nL > 0 ? nL : 1);
     for (int i = 0; i < nL; i++) {
         if (lights[i].kind != XRT_LIGHT_SPOT && lights[i].kind != XRT_LIGHT_DIRECTIONAL) return fail(XRT_E_INVALID_ARG, "unknown light kind");
@@ -280,59 +281,145 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     if (!e0 || !e1) return fail(XRT_E_HIP, "hipEventCreate failed");
     HIPCHECK(hipEventRecord(e0, st));
     s->progress.store(0.0f);
-    for (int c = 0; c < nChunks; c++) {
-        const long long pathBase = (long long)c * chunkPaths;
-        const int Pc = (int)((totalPaths - pathBase) < chunkPaths ? (totalPaths - pathBase) : chunkPaths);
-        int *cnt = s->cnts.p + (size_t)c * cntStride, *scnt = cnt + (R + 2);
-        unsigned *q = s->queues.p + (size_t)c * qStride;
-        // cnt[0] counts the primary rays that reach the scene's root box; paths[1] doubles as their index list
-        launch_raygen(g, S, rays[0], s->hits.p, paths[1], cnt, Pc, pathBase, st);
-        for (int k = 0; k <= R; k++) {
-            const int cur = k & 1, nxt = cur ^ 1;
-            IntersectArgs A;
-            A.rays = rays[cur]; A.hits = s->hits.p; A.index = k == 0 ? paths[1] : nullptr; A.nDev = cnt + k; A.nMul = 1; A.n = Pc;
-            A.queue = q + 2 * k; A.mode = s->sceneMode; A.meshId = 0;
-            A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.firstBatch = s->firstBatch;
-            hipEvent_t a0 = get_event(s, ev), a1 = get_event(s, ev + 1);
-            if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
-            pairs.push_back({ev, ev + 1}); ev += 2;
-            HIPCHECK(hipEventRecord(a0, st));
-            launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st);
-            HIPCHECK(hipEventRecord(a1, st));
-            if (opts->collect_stats) {   // the reference tests the root box for every ray: count over all of them
-                IntersectArgs Ac = A;
-                if (k == 0) { Ac.index = nullptr; Ac.nDev = nullptr; }
-                launch_count(S, Ac, s->counters.p, st);
-            }
-            launch_shade_a(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : cnt + k, Pc, k == 0 ? nullptr : paths[cur],
-                           (heap && k > 0) ? nodesOf[cur] : nullptr, s->lvlB.p, s->shadowRays.p, s->shadowSrc.p, scnt + k, P, k, st);
-            if (nL > 0) {
-                IntersectArgs B;
-                B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.index = nullptr; B.nDev = scnt + k; B.nMul = nL; B.n = 0;
-                B.queue = q + 2 * k + 1; B.mode = s->sceneMode; B.meshId = 0;
-                B.refillMin = s->tune[0]; B.nodeBurst = s->tune[1]; B.leafBurst = s->tune[2]; B.firstBatch = s->firstBatch;
-                hipEvent_t b0 = get_event(s, ev), b1 = get_event(s, ev + 1);
-                if (!b0 || !b1) return fail(XRT_E_HIP, "hipEventCreate failed");
+    unsigned long long shaded = 0, closestDeep = 0, livePaths = 0;
+
+    // One pass = trace `total` paths produced by generator `gp`; after every chunk `post(Pc, pathBase)` consumes sampleColor.
+    auto run_pass = [&](const RayGenParams &gp, long long total, auto &&post, float progress0, float progress1) -> int {
+        const int nChunks = (int)((total + chunkPaths - 1) / chunkPaths);
+        int rc2;
+        if ((rc2 = s->cnts.ensure((size_t)nChunks * cntStride)) || (rc2 = s->queues.ensure((size_t)nChunks * qStride))) return rc2;
+        HIPCHECK(hipMemsetAsync(s->cnts.p, 0, (size_t)nChunks * cntStride * sizeof(int), st));
+        HIPCHECK(hipMemsetAsync(s->queues.p, 0, (size_t)nChunks * qStride * sizeof(unsigned), st));
+        for (int c = 0; c < nChunks; c++) {
+            const long long pathBase = (long long)c * chunkPaths;
+            const int Pc = (int)((total - pathBase) < chunkPaths ? (total - pathBase) : chunkPaths);
+            int *cnt = s->cnts.p + (size_t)c * cntStride, *scnt = cnt + (R + 2);
+            unsigned *q = s->queues.p + (size_t)c * qStride;
+            // cnt[0] counts the primary rays that reach the scene's root box; paths[1] doubles as their index list
+            launch_raygen(gp, S, rays[0], s->hits.p, paths[1], cnt, Pc, pathBase, st);
+            for (int k = 0; k <= R; k++) {
+                const int cur = k & 1, nxt = cur ^ 1;
+                IntersectArgs A;
+                A.rays = rays[cur]; A.hits = s->hits.p; A.index = k == 0 ? paths[1] : nullptr; A.nDev = cnt + k; A.nMul = 1; A.n = Pc;
+                A.queue = q + 2 * k; A.mode = s->sceneMode; A.meshId = 0;
+                A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.firstBatch = s->firstBatch;
+                hipEvent_t a0 = get_event(s, ev), a1 = get_event(s, ev + 1);
+                if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 pairs.push_back({ev, ev + 1}); ev += 2;
-                HIPCHECK(hipEventRecord(b0, st));
-                launch_intersect(S, B, s->stackNeeded, persistent_grid(s, -1), st);
-                HIPCHECK(hipEventRecord(b1, st));
-                if (opts->collect_stats) launch_count(S, B, s->counters.p + C_COUNT, st);
+                HIPCHECK(hipEventRecord(a0, st));
+                launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st);
+                HIPCHECK(hipEventRecord(a1, st));
+                if (opts->collect_stats) {   // the reference tests the root box for every ray: count over all of them
+                    IntersectArgs Ac = A;
+                    if (k == 0) { Ac.index = nullptr; Ac.nDev = nullptr; }
+                    launch_count(S, Ac, s->counters.p, st);
+                }
+                launch_shade_a(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : cnt + k, Pc, k == 0 ? nullptr : paths[cur],
+                               (heap && k > 0) ? nodesOf[cur] : nullptr, s->lvlB.p, s->shadowRays.p, s->shadowSrc.p, scnt + k, P, k, st);
+                if (nL > 0) {
+                    IntersectArgs B;
+                    B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.index = nullptr; B.nDev = scnt + k; B.nMul = nL; B.n = 0;
+                    B.queue = q + 2 * k + 1; B.mode = s->sceneMode; B.meshId = 0;
+                    B.refillMin = s->tune[0]; B.nodeBurst = s->tune[1]; B.leafBurst = s->tune[2]; B.firstBatch = s->firstBatch;
+                    hipEvent_t b0 = get_event(s, ev), b1 = get_event(s, ev + 1);
+                    if (!b0 || !b1) return fail(XRT_E_HIP, "hipEventCreate failed");
+                    pairs.push_back({ev, ev + 1}); ev += 2;
+                    HIPCHECK(hipEventRecord(b0, st));
+                    launch_intersect(S, B, s->stackNeeded, persistent_grid(s, -1), st);
+                    HIPCHECK(hipEventRecord(b1, st));
+                    if (opts->collect_stats) launch_count(S, B, s->counters.p + C_COUNT, st);
+                }
+                TreeArgs T;
+                T.heap = heap ? 1 : 0;
+                T.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; T.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
+                T.nextNode = heap ? nodesOf[nxt] : nullptr; T.nextRef = heap ? refOf[nxt] : nullptr; T.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
+                launch_shade_b(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : paths[cur], scnt + k, s->shadowSrc.p, s->shadowHits.p, s->lvlA.p,
+                               s->lvlB.p, rays[nxt], paths[nxt], cnt + k + 1, P, k, R, T, st);
             }
-            TreeArgs T;
-            T.heap = heap ? 1 : 0;
-            T.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; T.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
-            T.nextNode = heap ? nodesOf[nxt] : nullptr; T.nextRef = heap ? refOf[nxt] : nullptr; T.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
-            launch_shade_b(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : paths[cur], scnt + k, s->shadowSrc.p, s->shadowHits.p, s->lvlA.p,
-                           s->lvlB.p, rays[nxt], paths[nxt], cnt + k + 1, P, k, R, T, st);
+            if (heap) launch_compose_tree(s->lvlA.p, s->lvlB.p, s->lvlAlpha.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
+            else launch_compose(s->lvlA.p, s->lvlB.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
+            if ((rc2 = post(Pc, pathBase))) return rc2;
+            if (nChunks > 1) {
+                HIPCHECK(hipStreamSynchronize(st));
+                s->progress.store(progress0 + (progress1 - progress0) * (float)(c + 1) / (float)nChunks);
+            }
         }
-        if (heap) launch_compose_tree(s->lvlA.p, s->lvlB.p, s->lvlAlpha.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
-        else launch_compose(s->lvlA.p, s->lvlB.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
-        launch_resolve(g, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, Pc / g.samples, pathBase / g.samples, d_out, d_outF32, st);
-        if (nChunks > 1) {
+        if (stats) {   // per-pass ray accounting (the counter block is reused by the next pass)
             HIPCHECK(hipStreamSynchronize(st));
-            s->progress.store((float)(c + 1) / (float)nChunks);
+            std::vector<int> hc((size_t)nChunks * cntStride);
+            HIPCHECK(hipMemcpy(hc.data(), s->cnts.p, hc.size() * sizeof(int), hipMemcpyDeviceToHost));
+            for (int c = 0; c < nChunks; c++)
+                for (int k = 0; k <= R; k++) {
+                    shaded += (unsigned long long)hc[(size_t)c * cntStride + (R + 2) + k];
+                    if (k > 0) closestDeep += (unsigned long long)hc[(size_t)c * cntStride + k];
+                }
         }
+        return XRT_OK;
+    };
+
+    // valid pixels of this shard
+    unsigned long long validPixels = 0;
+    for (long long t = g.shardRank; t < totalTiles; t += g.shardCount) {
+        int tx = (int)(t % g.tilesX), ty = (int)(t / g.tilesX);
+        int w = g.width - tx * XRT_TILE_W; if (w > XRT_TILE_W) w = XRT_TILE_W;
+        int h = g.height - ty * XRT_TILE_H; if (h > XRT_TILE_H) h = XRT_TILE_H;
+        validPixels += (unsigned long long)w * h;
+    }
+
+    if (!adaptive) {
+        livePaths = validPixels * (unsigned long long)g.samples;
+        rc = run_pass(g, firstPaths, [&](int Pc, long long pathBase) -> int {
+            launch_resolve(g, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, Pc / g.samples, pathBase / g.samples, d_out, d_outF32, st);
+            return XRT_OK;
+        }, 0.0f, 1.0f);
+        if (rc != XRT_OK) return rc;
+    } else {
+        // RenderFirstPass / GetColorForQuadrant (RT:170-311): level 0 quadrants are the pixels (size 1); a level's
+        // quadrants each cast four rays; corners that deviate are subdivided into the next level, down to
+        // MultisampleQuality; results fold back up.
+        struct Level { DevBuf<uint32_t> color; DevBuf<int> childBase, childMask; DevBuf<float> cx, cy; long long n = 0; };
+        std::vector<Level> lv((size_t)quality + 1);
+        int *levelCount = reinterpret_cast<int *>(s->counters.p + 2 * C_COUNT);   // [quality+1] ints in the spare counter words
+        auto free_levels = [&]() { for (auto &l : lv) { l.color.release(); l.childBase.release(); l.childMask.release(); l.cx.release(); l.cy.release(); } };
+        lv[0].n = totalPixels;
+        float size = 1.0f;
+        for (int l = 0; l <= quality && rc == XRT_OK; l++) {
+            Level &L = lv[l];
+            if (L.n == 0) break;
+            if ((rc = L.color.ensure((size_t)L.n * 4))) break;
+            RayGenParams gl = g;
+            gl.quadLevel = l; gl.quadSize = size; gl.quadCx = L.cx.p; gl.quadCy = L.cy.p;
+            livePaths += (l == 0 ? validPixels : (unsigned long long)L.n) * 4ull;
+            rc = run_pass(gl, L.n * 4, [&](int Pc, long long pathBase) -> int {
+                HIPCHECK(hipMemcpyAsync(L.color.p + pathBase, s->sampleColor.p, (size_t)Pc * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+                return XRT_OK;
+            }, (float)l / (float)(quality + 1), (float)(l + 1) / (float)(quality + 1));
+            if (rc != XRT_OK) break;
+            if (l < quality) {   // RT:279-306
+                Level &N = lv[l + 1];
+                if ((rc = L.childBase.ensure((size_t)L.n)) || (rc = L.childMask.ensure((size_t)L.n)) || (rc = N.cx.ensure((size_t)L.n * 4)) ||
+                    (rc = N.cy.ensure((size_t)L.n * 4)))
+                    break;
+                launch_ms_decide(gl, L.color.p, nullptr, (int)L.n, 0, L.childBase.p, L.childMask.p, N.cx.p, N.cy.p, levelCount + l + 1, st);
+                int hn = 0;
+                hipError_t e = hipMemcpyAsync(&hn, levelCount + l + 1, sizeof(int), hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e != hipSuccess) { rc = fail(XRT_E_HIP, "adaptive level readback: %s", hipGetErrorString(e)); break; }
+                N.n = hn;
+                size = size / 2.0f;   // RT:290
+            }
+        }
+        if (rc == XRT_OK) {
+            for (int l = quality - 1; l >= 0; l--)
+                if (lv[l + 1].n > 0) launch_ms_fold(lv[l].color.p, lv[l + 1].color.p, lv[l].childBase.p, lv[l].childMask.p, (int)lv[l].n, st);
+            RayGenParams g0 = g;
+            g0.quadLevel = 0; g0.quadSize = 1.0f;
+            launch_resolve(g0, lv[0].color.p, nullptr, (int)totalPixels, 0, d_out, d_outF32, st);
+            hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) rc = fail(XRT_E_HIP, "adaptive resolve: %s", hipGetErrorString(e));
+        }
+        free_levels();
+        if (rc != XRT_OK) return rc;
     }
     HIPCHECK(hipEventRecord(e1, st));
     HIPCHECK(hipStreamSynchronize(st));
@@ -340,27 +427,11 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     s->progress.store(1.0f);
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        std::vector<int> hc((size_t)nChunks * cntStride);
-        HIPCHECK(hipMemcpy(hc.data(), s->cnts.p, hc.size() * sizeof(int), hipMemcpyDeviceToHost));
         unsigned long long hcnt[2 * C_COUNT];
         HIPCHECK(hipMemcpy(hcnt, s->counters.p, sizeof(hcnt), hipMemcpyDeviceToHost));
-        unsigned long long shaded = 0, closest = 0;
-        for (int c = 0; c < nChunks; c++)
-            for (int k = 0; k <= R; k++) {
-                shaded += (unsigned long long)hc[(size_t)c * cntStride + (R + 2) + k];
-                if (k > 0) closest += (unsigned long long)hc[(size_t)c * cntStride + k];
-            }
-        // valid pixels of this shard
-        unsigned long long validPixels = 0;
-        for (long long t = g.shardRank; t < totalTiles; t += g.shardCount) {
-            int tx = (int)(t % g.tilesX), ty = (int)(t / g.tilesX);
-            int w = g.width - tx * XRT_TILE_W; if (w > XRT_TILE_W) w = XRT_TILE_W;
-            int h = g.height - ty * XRT_TILE_H; if (h > XRT_TILE_H) h = XRT_TILE_H;
-            validPixels += (unsigned long long)w * h;
-        }
         if (!opts->collect_stats) {
             std::memset(hcnt, 0, sizeof(hcnt));
-            hcnt[C_RAYS] = validPixels * g.samples + closest;
+            hcnt[C_RAYS] = livePaths + closestDeep;
             hcnt[C_HITS] = shaded;
             hcnt[C_COUNT + C_RAYS] = shaded * (unsigned long long)nL;
         }

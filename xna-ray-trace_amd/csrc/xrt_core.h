@@ -263,8 +263,10 @@ struct RayGenParams {
     int   width, height;
     int   tilesX, tilesY;
     int   shardRank, shardCount;   // path -> tile mapping
-    int   samples;                 // 1, or 16 for XRT_MS_FIXED16
-    int   pad;
+    int   samples;                 // 1, or 16 for XRT_MS_FIXED16, or 4 for one level of the adaptive quadrants
+    int   quadLevel;               // adaptive supersampling (RT:215-311): -1 off; level 0 quadrants are the pixels,
+    const float *quadCx, *quadCy;  // deeper ones are listed (centre per quadrant)
+    float quadSize;                // 1, 0.5, 0.25 ... (RT:195, RT:290 size / 2.0f)
 };
 
 // One Viewport.Unproject (RT:415 / RT:419) given the hoisted inverse matrix.
