@@ -86,6 +86,30 @@ struct Material {
                    (float)((baseArgb >> 8) & 0xFF) * BYTE_RECIPROCAL,
                    (float)(baseArgb & 0xFF) * BYTE_RECIPROCAL);
     }
+    // MAT:162-232.  Texture.ColorData is the Format32bppPArgb copy (TEX:24-33); for opaque textures (every
+    // fixture; a 24-bpp BMP has no alpha) it equals the Format32bppArgb words, which is what is stored here.
+    void GetColorBilinear(Vector2 uv, Vector3 &color) const {
+        const float tdx = 1.0f / (float)Width, tdy = 1.0f / (float)Height;   // texelDensity (MAT:67)
+        double remainderX = std::remainder((double)uv.X, (double)tdx);         // Math.IEEERemainder (MAT:168-169)
+        double remainderY = std::remainder((double)uv.Y, (double)tdy);
+        uv.X -= (float)remainderX;
+        uv.Y -= (float)remainderY;
+        int x = (int)(uv.X * (float)(Width - 1));
+        int y = (int)(uv.Y * (float)(Height - 1));
+        int x2 = (int)((uv.X + tdx) * (float)(Width - 1));
+        int y2 = (int)((uv.Y + tdy) * (float)(Height - 1));
+        auto texel = [&](int xx, int yy) {   // the C# indexes a managed int[] (IndexOutOfRangeException when outside); guarded here
+            int64_t idx = (int64_t)Width * yy + xx;
+            if (idx < 0 || idx >= (int64_t)argb.size()) idx = 0;
+            uint32_t w = argb[(size_t)idx];
+            return V3((float)((w >> 16) & 0xFF), (float)((w >> 8) & 0xFF), (float)(w & 0xFF));
+        };
+        Vector3 baseColor = texel(x, y), blendXColor = texel(x2, y), blendYColor = texel(x, y2), blendXYColor = texel(x2, y2);
+        float dx = (float)(remainderX * (double)Width) + 0.5f;
+        float dy = (float)(remainderY * (double)Height) + 0.5f;
+        float invertDx = 1.0f - dx, invertDy = 1.0f - dy;
+        color = ((baseColor * invertDx * invertDy) + (blendYColor * invertDx * dy) + (blendXColor * dx * invertDy) + (blendXYColor * dx * dy)) * BYTE_RECIPROCAL;
+    }
     // MAT:71-100.  Returns false for what the C# answers with ArgumentException.
     bool LookupUV(Vector2 uv, int addressMode, int filtering, Vector3 &color) const {
         switch (addressMode) {
@@ -94,8 +118,9 @@ struct Material {
             case XRT_ADDRESS_MIRROR: MirrorUV(uv); break;
             default: return false;
         }
-        if (filtering != XRT_FILTER_POINT) return false;   // bilinear: SURVEY §8f N3 (next)
-        GetColorPoint(uv, color);
+        if (filtering == XRT_FILTER_POINT) GetColorPoint(uv, color);
+        else if (filtering == XRT_FILTER_BILINEAR) GetColorBilinear(uv, color);
+        else return false;
         return true;
     }
 };

@@ -266,6 +266,21 @@ def test_adaptive_supersampling(xrt, orc, quality):
             assert tracer.last_stats[k] == o_st[k], (k, tracer.last_stats[k], o_st[k])
 
 
+@pytest.mark.parametrize("address", [0, 1, 2])
+@pytest.mark.parametrize("filtering", [0, 1])
+def test_texture_address_modes_and_filters(xrt, orc, address, filtering):
+    """MAT:71-232: Clamp / Wrap / Mirror addressing with point and bilinear filtering (IEEERemainder in double).
+    UVs are scaled beyond [0,1] so the address modes matter."""
+    spec = xrt.configs.crate_grid_scene(120, 68, n=2, grid=3)
+    data, m = spec.meshes[0]
+    data.uv[:] = data.uv * np.float32(2.5) - np.float32(0.75)
+    spec.address_mode, spec.filtering = address, filtering
+    scene, tracer = xrt.configs.build_product(spec)
+    rgba, rgbf = tracer.Render(want_float=True)
+    o_rgba, o_rgbf, _ = orc.OracleScene(spec).render(nthreads=8)
+    assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+
+
 def test_error_conventions_on_gpu(xrt):
     spec = xrt.configs.config("C1")
     scene, tracer = xrt.configs.build_product(spec)

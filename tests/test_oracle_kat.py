@@ -250,8 +250,20 @@ def test_texture_lookup_wrap_point(xrt, orc):
     assert look(1.25, -0.25) == look(0.25, 0.75)      # wrap (MAT:127-135)
     assert look(7.0, 0) == texel(0, 0)                # 7 % 1 == 0
     assert look(1.5, 2.0, xrt.abi.ADDRESS_CLAMP) == texel(3, 3)
-    # unsupported filter / bad enum -> the C# throws ArgumentException (MAT:85,97)
+    # bad enum -> the C# throws ArgumentException (MAT:85,97)
     assert orc.lib().orc_kat_lookup_uv(C.byref(m), _p(fa(0, 0)), 7, xrt.abi.FILTER_POINT, _p(out)) == -1
+    assert orc.lib().orc_kat_lookup_uv(C.byref(m), _p(fa(0, 0)), xrt.abi.ADDRESS_WRAP, 5, _p(out)) == -1
+    # bilinear (MAT:162-232) on a 2x2 texture {black, red / green, blue}: at uv (0.5, 0.5) IEEERemainder(0.5, 0.5) = 0,
+    # dx = dy = 0.5, the four texels blend with weight 1/4 each -> 63.75 / 255 = 0.25 per channel (hand computed)
+    t2 = np.array([[0xFF000000, 0xFFFF0000], [0xFF00FF00, 0xFF0000FF]], dtype=np.uint32)
+    m2 = xrt.abi.xrt_material()
+    m2.use_texture, m2.tex_width, m2.tex_height = 1, 2, 2
+    m2.tex_argb = t2.ctypes.data_as(C.POINTER(C.c_uint32))
+    assert orc.lib().orc_kat_lookup_uv(C.byref(m2), _p(fa(0.5, 0.5)), xrt.abi.ADDRESS_WRAP, xrt.abi.FILTER_BILINEAR, _p(out)) == 0
+    assert tuple(out) == (0.25, 0.25, 0.25)
+    # at uv (1, 1): remainder 0, x = x2 = 1 -> 0.25 * 4 * blue
+    assert orc.lib().orc_kat_lookup_uv(C.byref(m2), _p(fa(1.0, 1.0)), xrt.abi.ADDRESS_WRAP, xrt.abi.FILTER_BILINEAR, _p(out)) == 0
+    assert tuple(out) == (0.0, 0.0, 1.0)
 
 
 def test_k10_golden_c1_frame(xrt, orc):

@@ -509,6 +509,25 @@ __device__ __forceinline__ v3 lookup_uv(const ShadeView &V, const MaterialRec &M
         if (((int)(ox - ux)) % 2 == 0) ux = 1.0f - ux;
         if (((int)(oy - uy)) % 2 == 0) uy = 1.0f - uy;
     }
+    if (V.filtering == XRT_FILTER_BILINEAR) {   // MAT:162-232 (Texture.ColorData == the Argb words for opaque textures)
+        const float tdx = 1.0f / (float)M.texWidth, tdy = 1.0f / (float)M.texHeight;   // MAT:67
+        const double remX = remainder((double)ux, (double)tdx), remY = remainder((double)uy, (double)tdy);   // Math.IEEERemainder, exact
+        ux -= (float)remX;
+        uy -= (float)remY;
+        const int bx = (int)(ux * (float)(M.texWidth - 1)), by = (int)(uy * (float)(M.texHeight - 1));
+        const int bx2 = (int)((ux + tdx) * (float)(M.texWidth - 1)), by2 = (int)((uy + tdy) * (float)(M.texHeight - 1));
+        auto texel = [&](int xx, int yy) {
+            long long idx = (long long)M.texWidth * yy + xx;
+            if (idx < 0 || idx >= (long long)M.texWidth * M.texHeight) idx = 0;
+            uint32_t w = V.texels[M.texOffset + idx];
+            return mk((float)((w >> 16) & 0xffu), (float)((w >> 8) & 0xffu), (float)(w & 0xffu));
+        };
+        const v3 c00 = texel(bx, by), c10 = texel(bx2, by), c01 = texel(bx, by2), c11 = texel(bx2, by2);
+        const float dx = (float)(remX * (double)M.texWidth) + 0.5f, dy = (float)(remY * (double)M.texHeight) + 0.5f;
+        const float ix = 1.0f - dx, iy = 1.0f - dy;
+        v3 sum = add(add(add(scale(scale(c00, ix), iy), scale(scale(c01, ix), dy)), scale(scale(c10, dx), iy)), scale(scale(c11, dx), dy));
+        return scale(sum, 1.0f / 255.0f);
+    }
     int x = (int)(ux * (float)(M.texWidth - 1));    // MAT:147
     int y = (int)(uy * (float)(M.texHeight - 1));   // MAT:148
     long long idx = (long long)M.texWidth * y + x;

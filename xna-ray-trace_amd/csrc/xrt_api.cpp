@@ -219,8 +219,6 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
         return fail(XRT_E_INVALID_ARG, "Value does not fall within the expected range: addressMode (MAT:85)");
     if (opts->filtering != XRT_FILTER_POINT && opts->filtering != XRT_FILTER_BILINEAR)
         return fail(XRT_E_INVALID_ARG, "Value does not fall within the expected range: filtering (MAT:97)");
-    if (opts->filtering == XRT_FILTER_BILINEAR && s->hs.arrays.anyTexture)
-        return fail(XRT_E_UNSUPPORTED, "bilinear texture filtering (MAT:162-232) is not implemented yet (SURVEY 8f N3)");
     const bool heap = s->hs.arrays.anyTransparent && opts->max_reflections > 0;   // RT:586-702: binary ray tree
     if (heap && opts->max_reflections > 12)
         return fail(XRT_E_UNSUPPORTED, "Transparent materials with MaxReflections > 12 (a ray tree of more than 8191 nodes per pixel)");
