@@ -77,7 +77,7 @@ int emu_intersect(emu_scene *s, int mode, int mesh, const xrt_ray *rays, int64_t
 int emu_wave_sim(emu_scene *s, int mode, int mesh, const xrt_ray *rays, int64_t n, int nWaves, int refillMin, int nodeBurst, int leafBurst, int64_t *out) {
     if (!s->hs.built) return -1;
     SceneView S = s->hs.host_view();
-    for (int i = 0; i < 12; i++) out[i] = 0;
+    for (int i = 0; i < 16; i++) out[i] = 0;
     const int BATCH = 256;
     std::vector<Lane> L(64);
     std::vector<EmuStack> stk(64);
@@ -118,6 +118,7 @@ int emu_wave_sim(emu_scene *s, int mode, int mesh, const xrt_ray *rays, int64_t 
             if (mode == MODE_SCENE) while (any(ST_SCENE)) { out[2]++; for (size_t i = 0; i < 64; i++) if (L[i].state == ST_SCENE) { out[3]++; advance_scene(L[i], S, stk[i]); } }
             for (int it = 0; it < nodeBurst && any(ST_NODE); it++) {
                 out[4]++;
+                for (size_t i = 0; i < 64; i++) { if (L[i].state == ST_IDLE) out[12]++; if (L[i].state == ST_LEAF) out[13]++; }
                 for (size_t i = 0; i < 64; i++) if (L[i].state == ST_NODE) {
                     out[5]++;
                     int sp0 = L[i].sp; bool wasEmpty = L[i].mask == 0;
@@ -127,6 +128,7 @@ int emu_wave_sim(emu_scene *s, int mode, int mesh, const xrt_ray *rays, int64_t 
             }
             for (int it = 0; it < leafBurst && any(ST_LEAF); it++) {
                 out[6]++;
+                for (size_t i = 0; i < 64; i++) { if (L[i].state == ST_IDLE || L[i].state == ST_FINISH) out[14]++; if (L[i].state == ST_NODE) out[15]++; }
                 for (size_t i = 0; i < 64; i++) if (L[i].state == ST_LEAF) { out[7]++; int sp = L[i].spec; advance_leaf(L[i], S); if (L[i].spec || sp) out[10]++; }
             }
             for (auto &l : L) if (l.state == ST_FINISH) l.state = ST_IDLE;

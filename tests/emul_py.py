@@ -103,7 +103,7 @@ class EmulScene:
     def wave_sim(self, rays, mode=0, mesh=0, n_waves=64, tune=(24, 64, 32)):
         """Wave-level scheduling model of the traversal kernel: step and active-lane counts per phase."""
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
-        out = np.zeros(12, dtype=np.int64)
+        out = np.zeros(16, dtype=np.int64)
         assert lib().emu_wave_sim(self.h, mode, mesh, rays.ctypes.data, rays.shape[0], n_waves, tune[0], tune[1], tune[2], out.ctypes.data) == 0
-        names = ("refills", "refilled", "scene_steps", "scene_lanes", "node_steps", "node_lanes", "leaf_steps", "leaf_lanes", "pop_lanes", "descend_lanes", "geom_lanes", "outer")
+        names = ("refills", "refilled", "scene_steps", "scene_lanes", "node_steps", "node_lanes", "leaf_steps", "leaf_lanes", "pop_lanes", "descend_lanes", "geom_lanes", "outer", "node_idle", "node_wait_leaf", "leaf_idle", "leaf_wait_node")
         return dict(zip(names, out.tolist()))

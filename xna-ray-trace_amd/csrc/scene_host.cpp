@@ -6,7 +6,7 @@
 namespace xrt {
 
 size_t SceneArrays::bytes() const {
-    return (blocks.size() + refN.size() + snodes.size() + shade.size()) * sizeof(f4) + refG.size() * sizeof(g3) +
+    return (blocks.size() + refN.size() + snodes.size() + shade.size() + leafNB.size()) * sizeof(f4) + refG.size() * sizeof(g3) +
            (childDfs.size() + srefs.size() + objMesh.size()) * sizeof(int) + meshes.size() * sizeof(MeshRec) +
            objects.size() * sizeof(ObjRec) + materials.size() * sizeof(MaterialRec) + texels.size() * sizeof(uint32_t);
 }
@@ -74,6 +74,30 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
             A.blocks.push_back(lo); A.blocks.push_back(hi);
         }
         A.childDfs.insert(A.childDfs.end(), t.childDfs.begin(), t.childDfs.end());
+        // per leaf: bounds of its triangles' surface normals, so a leaf whose triangles all face away from a ray
+        // (RE:48-51 would reject every one of them) can be skipped without reading its references
+        for (size_t bi = 0; bi < t.blocks.size() / 2; bi++) {
+            const f4 lo = t.blocks[2 * bi], hi = t.blocks[2 * bi + 1];
+            const int lref = f2i(lo.y), masks = f2i(lo.z), total = f2i(lo.w);
+            const int offw[4] = {f2i(hi.x), f2i(hi.y), f2i(hi.z), f2i(hi.w)};
+            auto off = [&](int q) { int w = offw[q >> 1]; return (q & 1) ? (int)((unsigned)w >> 16) : (w & 0xffff); };
+            for (int c = 0; c < 8; c++) {
+                f4 mn{0, 0, 0, 0}, mx{0, 0, 0, 0};
+                if (!((masks >> c) & 1)) {
+                    const int b0 = lref + off(c), b1 = lref + (c == 7 ? total : off(c + 1));
+                    for (int r = b0; r < b1; r++) {
+                        const float *sn = &m.sn[(size_t)t.leafRefs[r] * 3];
+                        if (r == b0) { mn = f4{sn[0], sn[1], sn[2], 0}; mx = mn; }
+                        else {
+                            mn.x = sn[0] < mn.x ? sn[0] : mn.x; mn.y = sn[1] < mn.y ? sn[1] : mn.y; mn.z = sn[2] < mn.z ? sn[2] : mn.z;
+                            mx.x = sn[0] > mx.x ? sn[0] : mx.x; mx.y = sn[1] > mx.y ? sn[1] : mx.y; mx.z = sn[2] > mx.z ? sn[2] : mx.z;
+                        }
+                        if (!(sn[0] == sn[0] && sn[1] == sn[1] && sn[2] == sn[2])) { mn.w = 1.0f; }   // a NaN normal: never skip this leaf
+                    }
+                }
+                A.leafNB.push_back(mn); A.leafNB.push_back(mx);
+            }
+        }
         for (int tri : t.leafRefs) {   // leaf references in leaf order: normal stream + geometry stream
             const float *p = &m.v[(size_t)tri * 9];
             const float *sn = &m.sn[(size_t)tri * 3];
@@ -137,6 +161,7 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
     if (A.objects.empty()) { ObjRec z; std::memset(&z, 0, sizeof(z)); A.objects.push_back(z); }
     if (A.materials.empty()) { MaterialRec z; std::memset(&z, 0, sizeof(z)); A.materials.push_back(z); }
     if (A.blocks.empty()) A.blocks.assign(2, f4{0, 0, 0, 0});
+    if (A.leafNB.empty()) A.leafNB.assign(16, f4{0, 0, 0, 0});
     if (A.childDfs.empty()) A.childDfs.assign(8, -1);
     built = true;
     return true;
@@ -145,7 +170,7 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
 SceneView HostScene::host_view() const {
     SceneView S;
     const SceneArrays &A = arrays;
-    S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data();
+    S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data(); S.leafNB = A.leafNB.data();
     S.refN = A.refN.data(); S.refG = A.refG.data(); S.meshes = A.meshes.data();
     S.snodes = A.snodes.data(); S.srefs = A.srefs.data(); S.objects = A.objects.data(); S.objMesh = A.objMesh.data();
     S.nMeshes = (int)meshes.size(); S.nObjects = (int)objects.size();

@@ -15,7 +15,7 @@ constexpr int SHADE_F4 = 6;   // f4 per triangle shading record:
 //   s4 = (uv2.y, uv3.x, uv3.y, as_float(material))  s5 = (surfaceNormal.xyz, as_float(mesh))
 
 struct SceneArrays {
-    std::vector<f4> blocks, refN, snodes, shade;
+    std::vector<f4> blocks, refN, snodes, shade, leafNB;   // leafNB: 2 per node: component-wise min / max of the leaf's surface normals
     std::vector<g3> refG;
     std::vector<int> childDfs, srefs, objMesh;
     std::vector<MeshRec> meshes;

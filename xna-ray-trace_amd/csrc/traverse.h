@@ -20,6 +20,7 @@ namespace xrt {
 struct SceneView {
     const f4 *blocks;       // mesh octrees: 2 per block descriptor (implicit boxes, xrt_core.h)
     const int *childDfs;    // 8 per block: DFS pre-order index of child c
+    const f4 *leafNB;       // 2 per node: component-wise min / max of the leaf's surface normals
     const f4 *refN;         // per leaf reference: (surfaceNormal.xyz, global triangle id)
     const g3 *refG;         // 3 per leaf reference: v1, E1, E2
     const MeshRec *meshes;
@@ -152,7 +153,7 @@ XRT_HD void lane_begin(Lane &L, const SceneView &S, v3 o, v3 d, int ignoreMesh, 
     L.sfound = 0;
     L.sbKey = 0; L.sbD = 0; L.sbU = 0; L.sbV = 0; L.sbRef = 0; L.sbLeaf = 0; L.sbObj = -1; L.sbMesh = -1;
     L.sRef = 0; L.sRefEnd = 0; L.mPtr = 0; L.mEnd = 0; L.ssp = 0; L.sKey = 0; L.obj = -1;
-    L.spec = 1;
+    L.spec = (L.ignoreId < 0) ? 1 : 0;   // rays leaving a surface (RT:485, RT:559) start among back faces
     if (mode == MODE_SCENE) {
         L.w = make_ray(o, d);
         L.sblk = 0; L.smask = 1;   // root = slot 0 of block 0
@@ -253,6 +254,18 @@ XRT_HD void finish_mesh_query(Lane &L, int mode) {
     L.state = (mode == MODE_SCENE) ? ST_SCENE : ST_FINISH;   // MODE_SINGLE: the one body's one mesh was the whole scene
 }
 
+// Every triangle of a leaf is rejected by the back-face test (RE:48-51: N.D > 0 in binary32) when a lower bound
+// of N.D over the box [nmin, nmax] of the leaf's normals exceeds the rounding error of the evaluated dot product:
+// |fl(N.D) - N.D| <= 3u * sum|N_k D_k| with u = 2^-24, and the bound itself is evaluated with the same error, so
+// a margin of 1e-5 * sum max|N_k| |D_k| (> 50 x 6u) is safe.  NaNs make the comparison false (no skip).
+XRT_HD bool all_back_facing(f4 nmin, f4 nmax, v3 d) {
+    float lx = fminf(nmin.x * d.x, nmax.x * d.x), ly = fminf(nmin.y * d.y, nmax.y * d.y), lz = fminf(nmin.z * d.z, nmax.z * d.z);
+    float sx = fmaxf(fabsf(nmin.x), fabsf(nmax.x)) * fabsf(d.x), sy = fmaxf(fabsf(nmin.y), fabsf(nmax.y)) * fabsf(d.y),
+          sz = fmaxf(fabsf(nmin.z), fabsf(nmax.z)) * fabsf(d.z);
+    float lower = (lx + ly) + lz, scale_ = (sx + sy) + sz;
+    return nmin.w == 0.0f && lower > 1e-5f * scale_ && scale_ < 3.0e38f && lower == lower && d.x == d.x && d.y == d.y && d.z == d.z;
+}
+
 // ---- mesh level: one child of the current block (MO:328-353), front to back, with key pruning ------------------
 // Memory is touched only when a block is entered (descend) or re-entered (pop): 32 bytes of descriptor.
 template <class Stack>
@@ -292,6 +305,10 @@ XRT_HD void advance_node(Lane &L, const SceneView &S, Stack &stk, int mode, bool
     if (!hitBox) return;
     if (!((L.d2 >> c) & 1)) {   // leaf child (non-empty by construction of the mask): its entry key is the bucket key
         if (L.mfound && key > L.mKey) return;
+        if (!L.spec) {   // the lane has lately met back faces only: can this whole leaf be rejected by RE:48-51 without reading it?
+            const f4 nlo = S.leafNB[2 * (size_t)(L.blk * 8 + c)], nhi = S.leafNB[2 * (size_t)(L.blk * 8 + c) + 1];
+            if (all_back_facing(nlo, nhi, L.r.d)) return;
+        }
         // offs[] is a running total over all eight children, so the list ends where the next child's starts
         const unsigned long long offLo = L.offLo, offHi = L.offHi;
         L.ref = L.d1 + child_ref_offset(offLo, offHi, c);

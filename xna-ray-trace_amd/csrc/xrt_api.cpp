@@ -69,7 +69,7 @@ struct xrt_scene {
     int device = -1;   // -1: host-only scene (inspection of the built trees; every compute call fails)
     HostScene hs;
     // HBM-resident scene
-    DevBuf<f4> blocks, refN, snodes, shade;
+    DevBuf<f4> blocks, refN, snodes, shade, leafNB;
     DevBuf<g3> refG;
     DevBuf<int> childDfs, srefs, objMesh;
     DevBuf<MeshRec> meshes;
@@ -105,7 +105,7 @@ struct xrt_scene {
             (void)hipSetDevice(device);
             for (auto e : events) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
-            blocks.release(); refN.release(); refG.release(); snodes.release(); shade.release();
+            blocks.release(); leafNB.release(); refN.release(); refG.release(); snodes.release(); shade.release();
             childDfs.release(); srefs.release(); objMesh.release(); meshes.release();
             objects.release(); materials.release(); texels.release();
             rays0.release(); rays1.release(); shadowRays.release(); apiRays.release(); hits.release();
@@ -570,14 +570,14 @@ int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_thre
     if (scene->device < 0) return XRT_OK;   // host-only scene: trees can be inspected, nothing can be traced
     HIPCHECK(hipSetDevice(scene->device));
     int rc;
-    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->refN, A.refN)) || (rc = upload(scene->refG, A.refG)) ||
+    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->leafNB, A.leafNB)) || (rc = upload(scene->refN, A.refN)) || (rc = upload(scene->refG, A.refG)) ||
         (rc = upload(scene->snodes, A.snodes)) || (rc = upload(scene->shade, A.shade)) || (rc = upload(scene->childDfs, A.childDfs)) ||
         (rc = upload(scene->srefs, A.srefs)) || (rc = upload(scene->objMesh, A.objMesh)) ||
         (rc = upload(scene->meshes, A.meshes)) || (rc = upload(scene->objects, A.objects)) || (rc = upload(scene->materials, A.materials)) ||
         (rc = upload(scene->texels, A.texels)))
         return rc;
     SceneView &S = scene->view;
-    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.refN = scene->refN.p; S.refG = scene->refG.p;
+    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.leafNB = scene->leafNB.p; S.refN = scene->refN.p; S.refG = scene->refG.p;
     S.meshes = scene->meshes.p; S.snodes = scene->snodes.p; S.srefs = scene->srefs.p;
     S.objects = scene->objects.p; S.objMesh = scene->objMesh.p;
     S.nMeshes = (int)scene->hs.meshes.size(); S.nObjects = (int)scene->hs.objects.size();
