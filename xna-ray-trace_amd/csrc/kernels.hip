@@ -14,6 +14,8 @@
 // Built with -ffp-contract=off: every result must be bit-identical to the oracle.
 #include "kernels.h"
 
+#include <hip/hip_ext.h>
+
 namespace xrt {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -88,7 +90,10 @@ __global__ __launch_bounds__(256) void k_intersect(SceneView S, IntersectArgs A)
     // Further batches come from the queue, guided (large while much work remains, 64 rays near the end), and
     // the next one is requested while the current one is being traced so the atomic's latency is hidden.
     const int nWaves = (int)gridDim.x * 4;
-    const int first = A.firstBatch;   // 64 for deep octrees (dynamic balance matters), 256 for trivial scenes (fixed costs matter)
+    // static share: at most A.firstBatch rays (64 for deep octrees where dynamic balance matters, 256 for trivial
+    // scenes where queue traffic matters), but no more than an even split of the launch over the resident waves
+    const int even = ((n + nWaves - 1) / nWaves + 63) & ~63;
+    const int first = even < 64 ? 64 : (even < A.firstBatch ? even : A.firstBatch);
     const unsigned qOffset = (unsigned)(nWaves * first);
     int batchNext = (wave * (int)gridDim.x + (int)blockIdx.x) * first;
     int batchEnd = min(batchNext + first, n);
@@ -177,22 +182,24 @@ int intersect_blocks_per_cu(int stackNeeded, int mode) {
     if (mode == MODE_MESH) return bpc_mode<MODE_MESH>(cap);
     return bpc_mode<MODE_SCENE>(cap);
 }
-template <int M> static void launch_mode(int cap, dim3 g, const SceneView &S, const IntersectArgs &A, hipStream_t st) {
+// The start/stop events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL): per-launch timing
+// without the ~3 us barrier packets hipEventRecord would put on both sides of every launch.
+template <int M> static void launch_mode(int cap, dim3 g, const SceneView &S, const IntersectArgs &A, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     dim3 b(256);
     switch (cap) {
-        case 8: hipLaunchKernelGGL((k_intersect<8, M>), g, b, 0, st, S, A); break;
-        case 12: hipLaunchKernelGGL((k_intersect<12, M>), g, b, 0, st, S, A); break;
-        case 16: hipLaunchKernelGGL((k_intersect<16, M>), g, b, 0, st, S, A); break;
-        case 24: hipLaunchKernelGGL((k_intersect<24, M>), g, b, 0, st, S, A); break;
-        default: hipLaunchKernelGGL((k_intersect<40, M>), g, b, 0, st, S, A); break;
+        case 8: hipExtLaunchKernelGGL((k_intersect<8, M>), g, b, 0, st, e0, e1, 0, S, A); break;
+        case 12: hipExtLaunchKernelGGL((k_intersect<12, M>), g, b, 0, st, e0, e1, 0, S, A); break;
+        case 16: hipExtLaunchKernelGGL((k_intersect<16, M>), g, b, 0, st, e0, e1, 0, S, A); break;
+        case 24: hipExtLaunchKernelGGL((k_intersect<24, M>), g, b, 0, st, e0, e1, 0, S, A); break;
+        default: hipExtLaunchKernelGGL((k_intersect<40, M>), g, b, 0, st, e0, e1, 0, S, A); break;
     }
 }
-void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeeded, int gridBlocks, hipStream_t st) {
+void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeeded, int gridBlocks, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     const int cap = intersect_stack_capacity(stackNeeded);
     dim3 g((unsigned)gridBlocks);
-    if (A.mode == MODE_SINGLE) launch_mode<MODE_SINGLE>(cap, g, S, A, st);
-    else if (A.mode == MODE_MESH) launch_mode<MODE_MESH>(cap, g, S, A, st);
-    else launch_mode<MODE_SCENE>(cap, g, S, A, st);
+    if (A.mode == MODE_SINGLE) launch_mode<MODE_SINGLE>(cap, g, S, A, st, e0, e1);
+    else if (A.mode == MODE_MESH) launch_mode<MODE_MESH>(cap, g, S, A, st, e0, e1);
+    else launch_mode<MODE_SCENE>(cap, g, S, A, st, e0, e1);
 }
 
 // ---- reference work counters (untimed) ---------------------------------------------------------------------------
@@ -357,7 +364,7 @@ __device__ __forceinline__ bool path_pixel(const RayGenParams &g, long long pix,
 
 // Rays that miss the scene octree's root box are answered here (OSM:318-320: no cuboid collected -> return
 // false) and the others are appended, wave by wave, to a compact index list for the traversal kernel.
-__global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneView S, xrt_ray *rays, xrt_hit *hits, int *index, int *count, int P,
+__global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneView S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P,
                                                          long long pathBase) {
     __shared__ int ldsCounts[17];
     const f4 rlo = S.snodes[0], rhi = S.snodes[1];
@@ -395,11 +402,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
                     live = slab(w, rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, key);   // OSM:460 on the root
                 }
             }
-            if (index && !live) {
-                HitOut h;
-                h.hit = 0; h.object = -1; h.mesh = -1; h.tri = -1; h.leaf = -1; h.u = 0; h.v = 0; h.d = 0; h.wx = 0; h.wy = 0; h.wz = 0;
-                store_hit(hits + p, h);
-            }
+            if (index && !live) lvlB0[p] = f4{0, 0, 0, i2f(FLAG_MISS)};   // generation 0 ends here (RT:729-733)
         }
         if (index) {   // block-uniform
             const int slot = block_append(count, live, ldsCounts);
@@ -407,12 +410,12 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
         }
     }
 }
-void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, xrt_hit *hits, int *index, int *count, int P, long long pathBase,
+void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase,
                    hipStream_t st) {
     int blocks = (P + APPEND_BLOCK - 1) / APPEND_BLOCK;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(APPEND_BLOCK), 0, st, g, S, rays, hits, index, count, P, pathBase);
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(APPEND_BLOCK), 0, st, g, S, rays, lvlB0, index, count, P, pathBase);
 }
 
 // ---- shading ----------------------------------------------------------------------------------------------------------
@@ -454,19 +457,21 @@ __device__ __forceinline__ void light_dir(const LightRec &L, v3 world, v3 &dir, 
 // Stage A of CastRay for one generation of rays: misses terminate their path (RT:729-733); every hit
 // emits one shadow ray per light (RT:535-537 -> RT:482-485), compacted with one atomic per wave.
 __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_a(SceneView S, ShadeView V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev,
-                                                 int nHost, const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays,
+                                                 int nHost, const int *index, const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays,
                                                  int *shadowSrc, int *scnt, int P, int level) {
     __shared__ int ldsCounts[17];
     const int n = nDev ? *nDev : nHost;
     const int stride = (int)(gridDim.x * blockDim.x);
     const int rounds = (n + stride - 1) / stride;
     for (int it = 0; it < rounds; it++) {
-        const int i = it * stride + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        const int j = it * stride + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        int i = j;
         int hit = 0, object, mesh = 0, tri = 0;
         float u = 0, v = 0, d = 0;
         v3 w = mk(0, 0, 0);
         int p = 0;
-        if (i < n) {
+        if (j < n) {
+            if (index) i = index[j];   // generation 0: only the rays that reached the scene's root box were traced
             load_hit(hits + i, hit, object, mesh, tri, u, v, d, w);
             p = rayPath ? rayPath[i] : i;
             const int node = rayNode ? rayNode[i] : level;   // chain of reflections: node == generation; ray tree: heap index
@@ -484,10 +489,10 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_a(SceneView S, ShadeView
     }
 }
 void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
-                    const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level,
-                    hipStream_t st) {
-    hipLaunchKernelGGL(k_shade_a, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, rays, hits, nDev, nHost, rayPath, rayNode, lvlB, shadowRays, shadowSrc,
-                       scnt, P, level);
+                    const int *index, const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P,
+                    int level, hipStream_t st) {
+    hipLaunchKernelGGL(k_shade_a, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, rays, hits, nDev, nHost, index, rayPath, rayNode, lvlB, shadowRays,
+                       shadowSrc, scnt, P, level);
 }
 
 // MAT:71-160 LookupUV: address mode + point sample

@@ -95,6 +95,8 @@ struct xrt_scene {
     DevBuf<LightRec> lights;
     DevBuf<unsigned long long> counters;
     std::vector<hipEvent_t> events;
+    void *pinned = nullptr;      // host staging for the per-frame counter read-back
+    size_t pinnedBytes = 0;
     int firstBatch = 64;
     int tune[3] = {24, 64, 32};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
     std::atomic<bool> busy{false};
@@ -104,6 +106,7 @@ struct xrt_scene {
         if (device >= 0) {
             (void)hipSetDevice(device);
             for (auto e : events) (void)hipEventDestroy(e);
+            if (pinned) (void)hipHostFree(pinned);
             if (stream) (void)hipStreamDestroy(stream);
             blocks.release(); leafNB.release(); refN.release(); refG.release(); snodes.release(); shade.release();
             childDfs.release(); srefs.release(); objMesh.release(); meshes.release();
@@ -280,9 +283,10 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     HIPCHECK(hipEventRecord(e0, st));
     s->progress.store(0.0f);
     unsigned long long shaded = 0, closestDeep = 0, livePaths = 0;
+    unsigned long long hcntHost[2 * C_COUNT] = {0};
 
     // One pass = trace `total` paths produced by generator `gp`; after every chunk `post(Pc, pathBase)` consumes sampleColor.
-    auto run_pass = [&](const RayGenParams &gp, long long total, auto &&post, float progress0, float progress1) -> int {
+    auto run_pass = [&](const RayGenParams &gp, long long total, auto &&post, float progress0, float progress1, bool finalPass) -> int {
         const int nChunks = (int)((total + chunkPaths - 1) / chunkPaths);
         int rc2;
         if ((rc2 = s->cnts.ensure((size_t)nChunks * cntStride)) || (rc2 = s->queues.ensure((size_t)nChunks * qStride))) return rc2;
@@ -294,7 +298,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
             int *cnt = s->cnts.p + (size_t)c * cntStride, *scnt = cnt + (R + 2);
             unsigned *q = s->queues.p + (size_t)c * qStride;
             // cnt[0] counts the primary rays that reach the scene's root box; paths[1] doubles as their index list
-            launch_raygen(gp, S, rays[0], s->hits.p, paths[1], cnt, Pc, pathBase, st);
+            launch_raygen(gp, S, rays[0], s->lvlB.p, paths[1], cnt, Pc, pathBase, st);
             for (int k = 0; k <= R; k++) {
                 const int cur = k & 1, nxt = cur ^ 1;
                 IntersectArgs A;
@@ -304,15 +308,13 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
                 hipEvent_t a0 = get_event(s, ev), a1 = get_event(s, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 pairs.push_back({ev, ev + 1}); ev += 2;
-                HIPCHECK(hipEventRecord(a0, st));
-                launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st);
-                HIPCHECK(hipEventRecord(a1, st));
+                launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st, a0, a1);
                 if (opts->collect_stats) {   // the reference tests the root box for every ray: count over all of them
                     IntersectArgs Ac = A;
                     if (k == 0) { Ac.index = nullptr; Ac.nDev = nullptr; }
                     launch_count(S, Ac, s->counters.p, st);
                 }
-                launch_shade_a(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : cnt + k, Pc, k == 0 ? nullptr : paths[cur],
+                launch_shade_a(S, V, rays[cur], s->hits.p, cnt + k, Pc, k == 0 ? paths[1] : nullptr, k == 0 ? nullptr : paths[cur],
                                (heap && k > 0) ? nodesOf[cur] : nullptr, s->lvlB.p, s->shadowRays.p, s->shadowSrc.p, scnt + k, P, k, st);
                 if (nL > 0) {
                     IntersectArgs B;
@@ -322,9 +324,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
                     hipEvent_t b0 = get_event(s, ev), b1 = get_event(s, ev + 1);
                     if (!b0 || !b1) return fail(XRT_E_HIP, "hipEventCreate failed");
                     pairs.push_back({ev, ev + 1}); ev += 2;
-                    HIPCHECK(hipEventRecord(b0, st));
-                    launch_intersect(S, B, s->stackNeeded, persistent_grid(s, -1), st);
-                    HIPCHECK(hipEventRecord(b1, st));
+                    launch_intersect(S, B, s->stackNeeded, persistent_grid(s, -1), st, b0, b1);
                     if (opts->collect_stats) launch_count(S, B, s->counters.p + C_COUNT, st);
                 }
                 TreeArgs T;
@@ -342,10 +342,20 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
                 s->progress.store(progress0 + (progress1 - progress0) * (float)(c + 1) / (float)nChunks);
             }
         }
-        if (stats) {   // per-pass ray accounting (the counter block is reused by the next pass)
+        if (finalPass) HIPCHECK(hipEventRecord(e1, st));
+        if (stats) {   // per-pass ray accounting (the counter block is reused by the next pass): one pinned read-back, one sync
+            const size_t nb = (size_t)nChunks * cntStride * sizeof(int), nb2 = 2 * C_COUNT * sizeof(unsigned long long);
+            if (s->pinnedBytes < nb + nb2) {
+                if (s->pinned) (void)hipHostFree(s->pinned);
+                s->pinned = nullptr; s->pinnedBytes = 0;
+                HIPCHECK(hipHostMalloc(&s->pinned, nb + nb2 + 4096, hipHostMallocDefault));
+                s->pinnedBytes = nb + nb2 + 4096;
+            }
+            HIPCHECK(hipMemcpyAsync(s->pinned, s->cnts.p, nb, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipMemcpyAsync((char *)s->pinned + nb, s->counters.p, nb2, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
-            std::vector<int> hc((size_t)nChunks * cntStride);
-            HIPCHECK(hipMemcpy(hc.data(), s->cnts.p, hc.size() * sizeof(int), hipMemcpyDeviceToHost));
+            const int *hc = (const int *)s->pinned;
+            std::memcpy(hcntHost, (char *)s->pinned + nb, nb2);
             for (int c = 0; c < nChunks; c++)
                 for (int k = 0; k <= R; k++) {
                     shaded += (unsigned long long)hc[(size_t)c * cntStride + (R + 2) + k];
@@ -369,7 +379,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
         rc = run_pass(g, firstPaths, [&](int Pc, long long pathBase) -> int {
             launch_resolve(g, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, Pc / g.samples, pathBase / g.samples, d_out, d_outF32, st);
             return XRT_OK;
-        }, 0.0f, 1.0f);
+        }, 0.0f, 1.0f, true);
         if (rc != XRT_OK) return rc;
     } else {
         // RenderFirstPass / GetColorForQuadrant (RT:170-311): level 0 quadrants are the pixels (size 1); a level's
@@ -391,7 +401,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
             rc = run_pass(gl, L.n * 4, [&](int Pc, long long pathBase) -> int {
                 HIPCHECK(hipMemcpyAsync(L.color.p + pathBase, s->sampleColor.p, (size_t)Pc * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
                 return XRT_OK;
-            }, (float)l / (float)(quality + 1), (float)(l + 1) / (float)(quality + 1));
+            }, (float)l / (float)(quality + 1), (float)(l + 1) / (float)(quality + 1), false);
             if (rc != XRT_OK) break;
             if (l < quality) {   // RT:279-306
                 Level &N = lv[l + 1];
@@ -413,20 +423,21 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
             RayGenParams g0 = g;
             g0.quadLevel = 0; g0.quadSize = 1.0f;
             launch_resolve(g0, lv[0].color.p, nullptr, (int)totalPixels, 0, d_out, d_outF32, st);
-            hipError_t e = hipStreamSynchronize(st);
+            hipError_t e = hipEventRecord(e1, st);
+            if (e == hipSuccess && stats) e = hipMemcpyAsync(hcntHost, s->counters.p, sizeof(hcntHost), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) rc = fail(XRT_E_HIP, "adaptive resolve: %s", hipGetErrorString(e));
         }
         free_levels();
         if (rc != XRT_OK) return rc;
     }
-    HIPCHECK(hipEventRecord(e1, st));
     HIPCHECK(hipStreamSynchronize(st));
     HIPCHECK(hipGetLastError());
     s->progress.store(1.0f);
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         unsigned long long hcnt[2 * C_COUNT];
-        HIPCHECK(hipMemcpy(hcnt, s->counters.p, sizeof(hcnt), hipMemcpyDeviceToHost));
+        std::memcpy(hcnt, hcntHost, sizeof(hcnt));
         if (!opts->collect_stats) {
             std::memset(hcnt, 0, sizeof(hcnt));
             hcnt[C_RAYS] = livePaths + closestDeep;
@@ -464,11 +475,9 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
         a0 = get_event(s, 0); a1 = get_event(s, 1);
         if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
         HIPCHECK(hipMemsetAsync(s->counters.p, 0, 2 * C_COUNT * sizeof(unsigned long long), st));
-        HIPCHECK(hipEventRecord(a0, st));
     }
-    if (n > 0) launch_intersect(s->view, A, s->stackNeeded, persistent_grid(s, n), st);
+    if (n > 0) launch_intersect(s->view, A, s->stackNeeded, persistent_grid(s, n), st, a0, a1);
     if (stats) {
-        HIPCHECK(hipEventRecord(a1, st));
         if (n > 0) launch_count(s->view, A, s->counters.p, st);
     }
     HIPCHECK(hipGetLastError());
@@ -479,7 +488,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
         HIPCHECK(hipMemcpy(hcnt, s->counters.p, sizeof(hcnt), hipMemcpyDeviceToHost));
         fill_stats(stats, hcnt, 0, 0);
         float ms = 0;
-        HIPCHECK(hipEventElapsedTime(&ms, a0, a1));
+        if (n > 0) HIPCHECK(hipEventElapsedTime(&ms, a0, a1));
         stats->ms_total = ms; stats->ms_intersect = ms; stats->intersect_launches = n > 0 ? 1 : 0;
     }
     return XRT_OK;
