@@ -46,33 +46,42 @@ def intersect_bytes(st):
     return st["algorithmic_bytes"] - 80 * st["shaded_hits"] - 4 * st["pixels"]
 
 
-def time_frames(tracer, out, steps, warmup, rank, world, width, height, gathered_out):
-    """W warm-up frames, then K timed frames bracketed by barrier + synchronize on both sides."""
-    render = tracer.PrepareDevice(out.data_ptr(), shard_rank=rank, shard_count=world)   # camera / lights marshalled once, as the C# host would
+def time_frames(tracer, outs, steps, warmup, rank, world, width, height, gathered_out):
+    """W warm-up frames, then K timed frames bracketed by barrier + synchronize on both sides.
+    N > 1: the gather of frame i (RCCL, its own stream) overlaps the rendering of frame i+1 (double-buffered tile
+    buffers); every frame is gathered and de-tiled before the closing barrier."""
+    renders = [tracer.PrepareDevice(o.data_ptr(), shard_rank=rank, shard_count=world) for o in outs]   # camera / lights marshalled once
+    nccl = world > 1 and dist.get_backend() == "nccl"
+    recv = [torch.empty(world * outs[0].numel(), dtype=outs[0].dtype, device="cuda" if nccl else "cpu") for _ in outs] if (world > 1 and rank == 0) else [None, None]
+    pending = []
 
-    def frame():
-        st = render()
-        if world > 1:
-            if dist.get_backend() == "nccl":
-                g = xrt.dist.gather_frame(out, width, height)      # the path's exchange step (RCCL gather over xGMI)
-            else:                                                  # gloo rehearsal on a box with fewer GPUs than ranks
-                g = xrt.dist.gather_frame(out.cpu(), width, height)
-                g = g.cuda() if g is not None else None
+    def finish():
+        while pending:
+            g = pending.pop(0)()
             if rank == 0:
-                xrt.dist.detile_device(g, width, height, world, gathered_out)
+                xrt.dist.detile_device(g if nccl else g.cuda(), width, height, world, gathered_out)
+
+    def frame(i):
+        st = renders[i % 2]()                      # blocking: this rank's tiles of frame i are in HBM
+        if world > 1:
+            finish()                               # frame i-1's gather ran while frame i was rendered
+            src = outs[i % 2] if nccl else outs[i % 2].cpu()   # gloo: rehearsal on a box with fewer GPUs than ranks
+            pending.append(xrt.dist.gather_frame_async(src, recv=recv[i % 2]))   # the path's exchange step (RCCL gather over xGMI)
         return st
-    for _ in range(warmup):
-        frame()
+    for i in range(warmup):
+        frame(i)
+    finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ms_intersect, launches = 0.0, 0
-    for _ in range(steps):
-        st = frame()
+    for i in range(steps):
+        st = frame(i)
         ms_intersect += st["ms_intersect"]
         launches += st["intersect_launches"]
+    finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -89,13 +98,13 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
     W, H = spec.width, spec.height
     tx, ty, tpr = xrt.dist.shard_layout(W, H, world)
     n_out = tpr * 512 if world > 1 else W * H
-    out = torch.zeros(n_out, dtype=torch.int32, device="cuda")
+    outs = [torch.zeros(n_out, dtype=torch.int32, device="cuda") for _ in range(2 if world > 1 else 1)] * (1 if world > 1 else 2)
     final = torch.zeros(W * H, dtype=torch.int32, device="cuda") if (world > 1 and rank == 0) else None
     # untimed: exact reference-work counters of this rank's shard (algorithmic bytes, ray counts)
     tracer.collect_stats = with_stats
-    st0 = tracer.RenderDevice(out.data_ptr(), shard_rank=rank, shard_count=world)
+    st0 = tracer.RenderDevice(outs[0].data_ptr(), shard_rank=rank, shard_count=world)
     tracer.collect_stats = False
-    dt, ms_int, launches = time_frames(tracer, out, steps, warmup, rank, world, W, H, final)
+    dt, ms_int, launches = time_frames(tracer, outs, steps, warmup, rank, world, W, H, final)
     rays = st0["rays_closest"] + st0["rays_shadow"]
     res = dict(rays=rays, seconds=dt, ms_intersect=ms_int, launches=launches, stats=st0, build_s=build_s, width=W, height=H,
                tris=sum(m[0].ntri for m in spec.meshes), instances=len(spec.objects))
@@ -189,7 +198,7 @@ def main():
         ms_per_launch = res["ms_intersect"] / launches
         achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
         line = {
-            "metric": "Mrays/sec (primary+shadow+reflection queries), 1920x1080" if args.scale == 1.0 else "Mrays/sec (scaled image, not a benchmark)",
+            "metric": ("Mrays/sec (primary+shadow+reflection queries), %dx%d" % (res["width"], res["height"])) if args.scale == 1.0 else "Mrays/sec (scaled image, not a benchmark)",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(seconds / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

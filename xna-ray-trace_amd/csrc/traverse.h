@@ -46,6 +46,7 @@ struct Lane {
     int state;
     // scene cursor
     int sblk, smask, ssp;
+    int wmask;           // sign mask of the world direction (for the pre-cull box test)
     int sRef, sRefEnd;
     float sKey;
     int obj, mPtr, mEnd;
@@ -156,6 +157,7 @@ XRT_HD void lane_begin(Lane &L, const SceneView &S, v3 o, v3 d, int ignoreMesh, 
     L.spec = (L.ignoreId < 0) ? 1 : 0;   // rays leaving a surface (RT:485, RT:559) start among back faces
     if (mode == MODE_SCENE) {
         L.w = make_ray(o, d);
+        L.wmask = dir_mask(d);
         L.sblk = 0; L.smask = 1;   // root = slot 0 of block 0
         L.state = ST_SCENE;
     } else if (mode == MODE_SINGLE) {
@@ -200,10 +202,16 @@ XRT_HD void advance_scene(Lane &L, const SceneView &S, Stack &stk) {
             begin_mesh_query(L, S, m);
         return;
     }
-    if (L.sRef < L.sRefEnd) {   // OSM:341-364: next body of the current leaf, world -> object space
+    while (L.sRef < L.sRefEnd) {   // OSM:341-364: next body of the current leaf, world -> object space
         int o = S.srefs[L.sRef++];
-        L.obj = o;
         const ObjRec &ob = S.objects[o];
+        if (ob.cullOk && !L.weird) {   // conservative world-space reject (xrt_core.h ObjRec): the visit would end at MESH:34-39 for every mesh
+            float kc;
+            const v3 cmn = mk(ob.cullMin[0], ob.cullMin[1], ob.cullMin[2]), cmx = mk(ob.cullMax[0], ob.cullMax[1], ob.cullMax[2]);
+            const bool hitBox = (L.w.par == 0) ? slab_fast(L.w, L.wmask, cmn, cmx, kc) : slab(L.w, cmn.x, cmn.y, cmn.z, cmx.x, cmx.y, cmx.z, kc);
+            if (!hitBox) continue;
+        }
+        L.obj = o;
         v3 rayDirPosition = add(L.w.o, L.w.d);                 // OSM:358
         v3 v1 = transform(L.w.o, ob.invWorld);                  // OSM:360
         v3 v2 = transform(rayDirPosition, ob.invWorld);         // OSM:361

@@ -74,12 +74,15 @@ struct MeshRec {        // 80 B = five f4
     int   dfsBase;      // offset of this mesh's entries in childDfs (= rootBlock * 8 for interior roots)
 };
 
-struct ObjRec {         // 144 B
+struct ObjRec {         // 176 B
     float invWorld[16]; // SO:198
     float world[16];    // SO:193
     int   meshStart;    // into objMesh[]
     int   meshCount;
-    int   pad0, pad1;
+    int   cullOk;       // cullMin/cullMax are valid (well-conditioned, finite transform)
+    int   pad0;
+    float cullMin[4];   // world-space box that contains the image of every mesh AABB of the object, enlarged by 1e-3 of
+    float cullMax[4];   // its size: a world ray that misses it cannot pass MESH:34-39 for any mesh
 };
 
 struct MaterialRec {    // 32 B (MAT:234-268)

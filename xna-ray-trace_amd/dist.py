@@ -60,12 +60,27 @@ def detile_host(gathered, width, height, world):
 def gather_frame(local, width, height, group=None, dst=0):
     """torch.distributed.gather of the per-rank tile buffers (int32 tensors, CPU/gloo or GPU/RCCL).
     Returns the rank-major gathered tensor on `dst`, None elsewhere."""
+    return gather_frame_async(local, group, dst)()
+
+
+def gather_frame_async(local, group=None, dst=0, recv=None):
+    """Start the gather and return a function that waits for it and yields the rank-major tensor on `dst`
+    (None elsewhere).  `recv` (dst only): a preallocated (world * len(local)) tensor whose row views receive
+    the shards directly, so no concatenation copy is needed."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
-    dist.gather(local, bufs, dst=dst, group=group)
-    return torch.cat(bufs) if rank == dst else None
+    bufs = None
+    if rank == dst:
+        if recv is None:
+            recv = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+        bufs = list(recv.view(world, -1).unbind(0))
+    work = dist.gather(local, bufs, dst=dst, group=group, async_op=True)
+
+    def wait():
+        work.wait()
+        return recv if rank == dst else None
+    return wait
 
 
 def detile_device(gathered, width, height, world, out, stream=None):
