@@ -197,6 +197,12 @@ def main():
         bytes_per_launch = intersect_bytes(st) * args.steps / launches
         ms_per_launch = res["ms_intersect"] / launches
         achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+        traffic = None   # HBM bytes per k_intersect launch from the committed PMC run of this command (profiles/)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final", "pmc_hbm_traffic.json")))
+            traffic = pmc.get(args.config, {}).get("traffic_bytes_per_launch") if world == 1 else None
+        except Exception:
+            traffic = None
         line = {
             "metric": ("Mrays/sec (primary+shadow+reflection queries), %dx%d" % (res["width"], res["height"])) if args.scale == 1.0 else "Mrays/sec (scaled image, not a benchmark)",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -206,10 +212,10 @@ def main():
                        "instances": res["instances"], "rays_per_frame": int(rays_frame), "parallelism": "image tiles 64x8 round-robin x%d" % world,
                        "scene_build_s": round(res["build_s"], 3)},
             "roofline": {"bound": "hbm", "kernel": "k_intersect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "ms_per_launch": round(ms_per_launch, 5),
                          "launches_per_frame": launches // max(args.steps, 1),
-                         "note": "numerator = the REFERENCE algorithm's bytes (SURVEY 8d); every fixture fits the 256 MiB Infinity Cache"},
+                         "note": "achieved = the REFERENCE algorithm's bytes (SURVEY 8d) / measured launch time; traffic = measured HBM bytes per launch (rocprofv3 2*FETCH_SIZE+WRITE_SIZE, profiles/r01_final/pmc_hbm_traffic.json): the scene fits the 256 MiB Infinity Cache and the GPU prunes, so traffic << achieved bytes"},
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(spec)
