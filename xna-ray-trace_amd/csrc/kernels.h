@@ -76,7 +76,16 @@ void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays,
                     int *nextPath, int *nextCnt, int P, int level, int maxReflections, const TreeArgs &T, hipStream_t st);
 void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections, uint32_t *sampleColor,
                          float *sampleF32, hipStream_t st);
-void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P /* level stride */, int maxReflections, uint32_t *sampleColor, float *sampleF32, hipStream_t st);
+// compose can write the framebuffer itself when there is one sample per pixel
+struct ResolveArgs {
+    int fused;
+    RayGenParams g;
+    long long pixelBase;
+    uint32_t *out;
+    float *outF32;
+};
+void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P /* level stride */, int maxReflections, uint32_t *sampleColor, float *sampleF32,
+                    const ResolveArgs &RA, hipStream_t st);
 void launch_resolve(const RayGenParams &g, const uint32_t *sampleColor, const float *sampleF32, int pixels, long long pixelBase,
                     uint32_t *out, float *outF32, hipStream_t st);
 void launch_ms_decide(const RayGenParams &g, const uint32_t *quadColor, const int *nQuadsDev, int nQuadsHost, long long pixelBase, int *childBase,

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_count(SceneView S, IntersectArgs A, uns
     LocalStack stk, stk2;
     for (int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x); idx < n; idx += (int)(gridDim.x * blockDim.x)) {
         v3 o, d; int im, it;
-        load_ray(A.rays + idx, o, d, im, it);
+        load_ray(A.rays + (A.index ? A.index[idx] : idx), o, d, im, it);
         if (im == DEAD_RAY) continue;
         c[C_RAYS]++;
         Lane L;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
             int x = 0, y = 0;
             const bool listed = g.quadLevel > 0;   // quadrant centres come from a list, every entry is valid
             if (!listed && !path_pixel(g, gp / g.samples, x, y)) {
-                store_ray(rays + p, mk(0, 0, 0), mk(0, 0, 0), DEAD_RAY, -1);
+                if (!index) store_ray(rays + p, mk(0, 0, 0), mk(0, 0, 0), DEAD_RAY, -1);
             } else {
                 float sx = (float)x, sy = (float)y;
                 if (g.quadLevel >= 0) {   // RT:218-276: four rays at centre -+ size/4, order UL, UR, LL, LR
@@ -395,12 +395,12 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
                 v3 nearP = unproject(g, sx, sy, 0.0f);   // RT:415
                 v3 farP = unproject(g, sx, sy, 1.0f);    // RT:419
                 v3 dir = normalize(sub(farP, nearP));    // RT:420-421
-                store_ray(rays + p, nearP, dir, -1, -1);
                 if (index) {
                     RayPre w = make_ray(nearP, dir);
                     float key;
                     live = slab(w, rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, key);   // OSM:460 on the root
                 }
+                if (live || !index) store_ray(rays + p, nearP, dir, -1, -1);   // a culled ray is never read again
             }
             if (index && !live) lvlB0[p] = f4{0, 0, 0, i2f(FLAG_MISS)};   // generation 0 ends here (RT:729-733)
         }
@@ -643,7 +643,8 @@ void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays,
 }
 
 // The return path of the CastRay recursion: deepest generation first, one RGBA8 quantisation per level.
-__global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32) {
+__global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32,
+                                                 ResolveArgs RA) {
     for (int p = (int)(blockIdx.x * blockDim.x + threadIdx.x); p < count; p += (int)(gridDim.x * blockDim.x)) {
         int kd = 0;
         int flag;
@@ -664,6 +665,18 @@ __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB,
             f4 a = lvlA[(size_t)k * P + p], b = lvlB[(size_t)k * P + p];
             cv = mul(lerp(unpack_color(col), mk(b.x, b.y, b.z), 1.0f - a.w), mk(a.x, a.y, a.z));
             col = pack_color(cv);
+        }
+        if (RA.fused) {   // one sample per pixel: write the framebuffer directly (RT:425), no sample buffer round trip
+            long long pix = RA.pixelBase + p;
+            int x, y;
+            bool ok = path_pixel(RA.g, pix, x, y);
+            if (RA.g.shardCount > 1) RA.out[pix] = ok ? col : 0u;
+            else if (ok) {
+                size_t o = (size_t)y * RA.g.width + x;
+                RA.out[o] = col;
+                if (RA.outF32) { RA.outF32[3 * o] = cv.x; RA.outF32[3 * o + 1] = cv.y; RA.outF32[3 * o + 2] = cv.z; }
+            }
+            continue;
         }
         sampleColor[p] = col;
         if (sampleF32) { sampleF32[3 * (size_t)p] = cv.x; sampleF32[3 * (size_t)p + 1] = cv.y; sampleF32[3 * (size_t)p + 2] = cv.z; }
@@ -728,10 +741,11 @@ void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, 
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_compose_tree, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, lvlA, lvlB, lvlAlpha, count, P, maxReflections, sampleColor, sampleF32);
 }
-void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32, hipStream_t st) {
+void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32,
+                    const ResolveArgs &RA, hipStream_t st) {
     int blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_compose, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, lvlA, lvlB, count, P, maxReflections, sampleColor, sampleF32);
+    hipLaunchKernelGGL(k_compose, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, lvlA, lvlB, count, P, maxReflections, sampleColor, sampleF32, RA);
 }
 
 // Supersample averaging (RT:309: mean of four quantised colours, re-quantised, twice for 16 samples) and the

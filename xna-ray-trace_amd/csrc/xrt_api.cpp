@@ -248,6 +248,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     const size_t rayCap = heap ? ((size_t)P << R) : (size_t)P;
     const size_t nodes = heap ? (((size_t)1 << (R + 1)) - 1) : (size_t)(R + 1);
     const bool wantF32 = d_outF32 != nullptr && !adaptive && g.samples == 1;
+    const bool fuseResolve = !adaptive && !heap && g.samples == 1;   // k_compose writes the framebuffer itself
     // buffers
     if ((rc = s->rays0.ensure(rayCap)) || (rc = s->rays1.ensure(rayCap)) || (rc = s->hits.ensure(rayCap)) || (rc = s->path0.ensure(rayCap)) ||
         (rc = s->path1.ensure(rayCap)) || (rc = s->shadowSrc.ensure(rayCap)) || (rc = s->shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
@@ -282,21 +283,23 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     if (!e0 || !e1) return fail(XRT_E_HIP, "hipEventCreate failed");
     HIPCHECK(hipEventRecord(e0, st));
     s->progress.store(0.0f);
-    unsigned long long shaded = 0, closestDeep = 0, livePaths = 0;
+    unsigned long long shaded = 0, closestDeep = 0, livePaths = 0, live0 = 0;
     unsigned long long hcntHost[2 * C_COUNT] = {0};
 
     // One pass = trace `total` paths produced by generator `gp`; after every chunk `post(Pc, pathBase)` consumes sampleColor.
     auto run_pass = [&](const RayGenParams &gp, long long total, auto &&post, float progress0, float progress1, bool finalPass) -> int {
         const int nChunks = (int)((total + chunkPaths - 1) / chunkPaths);
         int rc2;
-        if ((rc2 = s->cnts.ensure((size_t)nChunks * cntStride)) || (rc2 = s->queues.ensure((size_t)nChunks * qStride))) return rc2;
-        HIPCHECK(hipMemsetAsync(s->cnts.p, 0, (size_t)nChunks * cntStride * sizeof(int), st));
-        HIPCHECK(hipMemsetAsync(s->queues.p, 0, (size_t)nChunks * qStride * sizeof(unsigned), st));
+        // ray counts and queue heads of all chunks live in one allocation: one memset per pass
+        const size_t cntWords = (size_t)nChunks * cntStride, qWords = (size_t)nChunks * qStride;
+        if ((rc2 = s->cnts.ensure(cntWords + qWords))) return rc2;
+        unsigned *queuesBase = reinterpret_cast<unsigned *>(s->cnts.p + cntWords);
+        HIPCHECK(hipMemsetAsync(s->cnts.p, 0, (cntWords + qWords) * sizeof(int), st));
         for (int c = 0; c < nChunks; c++) {
             const long long pathBase = (long long)c * chunkPaths;
             const int Pc = (int)((total - pathBase) < chunkPaths ? (total - pathBase) : chunkPaths);
             int *cnt = s->cnts.p + (size_t)c * cntStride, *scnt = cnt + (R + 2);
-            unsigned *q = s->queues.p + (size_t)c * qStride;
+            unsigned *q = queuesBase + (size_t)c * qStride;
             // cnt[0] counts the primary rays that reach the scene's root box; paths[1] doubles as their index list
             launch_raygen(gp, S, rays[0], s->lvlB.p, paths[1], cnt, Pc, pathBase, st);
             for (int k = 0; k <= R; k++) {
@@ -309,11 +312,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 pairs.push_back({ev, ev + 1}); ev += 2;
                 launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st, a0, a1);
-                if (opts->collect_stats) {   // the reference tests the root box for every ray: count over all of them
-                    IntersectArgs Ac = A;
-                    if (k == 0) { Ac.index = nullptr; Ac.nDev = nullptr; }
-                    launch_count(S, Ac, s->counters.p, st);
-                }
+                if (opts->collect_stats) launch_count(S, A, s->counters.p, st);   // generation 0: the live list; culled rays are added below
                 launch_shade_a(S, V, rays[cur], s->hits.p, cnt + k, Pc, k == 0 ? paths[1] : nullptr, k == 0 ? nullptr : paths[cur],
                                (heap && k > 0) ? nodesOf[cur] : nullptr, s->lvlB.p, s->shadowRays.p, s->shadowSrc.p, scnt + k, P, k, st);
                 if (nL > 0) {
@@ -335,8 +334,12 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
                                s->lvlB.p, rays[nxt], paths[nxt], cnt + k + 1, P, k, R, T, st);
             }
             if (heap) launch_compose_tree(s->lvlA.p, s->lvlB.p, s->lvlAlpha.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
-            else launch_compose(s->lvlA.p, s->lvlB.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
-            if ((rc2 = post(Pc, pathBase))) return rc2;
+            else {
+                ResolveArgs RA;
+                RA.fused = fuseResolve ? 1 : 0; RA.g = gp; RA.pixelBase = pathBase; RA.out = d_out; RA.outF32 = d_outF32;
+                launch_compose(s->lvlA.p, s->lvlB.p, Pc, P, R, s->sampleColor.p, (wantF32 && !fuseResolve) ? s->sampleF32.p : nullptr, RA, st);
+            }
+            if (!(fuseResolve && !heap) && (rc2 = post(Pc, pathBase))) return rc2;
             if (nChunks > 1) {
                 HIPCHECK(hipStreamSynchronize(st));
                 s->progress.store(progress0 + (progress1 - progress0) * (float)(c + 1) / (float)nChunks);
@@ -360,6 +363,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
                 for (int k = 0; k <= R; k++) {
                     shaded += (unsigned long long)hc[(size_t)c * cntStride + (R + 2) + k];
                     if (k > 0) closestDeep += (unsigned long long)hc[(size_t)c * cntStride + k];
+                    else live0 += (unsigned long long)hc[(size_t)c * cntStride];
                 }
         }
         return XRT_OK;
@@ -438,7 +442,12 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
         std::memset(stats, 0, sizeof(*stats));
         unsigned long long hcnt[2 * C_COUNT];
         std::memcpy(hcnt, hcntHost, sizeof(hcnt));
-        if (!opts->collect_stats) {
+        if (opts->collect_stats) {
+            // primary rays answered by k_raygen (they miss the scene root box): one query and one OSM:460 test each
+            const unsigned long long culled = livePaths - live0;
+            hcnt[C_RAYS] += culled;
+            hcnt[C_SCENE_NODES] += culled;
+        } else {
             std::memset(hcnt, 0, sizeof(hcnt));
             hcnt[C_RAYS] = livePaths + closestDeep;
             hcnt[C_HITS] = shaded;
