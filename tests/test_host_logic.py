@@ -187,3 +187,63 @@ def test_degenerate_rays(xrt, orc, emul):
     rays = xrt.rays_array([(0, 50, 0), (0, 50, 0), (0, 50, 0), (1e30, 0, 0), (0, 50, 0), (0, 4.0, 0)],
                           [(0, 0, 0), (nan, -1, 0), (0, -1, 0), (-1, 0, 0), (1e-7, -1, 1e-7), (0, 1, 0)])
     assert hits_equal(o.intersect(rays), e.intersect(rays)) == {}
+
+
+def test_conservative_skips_under_grazing_rays(xrt, orc, emul):
+    """The two work-avoiding tests (world-space object pre-cull, all-back-facing leaf skip) must never change an
+    answer: random rotations / non-uniform scales, rays aimed at the corners and edges of the objects' boxes
+    (the pre-cull margin) and rays almost tangent to a smooth surface (N.D near zero, the leaf-skip margin)."""
+    rng = np.random.default_rng(17)
+    s = xrt.configs.SceneSpec("graze")
+    s.meshes.append((xrt.fixtures.crate(2), xrt.configs.material(0.5)))
+    s.meshes.append((xrt.fixtures.heightfield(40), xrt.configs.material(0.3)))
+    pos = []
+    for k in range(24):
+        p = tuple(float(x) for x in rng.uniform(-150, 150, size=3))
+        rot = tuple(float(x) for x in rng.uniform(-3.1, 3.1, size=3))
+        sc = tuple(float(x) for x in rng.uniform(0.3, 3.0, size=3))
+        s.objects.append(([k % 2], p, rot, sc))
+        pos.append(p)
+    s.camera = xrt.configs.camera((0, 200, 400), (0, 0, 0))
+    s.lights = [xrt.configs.spot((0, 300, 300))]
+    s = s.with_size(64, 36)
+    o, e = orc.OracleScene(s), emul.EmulScene(s)
+    # rays from far away through points jittered around each object's world-space box corners
+    origins, dirs = [], []
+    for k, (ids, p, rot, sc) in enumerate(s.objects):
+        bb = s.meshes[ids[0]][0].bbox
+        world, inv, wbb = xrt.xna.build_world(sc, rot, p, bb)
+        W = xrt.xna.as_array(world).reshape(4, 4).astype(np.float64)
+        for c in range(8):
+            corner = np.array([bb[3 if c & 1 else 0], bb[4 if c & 2 else 1], bb[5 if c & 4 else 2], 1.0])
+            wc = corner @ W
+            for j in range(12):
+                tgt = wc[:3] + rng.normal(scale=10.0 ** rng.uniform(-6, 0), size=3)
+                org = rng.normal(size=3)
+                org = org / np.linalg.norm(org) * 900.0
+                d = tgt - org
+                origins.append(org)
+                dirs.append(d / np.linalg.norm(d))
+    rays = xrt.rays_array(np.array(origins, dtype=np.float32), np.array(dirs, dtype=np.float32))
+    ho = o.intersect(rays)
+    assert hits_equal(ho, e.intersect(rays)) == {}
+    # near-tangent rays leaving the smooth surface: directions within 1e-6 .. 1e-1 of the tangent plane
+    hf = s.meshes[1][0]
+    m = (ho["hit"] == 1) & (ho["mesh"] == 1)
+    if m.sum() < 50:
+        prim = o.primary_rays()
+        hp = o.intersect(prim)
+        m2 = (hp["hit"] == 1) & (hp["mesh"] == 1)
+        P, T, Mh = hp["w"][m2], hp["tri"][m2], hp["mesh"][m2]
+    else:
+        P, T, Mh = ho["w"][m], ho["tri"][m], ho["mesh"][m]
+    if len(P):
+        N = hf.surface_normal[T].astype(np.float64)
+        t = rng.normal(size=N.shape)
+        t -= (t * N).sum(axis=1, keepdims=True) * N
+        t /= np.linalg.norm(t, axis=1, keepdims=True)
+        eps = (10.0 ** rng.uniform(-7, -1, size=(len(P), 1))) * rng.choice([-1.0, 1.0], size=(len(P), 1))
+        d = t + eps * N
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        sec = xrt.rays_array(P, d.astype(np.float32), Mh, T)
+        assert hits_equal(o.intersect(sec), e.intersect(sec)) == {}
