@@ -77,7 +77,7 @@ __device__ __forceinline__ int block_append(int *counter, bool flag, int *ldsCou
 constexpr int RAY_BATCH_MAX = 512; // largest guided batch a wave takes per queue atomic
 
 template <int T, int M>
-__global__ __launch_bounds__(256) void k_intersect(SceneView S, IntersectArgs A) {
+__global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs A) {
     __shared__ unsigned stk[4 * T * 64];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     LdsStack st{&stk[wave * T * 64 + lane]};
