@@ -281,6 +281,20 @@ def test_texture_address_modes_and_filters(xrt, orc, address, filtering):
     assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
 
 
+def test_default_game_scene(xrt, orc):
+    """G1: the reference's own default workload (Game1.cs:98-138: 4 Transparent spheres of Sphere.fbx, interpolated
+    normals, MaxReflections 8 -> a 511-node ray tree per pixel), at reduced resolution against the oracle."""
+    spec = xrt.configs.default_game_scene(96, 96, 8)
+    scene, tracer = xrt.configs.build_product(spec)
+    tracer.collect_stats = True
+    rgba, rgbf = tracer.Render(want_float=True)
+    o_rgba, o_rgbf, o_st = orc.OracleScene(spec).render(nthreads=8)
+    assert o_st["rays_closest"] > 96 * 96 + 2 * o_st["shaded_hits"] * 0.4   # the ray tree branches
+    assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+    for k in ("rays_closest", "rays_shadow", "shaded_hits", "algorithmic_bytes"):
+        assert tracer.last_stats[k] == o_st[k], (k, tracer.last_stats[k], o_st[k])
+
+
 def test_error_conventions_on_gpu(xrt):
     spec = xrt.configs.config("C1")
     scene, tracer = xrt.configs.build_product(spec)

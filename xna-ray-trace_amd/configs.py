@@ -97,6 +97,25 @@ def heightfield_scene(width, height, m=707, max_reflections=2, multisampling=abi
     return s.with_size(width, height)
 
 
+def default_game_scene(width=512, height=512, max_reflections=8):
+    """G1: the scene Game1.LoadContent builds and the Stopwatch of the reference would time (Game1.cs:44-45, 98-138;
+    BASELINE.md): 2x2 Transparent spheres from Sphere.fbx (960 triangles, Scale 2, DiffuseColor 255,0,0,100,
+    RefractionIndex 1.32, Reflectiveness 0.7, interpolated normals — contentproj:87-96, TMP:30) sharing one Mesh,
+    camera (0,16,32) -> origin, one spot light at (0,5,20), 512x512, MaxReflections 8."""
+    import os
+    s = SceneSpec("game1_default")
+    z = np.load(os.path.join(fixtures._GOLDEN, "sphere_mesh.npz"))
+    sphere = fixtures.MeshData(z["v"], z["n"], z["uv"], z["color"])
+    s.meshes.append((sphere, material(0.7, transparent=True, refraction_index=float(f32(1.32)), interpolate_normals=True)))
+    for x in range(2):
+        for y in range(2):
+            s.objects.append(([0], (-7.5 + 5 * x, 2.0, -7.5 + 5 * y), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    s.camera = camera((0, 16, 32), (0, 0, 0))
+    s.lights = [spot((0, 5, 20))]
+    s.max_reflections = max_reflections
+    return s.with_size(width, height)
+
+
 def config(name, scale=1.0):
     """BASELINE.json configs by id.  `scale` shrinks the image (parity tests at oracle-friendly sizes)."""
     def sz(w, h):
@@ -115,6 +134,8 @@ def config(name, scale=1.0):
         return heightfield_scene(*sz(1920, 1080), m=707)
     if name == "H100k":
         return heightfield_scene(*sz(1920, 1080), m=224)
+    if name == "G1":
+        return default_game_scene(*sz(512, 512))
     raise KeyError(name)
 
 

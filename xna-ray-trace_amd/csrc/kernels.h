@@ -25,6 +25,7 @@ struct IntersectArgs {
     const int *nDev;    // when non-null the ray count is (*nDev) * nMul, else n
     int nMul;
     int n;
+    int nCap;           // upper bound of the ray count (buffer capacity); 0 = none
     unsigned *queue;    // zeroed work-queue head of this launch
     int mode, meshId;
     int firstBatch;     // rays of the static first batch of every wave
@@ -40,6 +41,8 @@ constexpr int FLAG_MISS = 0, FLAG_HIT = 1, FLAG_TRANSPARENT = 2;
 // index of the medium each ray travels in.  heap == 0: plain reflection chain, node == generation.
 struct TreeArgs {
     int heap;
+    int cap;         // capacity of the next generation's ray buffers
+    int *overflow;   // set when a generation does not fit (the host retries the chunk with fewer paths)
     const int *rayNode;
     const float *rayRef;
     int *nextNode;
@@ -70,7 +73,7 @@ void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long
 void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase, hipStream_t st);
 void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
                     const int *index, const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level,
-                    hipStream_t st);
+                    int cap, int *overflow, hipStream_t st);
 void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath,
                     const int *scnt, const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB, xrt_ray *nextRays,
                     int *nextPath, int *nextCnt, int P, int level, int maxReflections, const TreeArgs &T, hipStream_t st);

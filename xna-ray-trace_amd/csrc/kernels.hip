@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
     __shared__ unsigned stk[4 * T * 64];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     LdsStack st{&stk[wave * T * 64 + lane]};
-    const int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
+    int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
+    if (A.nCap > 0 && n > A.nCap) n = A.nCap;   // an overflowed generation is discarded by the host; stay inside the buffers
     Lane L;
     L.state = ST_IDLE;
     // Work distribution.  The first 64 rays of every wave are static (no atomic: a grid-wide burst on one word
@@ -269,7 +270,8 @@ __device__ void run_query(Lane &L, const SceneView &S, LocalStack &stk, int mode
 }
 
 __global__ __launch_bounds__(256) void k_count(SceneView S, IntersectArgs A, unsigned long long *counters) {
-    const int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
+    int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
+    if (A.nCap > 0 && n > A.nCap) n = A.nCap;
     unsigned long long c[C_COUNT];
     for (int i = 0; i < C_COUNT; i++) c[i] = 0;
     LocalStack stk, stk2;
@@ -458,9 +460,10 @@ __device__ __forceinline__ void light_dir(const LightRec &L, v3 world, v3 &dir, 
 // emits one shadow ray per light (RT:535-537 -> RT:482-485), compacted with one atomic per wave.
 __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_a(SceneView S, ShadeView V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev,
                                                  int nHost, const int *index, const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays,
-                                                 int *shadowSrc, int *scnt, int P, int level) {
+                                                 int *shadowSrc, int *scnt, int P, int level, int cap, int *overflow) {
     __shared__ int ldsCounts[17];
-    const int n = nDev ? *nDev : nHost;
+    int n = nDev ? *nDev : nHost;
+    if (n > cap) n = cap;
     const int stride = (int)(gridDim.x * blockDim.x);
     const int rounds = (n + stride - 1) / stride;
     for (int it = 0; it < rounds; it++) {
@@ -478,6 +481,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_a(SceneView S, ShadeView
             if (!hit) lvlB[(size_t)node * P + p] = f4{0, 0, 0, i2f(FLAG_MISS)};
         }
         const int slot = block_append(scnt, hit != 0, ldsCounts);
+        if (hit && slot >= cap) { *overflow = 1; hit = 0; }   // more rays than the chunk's buffers hold: the host retries with fewer paths
         if (hit) {
             shadowSrc[slot] = i;
             for (int l = 0; l < V.nLights; l++) {
@@ -490,9 +494,9 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_a(SceneView S, ShadeView
 }
 void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
                     const int *index, const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P,
-                    int level, hipStream_t st) {
+                    int level, int cap, int *overflow, hipStream_t st) {
     hipLaunchKernelGGL(k_shade_a, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, rays, hits, nDev, nHost, index, rayPath, rayNode, lvlB, shadowRays,
-                       shadowSrc, scnt, P, level);
+                       shadowSrc, scnt, P, level, cap, overflow);
 }
 
 // MAT:71-160 LookupUV: address mode + point sample
@@ -549,7 +553,8 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_b(SceneView S, ShadeView
                                                  xrt_ray *nextRays, int *nextPath, int *nextCnt, int P, int level, int maxReflections,
                                                  TreeArgs T) {
     __shared__ int ldsCounts[17];
-    const int n = *scnt;
+    int n = *scnt;
+    if (n > T.cap) n = T.cap;
     const int stride = (int)(gridDim.x * blockDim.x);
     const int rounds = (n + stride - 1) / stride;
     for (int it = 0; it < rounds; it++) {
@@ -619,14 +624,16 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_b(SceneView S, ShadeView
         }
         if (level < maxReflections) {   // grid-uniform
             const int slot = block_append(nextCnt, valid, ldsCounts);
-            if (valid) {
+            if (valid && slot >= T.cap) *T.overflow = 1;
+            else if (valid) {
                 store_ray(nextRays + slot, w, rdir, mesh, tri);   // origin = result.triangle (RT:559)
                 nextPath[slot] = p;
                 if (T.heap) { T.nextNode[slot] = 2 * node + 1; T.nextRef[slot] = curRef; }
             }
             if (T.heap) {   // the refracted ray of RT:698 continues in the medium with index n2
                 const int slot2 = block_append(nextCnt, refracts, ldsCounts);
-                if (refracts) {
+                if (refracts && slot2 >= T.cap) *T.overflow = 1;
+                else if (refracts) {
                     store_ray(nextRays + slot2, w, tdir, mesh, tri);
                     nextPath[slot2] = p;
                     T.nextNode[slot2] = 2 * node + 2; T.nextRef[slot2] = n2;

@@ -154,6 +154,16 @@ XRT_HD void lane_begin(Lane &L, const SceneView &S, v3 o, v3 d, int ignoreMesh, 
     L.sfound = 0;
     L.sbKey = 0; L.sbD = 0; L.sbU = 0; L.sbV = 0; L.sbRef = 0; L.sbLeaf = 0; L.sbObj = -1; L.sbMesh = -1;
     L.sRef = 0; L.sRefEnd = 0; L.mPtr = 0; L.mEnd = 0; L.ssp = 0; L.sKey = 0; L.obj = -1;
+    if (is_nan(o.x) || is_nan(o.y) || is_nan(o.z) || is_nan(d.x) || is_nan(d.y) || is_nan(d.z)) {
+        // A NaN component (e.g. the refracted direction of a total internal reflection, RT:676-694) poisons every
+        // determinant of RE:42-75 (NaN * 0 is NaN): no triangle can be accepted, while the NaN-propagating box test
+        // of the reference accepts EVERY box — the reference walks the whole scene to return "no intersection".
+        L.w = make_ray(o, d);   // (the counting pass reproduces that walk from L.w)
+        L.r = L.w;
+        L.mfound = 0; L.mKey = 0;
+        L.state = ST_FINISH;
+        return;
+    }
     L.spec = (L.ignoreId < 0) ? 1 : 0;   // rays leaving a surface (RT:485, RT:559) start among back faces
     if (mode == MODE_SCENE) {
         L.w = make_ray(o, d);

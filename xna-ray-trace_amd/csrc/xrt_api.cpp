@@ -241,12 +241,23 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     const long long totalPixels = myTiles * 512;
     if (adaptive && totalPixels * 4 > 0x7fffffffLL) return fail(XRT_E_UNSUPPORTED, "frame too large for adaptive supersampling");
     const long long firstPaths = totalPixels * g.samples;
-    // a path owns up to 2^R rays of one generation when materials refract, one otherwise
-    const long long maxPaths = heap ? (MAX_CHUNK_PATHS >> R) : MAX_CHUNK_PATHS;
+    // Chunking.  Without refraction a path owns one ray per generation.  With Transparent materials it may own up to
+    // 2^k in generation k, but few paths do: chunks are sized optimistically (ray buffers of MAX_CHUNK_PATHS rays,
+    // level records bounded by 8 GB) and a chunk whose generation overflows is retried with a quarter of the paths.
+    const size_t nodes = heap ? (((size_t)1 << (R + 1)) - 1) : (size_t)(R + 1);
+    long long maxPaths = MAX_CHUNK_PATHS;
+    if (heap) {
+        maxPaths = 262144;
+        const long long byRecords = (long long)((8ull << 30) / (nodes * 36ull));
+        if (byRecords < maxPaths) maxPaths = byRecords;
+        maxPaths &= ~63LL;
+        if (maxPaths < 64) maxPaths = 64;
+    }
     const long long chunkPaths = firstPaths < maxPaths ? firstPaths : maxPaths;
     const int P = (int)chunkPaths;
-    const size_t rayCap = heap ? ((size_t)P << R) : (size_t)P;
-    const size_t nodes = heap ? (((size_t)1 << (R + 1)) - 1) : (size_t)(R + 1);
+    size_t rayCap = (size_t)P;
+    if (heap) { rayCap = (R < 20 && ((size_t)P << R) < (size_t)MAX_CHUNK_PATHS) ? ((size_t)P << R) : (size_t)MAX_CHUNK_PATHS; if (rayCap < (size_t)P) rayCap = (size_t)P; }
+    const size_t shadowCap = rayCap;   // hits of one generation (each emits nL shadow rays)
     const bool wantF32 = d_outF32 != nullptr && !adaptive && g.samples == 1;
     const bool fuseResolve = !adaptive && !heap && g.samples == 1;   // k_compose writes the framebuffer itself
     // buffers
@@ -287,9 +298,114 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     unsigned long long hcntHost[2 * C_COUNT] = {0};
 
     // One pass = trace `total` paths produced by generator `gp`; after every chunk `post(Pc, pathBase)` consumes sampleColor.
+    int *overflowFlag = reinterpret_cast<int *>(s->counters.p + 2 * C_COUNT) + 12;   // spare counter words (zeroed above)
+
+    // Enqueue one chunk of `Pc` paths starting at `pathBase`: raygen, the generations, compose.
+    auto enqueue_chunk = [&](const RayGenParams &gp, int *cnt, unsigned *q, int Pc, long long pathBase) -> int {
+        int *scnt = cnt + (R + 2);
+        // cnt[0] counts the primary rays that reach the scene's root box; paths[1] doubles as their index list
+        launch_raygen(gp, S, rays[0], s->lvlB.p, paths[1], cnt, Pc, pathBase, st);
+        for (int k = 0; k <= R; k++) {
+            const int cur = k & 1, nxt = cur ^ 1;
+            IntersectArgs A;
+            A.rays = rays[cur]; A.hits = s->hits.p; A.index = k == 0 ? paths[1] : nullptr; A.nDev = cnt + k; A.nMul = 1; A.n = Pc;
+            A.nCap = (int)rayCap;
+            A.queue = q + 2 * k; A.mode = s->sceneMode; A.meshId = 0;
+            A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.firstBatch = s->firstBatch;
+            hipEvent_t a0 = get_event(s, ev), a1 = get_event(s, ev + 1);
+            if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
+            pairs.push_back({ev, ev + 1}); ev += 2;
+            launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st, a0, a1);
+            if (opts->collect_stats) launch_count(S, A, s->counters.p, st);   // generation 0: the live list; culled rays are added below
+            launch_shade_a(S, V, rays[cur], s->hits.p, cnt + k, Pc, k == 0 ? paths[1] : nullptr, k == 0 ? nullptr : paths[cur],
+                           (heap && k > 0) ? nodesOf[cur] : nullptr, s->lvlB.p, s->shadowRays.p, s->shadowSrc.p, scnt + k, P, k, (int)shadowCap,
+                           overflowFlag, st);
+            if (nL > 0) {
+                IntersectArgs B;
+                B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.index = nullptr; B.nDev = scnt + k; B.nMul = nL; B.n = 0;
+                B.nCap = (int)shadowCap * nL;
+                B.queue = q + 2 * k + 1; B.mode = s->sceneMode; B.meshId = 0;
+                B.refillMin = s->tune[0]; B.nodeBurst = s->tune[1]; B.leafBurst = s->tune[2]; B.firstBatch = s->firstBatch;
+                hipEvent_t b0 = get_event(s, ev), b1 = get_event(s, ev + 1);
+                if (!b0 || !b1) return fail(XRT_E_HIP, "hipEventCreate failed");
+                pairs.push_back({ev, ev + 1}); ev += 2;
+                launch_intersect(S, B, s->stackNeeded, persistent_grid(s, -1), st, b0, b1);
+                if (opts->collect_stats) launch_count(S, B, s->counters.p + C_COUNT, st);
+            }
+            TreeArgs T;
+            T.heap = heap ? 1 : 0;
+            T.cap = (int)rayCap; T.overflow = overflowFlag;
+            T.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; T.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
+            T.nextNode = heap ? nodesOf[nxt] : nullptr; T.nextRef = heap ? refOf[nxt] : nullptr; T.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
+            launch_shade_b(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : paths[cur], scnt + k, s->shadowSrc.p, s->shadowHits.p, s->lvlA.p,
+                           s->lvlB.p, rays[nxt], paths[nxt], cnt + k + 1, P, k, R, T, st);
+        }
+        if (heap) launch_compose_tree(s->lvlA.p, s->lvlB.p, s->lvlAlpha.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
+        else {
+            ResolveArgs RA;
+            RA.fused = fuseResolve ? 1 : 0; RA.g = gp; RA.pixelBase = pathBase; RA.out = d_out; RA.outF32 = d_outF32;
+            launch_compose(s->lvlA.p, s->lvlB.p, Pc, P, R, s->sampleColor.p, (wantF32 && !fuseResolve) ? s->sampleF32.p : nullptr, RA, st);
+        }
+        return XRT_OK;
+    };
+    auto ensure_pinned = [&](size_t bytes) -> int {
+        if (s->pinnedBytes < bytes) {
+            if (s->pinned) (void)hipHostFree(s->pinned);
+            s->pinned = nullptr; s->pinnedBytes = 0;
+            HIPCHECK(hipHostMalloc(&s->pinned, bytes + 4096, hipHostMallocDefault));
+            s->pinnedBytes = bytes + 4096;
+        }
+        return XRT_OK;
+    };
+    auto tally = [&](const int *hc) {
+        for (int k = 0; k <= R; k++) {
+            shaded += (unsigned long long)hc[(R + 2) + k];
+            if (k > 0) closestDeep += (unsigned long long)hc[k];
+            else live0 += (unsigned long long)hc[0];
+        }
+    };
+
+    // One pass = trace `total` paths produced by generator `gp`; after every chunk `post(Pc, pathBase)` consumes sampleColor.
     auto run_pass = [&](const RayGenParams &gp, long long total, auto &&post, float progress0, float progress1, bool finalPass) -> int {
-        const int nChunks = (int)((total + chunkPaths - 1) / chunkPaths);
         int rc2;
+        const size_t nb2 = 2 * C_COUNT * sizeof(unsigned long long);
+        if (heap) {
+            // ray-tree mode: one chunk at a time, checked for overflow, retried with fewer paths when a generation did not fit
+            const size_t words = (size_t)cntStride + (size_t)qStride;
+            if ((rc2 = s->cnts.ensure(words)) || (rc2 = ensure_pinned(words * sizeof(int) + nb2 + 64))) return rc2;
+            unsigned *q = reinterpret_cast<unsigned *>(s->cnts.p + cntStride);
+            long long pathBase = 0, curChunk = chunkPaths;
+            while (pathBase < total) {
+                const int Pc = (int)((total - pathBase) < curChunk ? (total - pathBase) : curChunk);
+                HIPCHECK(hipMemsetAsync(s->cnts.p, 0, words * sizeof(int), st));
+                const size_t pairsMark = pairs.size(), evMark = ev;
+                if ((rc2 = enqueue_chunk(gp, s->cnts.p, q, Pc, pathBase))) return rc2;
+                char *pin = (char *)s->pinned;
+                HIPCHECK(hipMemcpyAsync(pin, s->cnts.p, (size_t)cntStride * sizeof(int), hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipMemcpyAsync(pin + (size_t)cntStride * sizeof(int), overflowFlag, sizeof(int), hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipMemcpyAsync(pin + (size_t)cntStride * sizeof(int) + 64, s->counters.p, nb2, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+                const int over = *(const int *)(pin + (size_t)cntStride * sizeof(int));
+                if (over) {
+                    if (curChunk <= 64) return fail(XRT_E_UNSUPPORTED, "the ray tree of 64 paths does not fit the ray buffers (MaxReflections too high for this scene)");
+                    curChunk = (curChunk / 4) & ~63LL;
+                    if (curChunk < 64) curChunk = 64;
+                    HIPCHECK(hipMemsetAsync(overflowFlag, 0, sizeof(int), st));
+                    HIPCHECK(hipMemcpyAsync(s->counters.p, hcntHost, nb2, hipMemcpyHostToDevice, st));   // undo this attempt's counting
+                    HIPCHECK(hipStreamSynchronize(st));
+                    pairs.resize(pairsMark); ev = evMark;   // its launches are not part of the frame's timing
+                    continue;
+                }
+                tally((const int *)pin);
+                std::memcpy(hcntHost, pin + (size_t)cntStride * sizeof(int) + 64, nb2);
+                if ((rc2 = post(Pc, pathBase))) return rc2;
+                pathBase += Pc;
+                s->progress.store(progress0 + (progress1 - progress0) * (float)pathBase / (float)total);
+            }
+            if (finalPass) HIPCHECK(hipEventRecord(e1, st));
+            return XRT_OK;
+        }
+        const int nChunks = (int)((total + chunkPaths - 1) / chunkPaths);
         // ray counts and queue heads of all chunks live in one allocation: one memset per pass
         const size_t cntWords = (size_t)nChunks * cntStride, qWords = (size_t)nChunks * qStride;
         if ((rc2 = s->cnts.ensure(cntWords + qWords))) return rc2;
@@ -298,48 +414,8 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
         for (int c = 0; c < nChunks; c++) {
             const long long pathBase = (long long)c * chunkPaths;
             const int Pc = (int)((total - pathBase) < chunkPaths ? (total - pathBase) : chunkPaths);
-            int *cnt = s->cnts.p + (size_t)c * cntStride, *scnt = cnt + (R + 2);
-            unsigned *q = queuesBase + (size_t)c * qStride;
-            // cnt[0] counts the primary rays that reach the scene's root box; paths[1] doubles as their index list
-            launch_raygen(gp, S, rays[0], s->lvlB.p, paths[1], cnt, Pc, pathBase, st);
-            for (int k = 0; k <= R; k++) {
-                const int cur = k & 1, nxt = cur ^ 1;
-                IntersectArgs A;
-                A.rays = rays[cur]; A.hits = s->hits.p; A.index = k == 0 ? paths[1] : nullptr; A.nDev = cnt + k; A.nMul = 1; A.n = Pc;
-                A.queue = q + 2 * k; A.mode = s->sceneMode; A.meshId = 0;
-                A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.firstBatch = s->firstBatch;
-                hipEvent_t a0 = get_event(s, ev), a1 = get_event(s, ev + 1);
-                if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
-                pairs.push_back({ev, ev + 1}); ev += 2;
-                launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st, a0, a1);
-                if (opts->collect_stats) launch_count(S, A, s->counters.p, st);   // generation 0: the live list; culled rays are added below
-                launch_shade_a(S, V, rays[cur], s->hits.p, cnt + k, Pc, k == 0 ? paths[1] : nullptr, k == 0 ? nullptr : paths[cur],
-                               (heap && k > 0) ? nodesOf[cur] : nullptr, s->lvlB.p, s->shadowRays.p, s->shadowSrc.p, scnt + k, P, k, st);
-                if (nL > 0) {
-                    IntersectArgs B;
-                    B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.index = nullptr; B.nDev = scnt + k; B.nMul = nL; B.n = 0;
-                    B.queue = q + 2 * k + 1; B.mode = s->sceneMode; B.meshId = 0;
-                    B.refillMin = s->tune[0]; B.nodeBurst = s->tune[1]; B.leafBurst = s->tune[2]; B.firstBatch = s->firstBatch;
-                    hipEvent_t b0 = get_event(s, ev), b1 = get_event(s, ev + 1);
-                    if (!b0 || !b1) return fail(XRT_E_HIP, "hipEventCreate failed");
-                    pairs.push_back({ev, ev + 1}); ev += 2;
-                    launch_intersect(S, B, s->stackNeeded, persistent_grid(s, -1), st, b0, b1);
-                    if (opts->collect_stats) launch_count(S, B, s->counters.p + C_COUNT, st);
-                }
-                TreeArgs T;
-                T.heap = heap ? 1 : 0;
-                T.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; T.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
-                T.nextNode = heap ? nodesOf[nxt] : nullptr; T.nextRef = heap ? refOf[nxt] : nullptr; T.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
-                launch_shade_b(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : paths[cur], scnt + k, s->shadowSrc.p, s->shadowHits.p, s->lvlA.p,
-                               s->lvlB.p, rays[nxt], paths[nxt], cnt + k + 1, P, k, R, T, st);
-            }
-            if (heap) launch_compose_tree(s->lvlA.p, s->lvlB.p, s->lvlAlpha.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
-            else {
-                ResolveArgs RA;
-                RA.fused = fuseResolve ? 1 : 0; RA.g = gp; RA.pixelBase = pathBase; RA.out = d_out; RA.outF32 = d_outF32;
-                launch_compose(s->lvlA.p, s->lvlB.p, Pc, P, R, s->sampleColor.p, (wantF32 && !fuseResolve) ? s->sampleF32.p : nullptr, RA, st);
-            }
-            if (!(fuseResolve && !heap) && (rc2 = post(Pc, pathBase))) return rc2;
+            if ((rc2 = enqueue_chunk(gp, s->cnts.p + (size_t)c * cntStride, queuesBase + (size_t)c * qStride, Pc, pathBase))) return rc2;
+            if (!fuseResolve && (rc2 = post(Pc, pathBase))) return rc2;
             if (nChunks > 1) {
                 HIPCHECK(hipStreamSynchronize(st));
                 s->progress.store(progress0 + (progress1 - progress0) * (float)(c + 1) / (float)nChunks);
@@ -347,24 +423,13 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
         }
         if (finalPass) HIPCHECK(hipEventRecord(e1, st));
         if (stats) {   // per-pass ray accounting (the counter block is reused by the next pass): one pinned read-back, one sync
-            const size_t nb = (size_t)nChunks * cntStride * sizeof(int), nb2 = 2 * C_COUNT * sizeof(unsigned long long);
-            if (s->pinnedBytes < nb + nb2) {
-                if (s->pinned) (void)hipHostFree(s->pinned);
-                s->pinned = nullptr; s->pinnedBytes = 0;
-                HIPCHECK(hipHostMalloc(&s->pinned, nb + nb2 + 4096, hipHostMallocDefault));
-                s->pinnedBytes = nb + nb2 + 4096;
-            }
+            const size_t nb = (size_t)nChunks * cntStride * sizeof(int);
+            if ((rc2 = ensure_pinned(nb + nb2))) return rc2;
             HIPCHECK(hipMemcpyAsync(s->pinned, s->cnts.p, nb, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipMemcpyAsync((char *)s->pinned + nb, s->counters.p, nb2, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
-            const int *hc = (const int *)s->pinned;
+            for (int c = 0; c < nChunks; c++) tally((const int *)s->pinned + (size_t)c * cntStride);
             std::memcpy(hcntHost, (char *)s->pinned + nb, nb2);
-            for (int c = 0; c < nChunks; c++)
-                for (int k = 0; k <= R; k++) {
-                    shaded += (unsigned long long)hc[(size_t)c * cntStride + (R + 2) + k];
-                    if (k > 0) closestDeep += (unsigned long long)hc[(size_t)c * cntStride + k];
-                    else live0 += (unsigned long long)hc[(size_t)c * cntStride];
-                }
         }
         return XRT_OK;
     };
@@ -477,7 +542,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
     if ((rc = s->queues.ensure(8)) || (rc = s->counters.ensure(2 * C_COUNT))) return rc;
     HIPCHECK(hipMemsetAsync(s->queues.p, 0, sizeof(unsigned), st));
     IntersectArgs A;
-    A.rays = d_rays; A.hits = d_hits; A.index = nullptr; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.queue = s->queues.p; A.mode = mode; A.meshId = meshId;
+    A.rays = d_rays; A.hits = d_hits; A.index = nullptr; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.nCap = 0; A.queue = s->queues.p; A.mode = mode; A.meshId = meshId;
     A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.firstBatch = s->firstBatch;
     hipEvent_t a0 = nullptr, a1 = nullptr;
     if (stats) {

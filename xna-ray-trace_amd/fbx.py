@@ -1,0 +1,206 @@
+"""Asset ingestion: FBX 6.x (ASCII 6.1 as written by Blender, binary 6100 as written by 3ds Max)
+-> the triangle arrays a `Mesh` carries, with the semantics of RayTracePipeline/TracerModelProcessor.cs:
+vertices are baked with the node's absolute transform (TMP:179-181), normals with its inverse transpose and
+re-normalised (TMP:191-197), surfaceNormal = normalize(cross(v3-v1, v2-v1)) (TMP:199-203), the mesh AABB starts at
+the origin (TMP:244-307), `Scale` is the ModelProcessor parameter of the .contentproj.
+
+The XNA FbxImporter itself is closed source; the behaviour fixed here is the build's definition:
+node transform = Scaling * RotX * RotY * RotZ * Translation in XNA's row-vector convention (FBX eEulerXYZ), Z-up
+files are turned Y-up by (x, y, z) -> (x, z, -y), polygons are fan-triangulated and their winding reversed to
+clockwise so that surfaceNormal agrees with the exported vertex normals.  All arithmetic in binary32.
+"""
+import re
+import struct
+
+import numpy as np
+
+from . import xna
+from .fixtures import MeshData
+
+f32 = np.float32
+
+
+class FbxMesh:
+    def __init__(self, name):
+        self.name = name
+        self.vertices = None          # (n, 3) float64 as written in the file
+        self.polygons = []            # lists of vertex indices
+        self.normals = None           # (m, 3)
+        self.normal_mapping = None    # "ByVertice" | "ByPolygonVertex"
+        self.uvs = None               # (k, 2)
+        self.uv_index = None
+        self.uv_mapping = None
+        self.translation = (0.0, 0.0, 0.0)
+        self.rotation = (0.0, 0.0, 0.0)   # degrees
+        self.scaling = (1.0, 1.0, 1.0)
+
+
+def _split_polygons(idx):
+    polys, cur = [], []
+    for i in idx:
+        if i < 0:
+            cur.append(~i)
+            polys.append(cur)
+            cur = []
+        else:
+            cur.append(i)
+    return polys
+
+
+def _numbers(text):
+    return [float(x) for x in re.findall(r"[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?", text)]
+
+
+def _ascii_block(text, start):
+    """text[start] is just after an opening '{'; returns the index of the matching '}'."""
+    depth, i = 1, start
+    while depth and i < len(text):
+        c = text[i]
+        if c == "{":
+            depth += 1
+        elif c == "}":
+            depth -= 1
+        elif c == '"':
+            i = text.index('"', i + 1)
+        i += 1
+    return i - 1
+
+
+def _ascii_array(body, key):
+    m = re.search(r"\b" + key + r":\s*([^A-Za-z{}\"]*)", body)
+    return _numbers(m.group(1)) if m else None
+
+
+def load_ascii(text):
+    up = re.search(r'Property:\s*"UpAxis",\s*"int",\s*"",\s*(-?\d+)', text)
+    up_axis = int(up.group(1)) if up else 1
+    meshes = []
+    for m in re.finditer(r'Model:\s*"Model::([^"]*)",\s*"Mesh"\s*\{', text):
+        end = _ascii_block(text, m.end())
+        body = text[m.end():end]
+        fm = FbxMesh(m.group(1))
+        for prop, attr in (("Lcl Translation", "translation"), ("Lcl Rotation", "rotation"), ("Lcl Scaling", "scaling")):
+            pm = re.search(r'Property:\s*"' + prop + r'",\s*"[^"]*",\s*"[^"]*",\s*([^\n]*)', body)
+            if pm:
+                setattr(fm, attr, tuple(_numbers(pm.group(1))[:3]))
+        verts, pvi = _ascii_array(body, "Vertices"), _ascii_array(body, "PolygonVertexIndex")
+        if not verts or not pvi:
+            continue   # a Model of type Mesh without geometry
+        fm.vertices = np.array(verts, dtype=np.float64).reshape(-1, 3)
+        fm.polygons = _split_polygons([int(x) for x in pvi])
+        nm = re.search(r"LayerElementNormal:\s*\d+\s*\{", body)
+        if nm:
+            nb = body[nm.end():_ascii_block(body, nm.end())]
+            fm.normal_mapping = re.search(r'MappingInformationType:\s*"([^"]*)"', nb).group(1)
+            fm.normals = np.array(_ascii_array(nb, "Normals"), dtype=np.float64).reshape(-1, 3)
+        um = re.search(r"LayerElementUV:\s*\d+\s*\{", body)
+        if um:
+            ub = body[um.end():_ascii_block(body, um.end())]
+            fm.uv_mapping = re.search(r'MappingInformationType:\s*"([^"]*)"', ub).group(1)
+            fm.uvs = np.array(_ascii_array(ub, "UV"), dtype=np.float64).reshape(-1, 2)
+            ui = _ascii_array(ub, "UVIndex")
+            fm.uv_index = [int(x) for x in ui] if ui else None
+        meshes.append(fm)
+    return meshes, up_axis
+
+
+def _binary_values(b, pos, limit=1 << 20):
+    vals, j = [], pos
+    while j < len(b) and len(vals) < limit:
+        t = b[j:j + 1]
+        if t == b"D":
+            vals.append(struct.unpack_from("<d", b, j + 1)[0]); j += 9
+        elif t == b"I":
+            vals.append(struct.unpack_from("<i", b, j + 1)[0]); j += 5
+        elif t == b"F":
+            vals.append(struct.unpack_from("<f", b, j + 1)[0]); j += 5
+        elif t == b"S" and j + 5 <= len(b) and struct.unpack_from("<I", b, j + 1)[0] < 256:   # string property: skipped
+            j += 5 + struct.unpack_from("<I", b, j + 1)[0]
+        else:
+            break
+    return vals
+
+
+def load_binary(b):
+    """Binary FBX 6100: node properties are typed scalars ('D' double, 'I' int32, 'F' float) following the node
+    name; enough to read the mesh arrays of a single-mesh file such as Crate_Fragile.FBX."""
+    def after(name, nth=0, min_len=1):
+        found = 0
+        for m in re.finditer(re.escape(name), b):
+            v = _binary_values(b, m.end())
+            if len(v) >= min_len:
+                if found == nth:
+                    return v
+                found += 1
+        return None
+    fm = FbxMesh("mesh")
+    fm.vertices = np.array(after(b"Vertices", min_len=9), dtype=np.float64).reshape(-1, 3)
+    fm.polygons = _split_polygons([int(x) for x in after(b"PolygonVertexIndex", min_len=3)])
+    nv = after(b"Normals", min_len=9)
+    if nv:
+        fm.normals = np.array(nv, dtype=np.float64).reshape(-1, 3)
+        fm.normal_mapping = "ByPolygonVertex" if len(fm.normals) == sum(len(p) for p in fm.polygons) else "ByVertice"
+    uv = after(b"UV", min_len=8)
+    if uv:
+        fm.uvs = np.array(uv, dtype=np.float64).reshape(-1, 2)
+        ui = after(b"UVIndex", min_len=3)
+        fm.uv_index = [int(x) for x in ui] if ui else None
+        fm.uv_mapping = "ByPolygonVertex"
+    t = after(b"Lcl Translation", min_len=3)
+    if t:
+        fm.translation = tuple(t[:3])
+    up = after(b"UpAxis")
+    return [fm], (int(up[0]) if up else 1)
+
+
+def load_fbx(path):
+    data = open(path, "rb").read()
+    if data.startswith(b"Kaydara FBX Binary"):
+        return load_binary(data)
+    return load_ascii(data.decode("latin-1"))
+
+
+def import_mesh(fm, up_axis=1, scale=1.0, diffuse_color=(255, 255, 255, 255), apply_node_transform=True, flip_v=True):
+    """FbxMesh -> fixtures.MeshData with TracerModelProcessor semantics (see module docstring)."""
+    if apply_node_transform:
+        rad = [f32(np.deg2rad(float(a))) for a in fm.rotation]
+        world, _, _ = xna.build_world(fm.scaling, rad, fm.translation, np.zeros(6, dtype=np.float32))
+    else:
+        world = xna.identity()
+    # normals: transpose(invert(absoluteTransform)) (TMP:141)
+    inv = xna.invert(world)
+    invT = [inv[4 * j + i] for i in range(4) for j in range(4)]
+    s = f32(scale)
+
+    def pos(p):
+        v = xna.transform(xna.vec3(*[float(x) for x in p]), world)
+        if up_axis == 2:
+            v = [v[0], v[2], -v[1]]
+        return tuple(float(c * s) for c in v)
+
+    def nrm(nv):
+        v = xna.transform(xna.vec3(*[float(x) for x in nv]), invT)
+        if up_axis == 2:
+            v = [v[0], v[2], -v[1]]
+        return tuple(float(c) for c in xna.normalize(v))
+    tris, nrms, uvs = [], [], []
+    pv = 0   # polygon-vertex counter
+    for poly in fm.polygons:
+        corner = []
+        for k, vi in enumerate(poly):
+            n = (0.0, 0.0, 0.0)
+            if fm.normals is not None:
+                n = nrm(fm.normals[pv + k] if fm.normal_mapping == "ByPolygonVertex" else fm.normals[vi])
+            uv = (0.0, 0.0)
+            if fm.uvs is not None:
+                ui = fm.uv_index[pv + k] if fm.uv_index is not None else pv + k
+                u, w = fm.uvs[ui]
+                uv = (float(f32(u)), float(f32(1.0) - f32(w)) if flip_v else float(f32(w)))
+            corner.append((pos(fm.vertices[vi]), n, uv))
+        pv += len(poly)
+        for k in range(1, len(poly) - 1):   # fan (p0, pk, pk+1), reversed to clockwise: (p0, pk+1, pk)
+            a, b, c = corner[0], corner[k + 1], corner[k]
+            tris.append((a[0], b[0], c[0])); nrms.append((a[1], b[1], c[1])); uvs.append((a[2], b[2], c[2]))
+    n = len(tris)
+    col = np.tile(np.array([[f32(c) / f32(255.0) for c in diffuse_color]], dtype=np.float32), (n, 1))   # Color.ToVector4 (TMP:228)
+    return MeshData(np.array(tris, dtype=np.float32), np.array(nrms, dtype=np.float32), np.array(uvs, dtype=np.float32), col)
