@@ -5,7 +5,7 @@ confs = sys.argv[2].split(",") if len(sys.argv) > 2 else ["C3", "C5_1spp"]
 for t in cfgs:
     for c in confs:
         env = dict(os.environ, XRT_TUNE=t)
-        out = subprocess.run([sys.executable, "bench.py", "--config", c, "--steps", "5", "--warmup", "1", "--no-extra", "--no-cpu"], env=env, capture_output=True, text=True)
+        out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "--config", c, "--steps", "5", "--warmup", "1", "--no-extra", "--no-cpu"], env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:
             print(t, c, "FAILED", out.stderr[-300:]); continue
