@@ -295,6 +295,39 @@ def test_default_game_scene(xrt, orc):
         assert tracer.last_stats[k] == o_st[k], (k, tracer.last_stats[k], o_st[k])
 
 
+def test_empty_and_tiny_scenes(xrt, orc):
+    """Edge cases of the containers: no bodies at all, a body without meshes, a mesh without triangles, one triangle."""
+    def spec_of(meshes, objects):
+        s = xrt.configs.SceneSpec("edge")
+        s.meshes, s.objects = meshes, objects
+        s.camera = xrt.configs.camera((0, 3, 6), (0, 0, 0))
+        s.lights = [xrt.configs.spot((0, 8, 8))]
+        s.max_reflections = 1
+        return s.with_size(70, 33)
+    one = xrt.fixtures.MeshData(np.array([[(-2, 0, -2), (2, 0, -2), (0, 0, 2)]], dtype=np.float32), np.zeros((1, 3, 3), np.float32),
+                                np.zeros((1, 3, 2), np.float32), np.ones((1, 4), np.float32))
+    none = xrt.fixtures.MeshData(np.zeros((0, 3, 3), np.float32), np.zeros((0, 3, 3), np.float32), np.zeros((0, 3, 2), np.float32),
+                                 np.zeros((0, 4), np.float32))
+    ident = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    cases = {
+        "no bodies": spec_of([(one, xrt.configs.material(0.5))], []),
+        "body without meshes": spec_of([(one, xrt.configs.material(0.5))], [([],) + ident, ([0],) + ident]),
+        "empty mesh": spec_of([(none, xrt.configs.material(0.5)), (one, xrt.configs.material(0.2))], [([0, 1],) + ident]),
+        "one triangle": spec_of([(one, xrt.configs.material(0.5))], [([0],) + ident]),
+    }
+    for name, spec in cases.items():
+        scene, tracer = xrt.configs.build_product(spec)
+        tracer.collect_stats = True
+        rgba, rgbf = tracer.Render(want_float=True)
+        o = orc.OracleScene(spec)
+        o_rgba, o_rgbf, o_st = o.render()
+        assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+        for k in ("rays_closest", "rays_shadow", "scene_node_tests", "instance_visits", "mesh_aabb_tests", "node_tests", "tri_tests", "algorithmic_bytes"):
+            assert tracer.last_stats[k] == o_st[k], (name, k, tracer.last_stats[k], o_st[k])
+        rays = o.primary_rays()
+        assert hits_equal(o.intersect(rays), scene.IntersectBatch(rays)) == {}, name
+
+
 def test_error_conventions_on_gpu(xrt):
     spec = xrt.configs.config("C1")
     scene, tracer = xrt.configs.build_product(spec)

@@ -46,6 +46,8 @@ def surface_normals(v):
 def mesh_bbox(v):
     """TracerModelProcessor.CreateBoundingBox (TMP:244-307): starts from new BoundingBox() = origin."""
     pts = v.reshape(-1, 3)
+    if pts.shape[0] == 0:
+        return np.zeros(6, dtype=np.float32)
     mn = np.minimum(pts.min(axis=0), f32(0.0))
     mx = np.maximum(pts.max(axis=0), f32(0.0))
     return np.concatenate([mn, mx]).astype(np.float32)
