@@ -62,27 +62,41 @@ def time_frames(tracer, outs, steps, warmup, rank, world, width, height, gathere
             if rank == 0:
                 xrt.dist.detile_device(g if nccl else g.cuda(), width, height, world, gathered_out)
 
-    def frame(i):
-        st = renders[i % 2]()                      # blocking: this rank's tiles of frame i are in HBM
+    open_frame = []                                # at most one (ticket, index): frame i is enqueued before frame i-1 is waited for
+
+    def complete():
+        t, j = open_frame.pop()
+        st = renders[j % 2].end(t)                 # blocking: this rank's tiles of frame j are in HBM
         if world > 1:
-            finish()                               # frame i-1's gather ran while frame i was rendered
-            src = outs[i % 2] if nccl else outs[i % 2].cpu()   # gloo: rehearsal on a box with fewer GPUs than ranks
-            pending.append(xrt.dist.gather_frame_async(src, recv=recv[i % 2]))   # the path's exchange step (RCCL gather over xGMI)
+            src = outs[j % 2] if nccl else outs[j % 2].cpu()   # gloo: rehearsal on a box with fewer GPUs than ranks
+            pending.append(xrt.dist.gather_frame_async(src, recv=recv[j % 2]))   # the path's exchange step (RCCL gather over xGMI)
+        return st
+
+    def frame(i):
+        finish()                                   # frame i-2's gather is done: its tile buffer is free again
+        t = renders[i % 2].begin()                 # host side of frame i overlaps the GPU side of frame i-1 (and its gather)
+        st = complete() if open_frame else None
+        open_frame.append((t, i))
+        return st
+
+    def drain():
+        st = complete() if open_frame else None
+        finish()
         return st
     for i in range(warmup):
         frame(i)
-    finish()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ms_intersect, launches = 0.0, 0
-    for i in range(steps):
-        st = frame(i)
-        ms_intersect += st["ms_intersect"]
-        launches += st["intersect_launches"]
-    finish()
+    for i in range(steps + 1):
+        st = frame(i) if i < steps else drain()
+        if st is not None:
+            ms_intersect += st["ms_intersect"]
+            launches += st["intersect_launches"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -234,6 +234,18 @@ int xrt_render_device(xrt_scene *scene, const xrt_camera *camera, const xrt_ligh
                       int32_t n_lights, const xrt_render_opts *opts, void *d_rgba_out,
                       void *stream, xrt_stats *stats_out /* nullable */);
 
+/* Pipelined form of xrt_render_device.  _begin enqueues the frame on `stream` and returns a ticket while the GPU is
+ * still working; _end waits for that frame and fills stats_out (may be NULL).  Up to two frames may be in flight on the
+ * same stream, so the host side of frame i+1 (argument marshalling, ~50 launches) overlaps the GPU side of frame i --
+ * the reference's game loop does the same with RenderAsync (RT:92-104) and one frame of latency.  d_rgba_out of a frame
+ * is complete when its _end returns (or, on the device, for work enqueued on `stream` after _begin).  Frames that need
+ * host decisions between passes (adaptive supersampling, Transparent materials, more than one chunk) finish inside
+ * _begin.  While a ticket is open every other call that renders or mutates the scene returns XRT_E_BUSY. */
+int xrt_render_device_begin(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights,
+                            int32_t n_lights, const xrt_render_opts *opts, void *d_rgba_out, void *stream,
+                            int32_t *ticket_out);
+int xrt_render_device_end(xrt_scene *scene, int32_t ticket, xrt_stats *stats_out);
+
 /* Image-tile shard geometry: tiles are XRT_TILE_W x XRT_TILE_H pixels, numbered row-major, tile t is
  * owned by rank t % shard_count and stored at slot t / shard_count of that rank's buffer. */
 #define XRT_TILE_W 64

@@ -393,3 +393,39 @@ def test_device_pointer_intersect(xrt, orc):
     torch.cuda.synchronize()
     hits = d_hits.cpu().numpy().reshape(-1).view(xrt.HIT_DTYPE)
     assert hits_equal(o.intersect(rays), hits) == {}
+
+
+def test_pipelined_frames_begin_end(xrt):
+    """xrt_render_device_begin / _end: two frames in flight give the frames and the accounting of the blocking call;
+    a third begin, or any other render, answers BUSY until a ticket is closed."""
+    import torch
+    spec = xrt.configs.config("C4", 0.25)
+    scene, tracer = xrt.configs.build_product(spec)
+    want = tracer.Render().copy()
+    st_want = dict(tracer.last_stats)
+    n = spec.width * spec.height
+    outs = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(2)]
+    fr = [tracer.PrepareDevice(o.data_ptr()) for o in outs]
+    t0 = fr[0].begin()
+    t1 = fr[1].begin()
+    assert {t0, t1} == {0, 1}
+    with pytest.raises(RuntimeError):
+        fr[0].begin()                        # both contexts busy
+    with pytest.raises(RuntimeError):
+        tracer.Render()                      # RT:62-63 while frames are open
+    st0 = fr[0].end(t0)
+    with pytest.raises(ValueError):
+        fr[0].end(t0)                        # closed already
+    t2 = fr[0].begin()                       # slot is free again, frame 1 still open
+    st1 = fr[1].end(t1)
+    st2 = fr[0].end(t2)
+    with pytest.raises(ValueError):
+        fr[0].end(7)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), want)
+    for st in (st0, st1, st2):
+        for k in ("rays_closest", "rays_shadow", "shaded_hits", "pixels", "intersect_launches"):
+            assert st[k] == st_want[k], (k, st[k], st_want[k])
+        assert st["ms_total"] > 0 and st["ms_intersect"] > 0
+    assert np.array_equal(tracer.Render(), want)   # the blocking call works again

@@ -1,0 +1,31 @@
+"""Where does a pipelined frame spend its time: host enqueue (begin) vs waiting for the GPU (end)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib, torch
+xrt = importlib.import_module("xna-ray-trace_amd")
+name = sys.argv[1] if len(sys.argv) > 1 else "C2"
+spec = xrt.configs.config(name)
+scene, tracer = xrt.configs.build_product(spec)
+out = torch.zeros(spec.width * spec.height, dtype=torch.int32, device="cuda")
+fr = tracer.PrepareDevice(out.data_ptr())
+for _ in range(5):
+    fr()
+N = 200
+tb = te = 0.0
+t0 = time.perf_counter()
+prev = None
+for i in range(N):
+    a = time.perf_counter()
+    t = fr.begin()
+    b = time.perf_counter()
+    if prev is not None:
+        st = fr.end(prev)
+    c = time.perf_counter()
+    tb += b - a
+    te += c - b
+    prev = t
+st = fr.end(prev)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("%s: frame %.1f us  begin %.1f us  end(wait) %.1f us  gpu ms_total %.1f us  intersect %.1f us (%d launches)" % (
+    name, dt / N * 1e6, tb / N * 1e6, te / N * 1e6, st["ms_total"] * 1e3, st["ms_intersect"] * 1e3, st["intersect_launches"]))

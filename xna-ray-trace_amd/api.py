@@ -445,6 +445,21 @@ class RayTracer:
             self.last_stats = st.as_dict()
             return self.last_stats
         frame.keepalive = (cam, opts, lights, st)
+
+        # pipelined form: begin() enqueues a frame and returns its ticket, end(ticket) waits for it (two may be open)
+        lib = abi.lib()
+        ticket = C.c_int32(0)
+        bargs = args[:-1] + (C.byref(ticket),)
+
+        def begin():
+            abi.check(lib.xrt_render_device_begin(*bargs))
+            return ticket.value
+
+        def end(t):
+            abi.check(lib.xrt_render_device_end(handle, t, C.byref(st)))
+            self.last_stats = st.as_dict()
+            return self.last_stats
+        frame.begin, frame.end = begin, end
         return frame
 
     def GeneratePrimaryRays(self):

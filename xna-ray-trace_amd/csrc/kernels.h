@@ -70,7 +70,7 @@ void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeede
                       hipEvent_t e1 = nullptr);
 int  intersect_blocks_per_cu(int stackNeeded, int mode);
 void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long *counters, hipStream_t st);
-void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase, hipStream_t st);
+void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase, hipStream_t st, hipEvent_t startEvent = nullptr);
 void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
                     const int *index, const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level,
                     int cap, int *overflow, hipStream_t st);
@@ -86,9 +86,14 @@ struct ResolveArgs {
     long long pixelBase;
     uint32_t *out;
     float *outF32;
+    // frame epilogue (single-chunk frames): the first cntWords ray counters go to host-visible memory and
+    // zeroWords counter / queue words are cleared for the next frame -- no copy or fill commands on the stream
+    int *cntSrc = nullptr;
+    int *hostCnt = nullptr;
+    int cntWords = 0, zeroWords = 0;
 };
 void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P /* level stride */, int maxReflections, uint32_t *sampleColor, float *sampleF32,
-                    const ResolveArgs &RA, hipStream_t st);
+                    const ResolveArgs &RA, hipStream_t st, hipEvent_t stopEvent = nullptr);
 void launch_resolve(const RayGenParams &g, const uint32_t *sampleColor, const float *sampleF32, int pixels, long long pixelBase,
                     uint32_t *out, float *outF32, hipStream_t st);
 void launch_ms_decide(const RayGenParams &g, const uint32_t *quadColor, const int *nQuadsDev, int nQuadsHost, long long pixelBase, int *childBase,

@@ -413,11 +413,11 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
     }
 }
 void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase,
-                   hipStream_t st) {
+                   hipStream_t st, hipEvent_t startEvent) {
     int blocks = (P + APPEND_BLOCK - 1) / APPEND_BLOCK;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(APPEND_BLOCK), 0, st, g, S, rays, lvlB0, index, count, P, pathBase);
+    hipExtLaunchKernelGGL(k_raygen, dim3(blocks), dim3(APPEND_BLOCK), 0, st, startEvent, nullptr, 0, g, S, rays, lvlB0, index, count, P, pathBase);
 }
 
 // ---- shading ----------------------------------------------------------------------------------------------------------
@@ -652,6 +652,14 @@ void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays,
 // The return path of the CastRay recursion: deepest generation first, one RGBA8 quantisation per level.
 __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32,
                                                  ResolveArgs RA) {
+    if (RA.cntSrc && blockIdx.x == 0) {   // every kernel that counts rays has finished: hand the counters to the host, clear them
+        for (int i = (int)threadIdx.x; i < RA.zeroWords; i += (int)blockDim.x) {
+            const int v = RA.cntSrc[i];
+            if (i < RA.cntWords) RA.hostCnt[i] = v;
+            RA.cntSrc[i] = 0;
+        }
+        __threadfence_system();
+    }
     for (int p = (int)(blockIdx.x * blockDim.x + threadIdx.x); p < count; p += (int)(gridDim.x * blockDim.x)) {
         int kd = 0;
         int flag;
@@ -749,10 +757,11 @@ void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, 
     hipLaunchKernelGGL(k_compose_tree, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, lvlA, lvlB, lvlAlpha, count, P, maxReflections, sampleColor, sampleF32);
 }
 void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32,
-                    const ResolveArgs &RA, hipStream_t st) {
+                    const ResolveArgs &RA, hipStream_t st, hipEvent_t stopEvent) {
     int blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_compose, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, lvlA, lvlB, count, P, maxReflections, sampleColor, sampleF32, RA);
+    hipExtLaunchKernelGGL(k_compose, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, nullptr, stopEvent, 0, lvlA, lvlB, count, P, maxReflections,
+                          sampleColor, sampleF32, RA);
 }
 
 // Supersample averaging (RT:309: mean of four quantised colours, re-quantised, twice for 16 samples) and the

@@ -94,9 +94,29 @@ struct xrt_scene {
     DevBuf<float> sampleF32, outF32;
     DevBuf<LightRec> lights;
     DevBuf<unsigned long long> counters;
-    std::vector<hipEvent_t> events;
-    void *pinned = nullptr;      // host staging for the per-frame counter read-back
-    size_t pinnedBytes = 0;
+    // Per-frame host state.  Two contexts so that the next frame can be enqueued while the previous one's counters
+    // and timings are still on their way back (xrt_render_device_begin / _end).
+    struct FrameCtx {
+        std::vector<hipEvent_t> events;
+        void *pinned = nullptr;      // host staging for the counter read-back
+        size_t pinnedBytes = 0;
+        std::vector<std::pair<size_t, size_t>> pairs;   // (start, stop) event indices of the k_intersect launches
+        size_t ev = 0;
+        hipEvent_t done = nullptr;   // recorded after the frame's last copy
+        std::vector<LightRec> hostLights;
+        bool pending = false;
+        bool fast = false;           // no copy / fill / event-record commands: k_compose hands the counters over, events ride on kernels
+        int *pinnedDev = nullptr;    // device view of `pinned`
+        // deferred accounting
+        int tallyChunks = 0, cntStride = 0, R = 0, nL = 0;
+        bool collect = false;
+        unsigned long long shaded = 0, closestDeep = 0, livePaths = 0, live0 = 0, validPixels = 0;
+        unsigned long long hcnt[2 * C_COUNT] = {0};
+    } frames[2];
+    std::vector<hipEvent_t> events;   // xrt_scene_intersect timing
+    bool cntsClean = false;           // cnts is all zero (the previous frame's epilogue cleared what it counted)
+    std::vector<LightRec> lightsOnDevice;   // what s->lights holds
+    const void *lightsDevPtr = nullptr;
     int firstBatch = 64;
     int tune[3] = {24, 64, 32};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
     std::atomic<bool> busy{false};
@@ -106,7 +126,11 @@ struct xrt_scene {
         if (device >= 0) {
             (void)hipSetDevice(device);
             for (auto e : events) (void)hipEventDestroy(e);
-            if (pinned) (void)hipHostFree(pinned);
+            for (auto &f : frames) {
+                for (auto e : f.events) (void)hipEventDestroy(e);
+                if (f.done) (void)hipEventDestroy(f.done);
+                if (f.pinned) (void)hipHostFree(f.pinned);
+            }
             if (stream) (void)hipStreamDestroy(stream);
             blocks.release(); leafNB.release(); refN.release(); refG.release(); snodes.release(); shade.release();
             childDfs.release(); srefs.release(); objMesh.release(); meshes.release();
@@ -132,6 +156,8 @@ struct BusyGuard {
     ~BusyGuard() { if (owned) s->busy.store(false); }
 };
 
+bool in_flight(const xrt_scene *s) { return s->busy.load() || s->frames[0].pending || s->frames[1].pending; }
+
 int need_device(xrt_scene *s, const char *fn) {
     if (!s) return fail(XRT_E_INVALID_ARG, "%s: null scene", fn);
     if (s->device < 0) return fail(XRT_E_NO_DEVICE, "%s: host-only scene (created with device -1); libxrt has no CPU execution path", fn);
@@ -140,14 +166,15 @@ int need_device(xrt_scene *s, const char *fn) {
     return XRT_OK;
 }
 
-hipEvent_t get_event(xrt_scene *s, size_t i) {
-    while (s->events.size() <= i) {
+hipEvent_t get_event(std::vector<hipEvent_t> &pool, size_t i) {
+    while (pool.size() <= i) {
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
-        s->events.push_back(e);
+        pool.push_back(e);
     }
-    return s->events[i];
+    return pool[i];
 }
+hipEvent_t get_event(xrt_scene *s, size_t i) { return get_event(s->events, i); }
 
 int persistent_grid(xrt_scene *s, long long nHost) {
     int full = s->numCUs * s->blocksPerCU;
@@ -214,8 +241,14 @@ int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g
 
 // The frame: for every chunk of paths  raygen -> [intersect -> shade_a -> intersect(shadow) -> shade_b] x (R+1) -> compose,
 // then resolve (pixel grid, fixed 16 sub-rays) or the quadrant levels of adaptive supersampling (RT:170-311).
-int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts, uint32_t *d_out,
-                float *d_outF32, hipStream_t st, xrt_stats *stats) {
+int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats);
+
+// Enqueues one frame on `st`.  On return the frame's kernels and its counter read-back are in flight (F.pending);
+// frame_finish waits for them.  Adaptive supersampling and ray-tree frames need host decisions between their passes and
+// are complete when this returns.
+int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts,
+                uint32_t *d_out, float *d_outF32, hipStream_t st) {
+    const bool stats = true;   // the read-back is two small pinned copies; always taken
     if (!cam || !opts || (!lights && nLights > 0) || nLights < 0) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
     if (opts->max_reflections < 0 || opts->max_reflections > 64) return fail(XRT_E_INVALID_ARG, "max_reflections out of range");
     if (opts->address_mode < XRT_ADDRESS_CLAMP || opts->address_mode > XRT_ADDRESS_MIRROR)
@@ -273,13 +306,27 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     if (wantF32 && (rc = s->sampleF32.ensure((size_t)P * 3))) return rc;
     const int cntStride = 2 * (R + 2);          // per chunk: cnt[R+2] then scnt[R+2]
     const int qStride = 2 * (R + 1);
-    HIPCHECK(hipMemsetAsync(s->counters.p, 0, (2 * C_COUNT + 8) * sizeof(unsigned long long), st));
-    std::vector<LightRec> hl(nL > 0 ? nL : 1);
+    // The common frame (one chunk, no supersampling levels, no ray tree, no counting pass) puts nothing but its kernels
+    // on the stream: counters come back through k_compose's epilogue and the frame's events ride on raygen / compose.
+    const bool fast = !adaptive && !heap && firstPaths <= chunkPaths && !opts->collect_stats;
+    F.fast = fast;
+    if (!fast) {
+        s->cntsClean = false;
+        HIPCHECK(hipMemsetAsync(s->counters.p, 0, (2 * C_COUNT + 8) * sizeof(unsigned long long), st));
+    }
+    std::vector<LightRec> &hl = F.hostLights;   // must outlive the asynchronous upload
+    hl.assign(nL > 0 ? nL : 1, LightRec());
     for (int i = 0; i < nL; i++) {
         if (lights[i].kind != XRT_LIGHT_SPOT && lights[i].kind != XRT_LIGHT_DIRECTIONAL) return fail(XRT_E_INVALID_ARG, "unknown light kind");
         hl[i] = make_light(lights[i]);
     }
-    if (nL > 0) HIPCHECK(hipMemcpyAsync(s->lights.p, hl.data(), nL * sizeof(LightRec), hipMemcpyHostToDevice, st));
+    const bool sameLights = s->lightsOnDevice.size() == (size_t)nL && s->lightsDevPtr == s->lights.p &&
+                            (nL == 0 || std::memcmp(s->lightsOnDevice.data(), hl.data(), nL * sizeof(LightRec)) == 0);
+    if (nL > 0 && !sameLights) {
+        HIPCHECK(hipMemcpyAsync(s->lights.p, hl.data(), nL * sizeof(LightRec), hipMemcpyHostToDevice, st));
+        s->lightsOnDevice.assign(hl.begin(), hl.begin() + nL);
+        s->lightsDevPtr = s->lights.p;
+    }
     ShadeView V;
     V.shade = s->shade.p; V.materials = s->materials.p; V.texels = s->texels.p; V.meshes = s->meshes.p;
     V.lights = s->lights.p; V.nLights = nL; V.addressMode = opts->address_mode; V.filtering = opts->filtering;
@@ -288,14 +335,20 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     int *paths[2] = {s->path0.p, s->path1.p};
     int *nodesOf[2] = {s->node0.p, s->node1.p};
     float *refOf[2] = {s->ref0.p, s->ref1.p};
-    size_t ev = 0;
-    std::vector<std::pair<size_t, size_t>> pairs;
-    hipEvent_t e0 = get_event(s, ev++), e1 = get_event(s, ev++);
-    if (!e0 || !e1) return fail(XRT_E_HIP, "hipEventCreate failed");
-    HIPCHECK(hipEventRecord(e0, st));
+    size_t &ev = F.ev;
+    ev = 0;
+    std::vector<std::pair<size_t, size_t>> &pairs = F.pairs;
+    pairs.clear();
+    hipEvent_t e0 = get_event(F.events, ev++), e1 = get_event(F.events, ev++);
+    if (!F.done && hipEventCreateWithFlags(&F.done, hipEventDisableTiming) != hipSuccess) F.done = nullptr;
+    if (!e0 || !e1 || !F.done) return fail(XRT_E_HIP, "hipEventCreate failed");
+    if (!fast) HIPCHECK(hipEventRecord(e0, st));
     s->progress.store(0.0f);
-    unsigned long long shaded = 0, closestDeep = 0, livePaths = 0, live0 = 0;
-    unsigned long long hcntHost[2 * C_COUNT] = {0};
+    unsigned long long &shaded = F.shaded, &closestDeep = F.closestDeep, &livePaths = F.livePaths, &live0 = F.live0;
+    shaded = closestDeep = livePaths = live0 = 0;
+    unsigned long long *hcntHost = F.hcnt;
+    std::memset(hcntHost, 0, sizeof(F.hcnt));
+    F.tallyChunks = 0; F.cntStride = cntStride; F.R = R; F.nL = nL; F.collect = opts->collect_stats != 0;
 
     // One pass = trace `total` paths produced by generator `gp`; after every chunk `post(Pc, pathBase)` consumes sampleColor.
     int *overflowFlag = reinterpret_cast<int *>(s->counters.p + 2 * C_COUNT) + 12;   // spare counter words (zeroed above)
@@ -304,7 +357,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
     auto enqueue_chunk = [&](const RayGenParams &gp, int *cnt, unsigned *q, int Pc, long long pathBase) -> int {
         int *scnt = cnt + (R + 2);
         // cnt[0] counts the primary rays that reach the scene's root box; paths[1] doubles as their index list
-        launch_raygen(gp, S, rays[0], s->lvlB.p, paths[1], cnt, Pc, pathBase, st);
+        launch_raygen(gp, S, rays[0], s->lvlB.p, paths[1], cnt, Pc, pathBase, st, fast ? e0 : nullptr);
         for (int k = 0; k <= R; k++) {
             const int cur = k & 1, nxt = cur ^ 1;
             IntersectArgs A;
@@ -312,7 +365,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
             A.nCap = (int)rayCap;
             A.queue = q + 2 * k; A.mode = s->sceneMode; A.meshId = 0;
             A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.firstBatch = s->firstBatch;
-            hipEvent_t a0 = get_event(s, ev), a1 = get_event(s, ev + 1);
+            hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
             if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
             pairs.push_back({ev, ev + 1}); ev += 2;
             launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st, a0, a1);
@@ -326,7 +379,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
                 B.nCap = (int)shadowCap * nL;
                 B.queue = q + 2 * k + 1; B.mode = s->sceneMode; B.meshId = 0;
                 B.refillMin = s->tune[0]; B.nodeBurst = s->tune[1]; B.leafBurst = s->tune[2]; B.firstBatch = s->firstBatch;
-                hipEvent_t b0 = get_event(s, ev), b1 = get_event(s, ev + 1);
+                hipEvent_t b0 = get_event(F.events, ev), b1 = get_event(F.events, ev + 1);
                 if (!b0 || !b1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 pairs.push_back({ev, ev + 1}); ev += 2;
                 launch_intersect(S, B, s->stackNeeded, persistent_grid(s, -1), st, b0, b1);
@@ -344,16 +397,21 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
         else {
             ResolveArgs RA;
             RA.fused = fuseResolve ? 1 : 0; RA.g = gp; RA.pixelBase = pathBase; RA.out = d_out; RA.outF32 = d_outF32;
-            launch_compose(s->lvlA.p, s->lvlB.p, Pc, P, R, s->sampleColor.p, (wantF32 && !fuseResolve) ? s->sampleF32.p : nullptr, RA, st);
+            if (fast) { RA.cntSrc = cnt; RA.hostCnt = F.pinnedDev; RA.cntWords = cntStride; RA.zeroWords = cntStride + qStride; }
+            launch_compose(s->lvlA.p, s->lvlB.p, Pc, P, R, s->sampleColor.p, (wantF32 && !fuseResolve) ? s->sampleF32.p : nullptr, RA, st,
+                           (fast && fuseResolve) ? e1 : nullptr);
         }
         return XRT_OK;
     };
     auto ensure_pinned = [&](size_t bytes) -> int {
-        if (s->pinnedBytes < bytes) {
-            if (s->pinned) (void)hipHostFree(s->pinned);
-            s->pinned = nullptr; s->pinnedBytes = 0;
-            HIPCHECK(hipHostMalloc(&s->pinned, bytes + 4096, hipHostMallocDefault));
-            s->pinnedBytes = bytes + 4096;
+        if (F.pinnedBytes < bytes) {
+            if (F.pinned) (void)hipHostFree(F.pinned);
+            F.pinned = nullptr; F.pinnedBytes = 0;
+            HIPCHECK(hipHostMalloc(&F.pinned, bytes + 4096, hipHostMallocMapped));
+            F.pinnedBytes = bytes + 4096;
+            void *dv = nullptr;
+            HIPCHECK(hipHostGetDevicePointer(&dv, F.pinned, 0));
+            F.pinnedDev = (int *)dv;
         }
         return XRT_OK;
     };
@@ -380,7 +438,7 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
                 HIPCHECK(hipMemsetAsync(s->cnts.p, 0, words * sizeof(int), st));
                 const size_t pairsMark = pairs.size(), evMark = ev;
                 if ((rc2 = enqueue_chunk(gp, s->cnts.p, q, Pc, pathBase))) return rc2;
-                char *pin = (char *)s->pinned;
+                char *pin = (char *)F.pinned;
                 HIPCHECK(hipMemcpyAsync(pin, s->cnts.p, (size_t)cntStride * sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipMemcpyAsync(pin + (size_t)cntStride * sizeof(int), overflowFlag, sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipMemcpyAsync(pin + (size_t)cntStride * sizeof(int) + 64, s->counters.p, nb2, hipMemcpyDeviceToHost, st));
@@ -408,34 +466,45 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
         const int nChunks = (int)((total + chunkPaths - 1) / chunkPaths);
         // ray counts and queue heads of all chunks live in one allocation: one memset per pass
         const size_t cntWords = (size_t)nChunks * cntStride, qWords = (size_t)nChunks * qStride;
+        const int *cntsBefore = s->cnts.p;
         if ((rc2 = s->cnts.ensure(cntWords + qWords))) return rc2;
         unsigned *queuesBase = reinterpret_cast<unsigned *>(s->cnts.p + cntWords);
-        HIPCHECK(hipMemsetAsync(s->cnts.p, 0, (cntWords + qWords) * sizeof(int), st));
+        if (fast && (rc2 = ensure_pinned(cntWords * sizeof(int)))) return rc2;
+        if (!fast || !s->cntsClean || s->cnts.p != cntsBefore) HIPCHECK(hipMemsetAsync(s->cnts.p, 0, s->cnts.cap * sizeof(int), st));
+        s->cntsClean = false;
         for (int c = 0; c < nChunks; c++) {
             const long long pathBase = (long long)c * chunkPaths;
             const int Pc = (int)((total - pathBase) < chunkPaths ? (total - pathBase) : chunkPaths);
             if ((rc2 = enqueue_chunk(gp, s->cnts.p + (size_t)c * cntStride, queuesBase + (size_t)c * qStride, Pc, pathBase))) return rc2;
             if (!fuseResolve && (rc2 = post(Pc, pathBase))) return rc2;
-            if (nChunks > 1) {
+            if (nChunks > 1) {   // frames of more than MAX_CHUNK_PATHS rays: xrt_progress follows the chunks
                 HIPCHECK(hipStreamSynchronize(st));
                 s->progress.store(progress0 + (progress1 - progress0) * (float)(c + 1) / (float)nChunks);
             }
         }
+        if (fast) {   // counters arrive with k_compose; frame_finish tallies them
+            if (!fuseResolve) HIPCHECK(hipEventRecord(e1, st));   // fixed 16 sub-rays: k_resolve is the last kernel
+            s->cntsClean = true;
+            F.tallyChunks = 1;
+            return XRT_OK;
+        }
         if (finalPass) HIPCHECK(hipEventRecord(e1, st));
-        if (stats) {   // per-pass ray accounting (the counter block is reused by the next pass): one pinned read-back, one sync
+        if (stats) {   // per-pass ray accounting (the counter block is reused by the next pass): one pinned read-back
             const size_t nb = (size_t)nChunks * cntStride * sizeof(int);
             if ((rc2 = ensure_pinned(nb + nb2))) return rc2;
-            HIPCHECK(hipMemcpyAsync(s->pinned, s->cnts.p, nb, hipMemcpyDeviceToHost, st));
-            HIPCHECK(hipMemcpyAsync((char *)s->pinned + nb, s->counters.p, nb2, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipMemcpyAsync(F.pinned, s->cnts.p, nb, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipMemcpyAsync((char *)F.pinned + nb, s->counters.p, nb2, hipMemcpyDeviceToHost, st));
+            if (finalPass) { F.tallyChunks = nChunks; return XRT_OK; }   // frame_finish tallies after the frame's done event
             HIPCHECK(hipStreamSynchronize(st));
-            for (int c = 0; c < nChunks; c++) tally((const int *)s->pinned + (size_t)c * cntStride);
-            std::memcpy(hcntHost, (char *)s->pinned + nb, nb2);
+            for (int c = 0; c < nChunks; c++) tally((const int *)F.pinned + (size_t)c * cntStride);
+            std::memcpy(hcntHost, (char *)F.pinned + nb, nb2);
         }
         return XRT_OK;
     };
 
     // valid pixels of this shard
-    unsigned long long validPixels = 0;
+    unsigned long long &validPixels = F.validPixels;
+    validPixels = 0;
     for (long long t = g.shardRank; t < totalTiles; t += g.shardCount) {
         int tx = (int)(t % g.tilesX), ty = (int)(t / g.tilesX);
         int w = g.width - tx * XRT_TILE_W; if (w > XRT_TILE_W) w = XRT_TILE_W;
@@ -493,46 +562,76 @@ int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, in
             g0.quadLevel = 0; g0.quadSize = 1.0f;
             launch_resolve(g0, lv[0].color.p, nullptr, (int)totalPixels, 0, d_out, d_outF32, st);
             hipError_t e = hipEventRecord(e1, st);
-            if (e == hipSuccess && stats) e = hipMemcpyAsync(hcntHost, s->counters.p, sizeof(hcntHost), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && stats) e = hipMemcpyAsync(hcntHost, s->counters.p, sizeof(F.hcnt), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) rc = fail(XRT_E_HIP, "adaptive resolve: %s", hipGetErrorString(e));
         }
         free_levels();
         if (rc != XRT_OK) return rc;
     }
-    HIPCHECK(hipStreamSynchronize(st));
+    if (!fast) HIPCHECK(hipEventRecord(F.done, st));
     HIPCHECK(hipGetLastError());
+    F.pending = true;
+    return XRT_OK;
+}
+
+// Waits for a frame enqueued by frame_begin and turns its counters / events into xrt_stats.
+int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
+    if (!F.pending) return fail(XRT_E_INVALID_ARG, "no frame in flight for this ticket");
+    F.pending = false;
+    HIPCHECK(hipEventSynchronize(F.fast ? F.events[1] : F.done));
     s->progress.store(1.0f);
+    const int R = F.R;
+    if (F.tallyChunks > 0) {   // single-pass frame: the read-back was left in flight
+        const size_t nb = (size_t)F.tallyChunks * F.cntStride * sizeof(int);
+        for (int c = 0; c < F.tallyChunks; c++) {
+            const int *hc = (const int *)F.pinned + (size_t)c * F.cntStride;
+            for (int k = 0; k <= R; k++) {
+                F.shaded += (unsigned long long)hc[(R + 2) + k];
+                if (k > 0) F.closestDeep += (unsigned long long)hc[k];
+                else F.live0 += (unsigned long long)hc[0];
+            }
+        }
+        if (!F.fast) std::memcpy(F.hcnt, (char *)F.pinned + nb, sizeof(F.hcnt));
+        F.tallyChunks = 0;
+    }
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         unsigned long long hcnt[2 * C_COUNT];
-        std::memcpy(hcnt, hcntHost, sizeof(hcnt));
-        if (opts->collect_stats) {
+        std::memcpy(hcnt, F.hcnt, sizeof(hcnt));
+        if (F.collect) {
             // primary rays answered by k_raygen (they miss the scene root box): one query and one OSM:460 test each
-            const unsigned long long culled = livePaths - live0;
+            const unsigned long long culled = F.livePaths - F.live0;
             hcnt[C_RAYS] += culled;
             hcnt[C_SCENE_NODES] += culled;
         } else {
             std::memset(hcnt, 0, sizeof(hcnt));
-            hcnt[C_RAYS] = livePaths + closestDeep;
-            hcnt[C_HITS] = shaded;
-            hcnt[C_COUNT + C_RAYS] = shaded * (unsigned long long)nL;
+            hcnt[C_RAYS] = F.livePaths + F.closestDeep;
+            hcnt[C_HITS] = F.shaded;
+            hcnt[C_COUNT + C_RAYS] = F.shaded * (unsigned long long)F.nL;
         }
-        fill_stats(stats, hcnt, shaded, validPixels);
-        if (!opts->collect_stats) stats->algorithmic_bytes = 0;   // needs the counting pass
+        fill_stats(stats, hcnt, F.shaded, F.validPixels);
+        if (!F.collect) stats->algorithmic_bytes = 0;   // needs the counting pass
         float ms = 0;
-        HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+        HIPCHECK(hipEventElapsedTime(&ms, F.events[0], F.events[1]));
         stats->ms_total = ms;
         double mi = 0;
-        for (auto &pr : pairs) {
+        for (auto &pr : F.pairs) {
             float t = 0;
-            HIPCHECK(hipEventElapsedTime(&t, s->events[pr.first], s->events[pr.second]));
+            HIPCHECK(hipEventElapsedTime(&t, F.events[pr.first], F.events[pr.second]));
             mi += t;
         }
         stats->ms_intersect = mi;
-        stats->intersect_launches = (uint32_t)pairs.size();
+        stats->intersect_launches = (uint32_t)F.pairs.size();
     }
     return XRT_OK;
+}
+
+int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts, uint32_t *d_out,
+                float *d_outF32, hipStream_t st, xrt_stats *stats) {
+    int rc = frame_begin(s, s->frames[0], cam, lights, nLights, opts, d_out, d_outF32, st);
+    if (rc != XRT_OK) return rc;
+    return frame_finish(s, s->frames[0], stats);
 }
 
 int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hits, int mode, int meshId, hipStream_t st, xrt_stats *stats,
@@ -612,7 +711,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
 
 int xrt_scene_destroy(xrt_scene *scene) {
     if (!scene) return XRT_OK;
-    if (scene->busy.load()) return fail(XRT_E_BUSY, "xrt_scene_destroy: a render is in flight");
+    if (in_flight(scene)) return fail(XRT_E_BUSY, "xrt_scene_destroy: a render is in flight");
     delete scene;
     return XRT_OK;
 }
@@ -620,7 +719,7 @@ int xrt_scene_destroy(xrt_scene *scene) {
 int xrt_scene_add_mesh(xrt_scene *scene, const float *v, const float *n, const float *uv, const float *surf_n, const float *color,
                        int32_t ntri, const xrt_material *material, const float bbox[6], int32_t *mesh_id_out) {
     if (!scene || !mesh_id_out) return fail(XRT_E_INVALID_ARG, "xrt_scene_add_mesh: null argument");
-    if (scene->busy.load()) return fail(XRT_E_BUSY, "scene is rendering");
+    if (in_flight(scene)) return fail(XRT_E_BUSY, "scene is rendering");
     std::string err;
     int id = scene->hs.add_mesh(v, n, uv, surf_n, color, ntri, material, bbox, err);
     if (id < 0) return fail(XRT_E_INVALID_ARG, "%s", err.c_str());
@@ -632,7 +731,7 @@ int xrt_scene_add_mesh(xrt_scene *scene, const float *v, const float *n, const f
 int xrt_scene_add_object(xrt_scene *scene, const int32_t *mesh_ids, int32_t n_meshes, const float world[16], const float inv_world[16],
                          const float bbox[6], const float world_bbox[6], int32_t *object_id_out) {
     if (!scene || !object_id_out) return fail(XRT_E_INVALID_ARG, "xrt_scene_add_object: null argument");
-    if (scene->busy.load()) return fail(XRT_E_BUSY, "scene is rendering");
+    if (in_flight(scene)) return fail(XRT_E_BUSY, "scene is rendering");
     std::string err;
     int id = scene->hs.add_object(mesh_ids, n_meshes, world, inv_world, bbox, world_bbox, err);
     if (id < 0) return fail(XRT_E_INVALID_ARG, "%s", err.c_str());
@@ -643,7 +742,7 @@ int xrt_scene_add_object(xrt_scene *scene, const int32_t *mesh_ids, int32_t n_me
 
 int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_threshold) {
     if (!scene) return fail(XRT_E_INVALID_ARG, "xrt_scene_build: null scene");
-    if (scene->busy.load()) return fail(XRT_E_BUSY, "scene is rendering");
+    if (in_flight(scene)) return fail(XRT_E_BUSY, "scene is rendering");
     std::string err;
     scene->resident = false;
     if (!scene->hs.build(mesh_threshold, scene_threshold, err)) return fail(XRT_E_UNSUPPORTED, "%s", err.c_str());
@@ -737,7 +836,8 @@ int xrt_render(xrt_scene *scene, const xrt_camera *camera, const xrt_light *ligh
     if (!camera || !opts || !rgba_out) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
     if (opts->shard_count > 1) return fail(XRT_E_INVALID_ARG, "xrt_render writes a whole frame; use xrt_render_device for shards");
     BusyGuard guard(scene);
-    if (!guard.owned) return fail(XRT_E_BUSY, "Current render operation not finished.");   // RT:62-63
+    if (!guard.owned || scene->frames[0].pending || scene->frames[1].pending)
+        return fail(XRT_E_BUSY, "Current render operation not finished.");   // RT:62-63
     const size_t px = (size_t)camera->vp_width * (size_t)camera->vp_height;
     if (camera->vp_width <= 0 || camera->vp_height <= 0) return fail(XRT_E_INVALID_ARG, "viewport must be positive");
     if ((rc = scene->outRGBA.ensure(px))) return rc;
@@ -756,9 +856,33 @@ int xrt_render_device(xrt_scene *scene, const xrt_camera *camera, const xrt_ligh
     if (rc != XRT_OK) return rc;
     if (!camera || !opts || !d_rgba_out) return fail(XRT_E_INVALID_ARG, "xrt_render_device: null argument");
     BusyGuard guard(scene);
-    if (!guard.owned) return fail(XRT_E_BUSY, "Current render operation not finished.");
+    if (!guard.owned || scene->frames[0].pending || scene->frames[1].pending) return fail(XRT_E_BUSY, "Current render operation not finished.");
     hipStream_t st = stream ? (hipStream_t)stream : scene->stream;
     return render_impl(scene, camera, lights, n_lights, opts, (uint32_t *)d_rgba_out, nullptr, st, stats_out);
+}
+
+int xrt_render_device_begin(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights, int32_t n_lights, const xrt_render_opts *opts,
+                            void *d_rgba_out, void *stream, int32_t *ticket_out) {
+    int rc = need_device(scene, "xrt_render_device_begin");
+    if (rc != XRT_OK) return rc;
+    if (!camera || !opts || !d_rgba_out || !ticket_out) return fail(XRT_E_INVALID_ARG, "xrt_render_device_begin: null argument");
+    BusyGuard guard(scene);
+    if (!guard.owned) return fail(XRT_E_BUSY, "Current render operation not finished.");
+    const int slot = !scene->frames[0].pending ? 0 : (!scene->frames[1].pending ? 1 : -1);
+    if (slot < 0) return fail(XRT_E_BUSY, "two frames are already in flight; call xrt_render_device_end first");
+    hipStream_t st = stream ? (hipStream_t)stream : scene->stream;
+    if ((rc = frame_begin(scene, scene->frames[slot], camera, lights, n_lights, opts, (uint32_t *)d_rgba_out, nullptr, st))) return rc;
+    *ticket_out = slot;
+    return XRT_OK;
+}
+
+int xrt_render_device_end(xrt_scene *scene, int32_t ticket, xrt_stats *stats_out) {
+    int rc = need_device(scene, "xrt_render_device_end");
+    if (rc != XRT_OK) return rc;
+    if (ticket < 0 || ticket > 1) return fail(XRT_E_INVALID_ARG, "xrt_render_device_end: unknown ticket");
+    BusyGuard guard(scene);
+    if (!guard.owned) return fail(XRT_E_BUSY, "Current render operation not finished.");
+    return frame_finish(scene, scene->frames[ticket], stats_out);
 }
 
 int xrt_shard_layout(int32_t width, int32_t height, int32_t shard_count, int32_t *tiles_x_out, int32_t *tiles_y_out, int32_t *tiles_per_rank_out) {
