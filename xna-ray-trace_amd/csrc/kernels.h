@@ -30,6 +30,11 @@ struct IntersectArgs {
     int mode, meshId;
     int firstBatch;     // rays of the static first batch of every wave
     int refillMin, nodeBurst, leafBurst;   // scheduling knobs of the persistent loop (defaults in xrt_api.cpp; XRT_TUNE overrides)
+    // optional second segment traced by the same launch: rays2[0 .. (*nDev2) * nMul2) -> hits2 (no index list)
+    const xrt_ray *rays2 = nullptr;
+    xrt_hit *hits2 = nullptr;
+    const int *nDev2 = nullptr;
+    int nMul2 = 0, nCap2 = 0;
 };
 
 // reference-work counters accumulated on the device (same order as the head of xrt_stats)
@@ -37,32 +42,24 @@ enum { C_RAYS = 0, C_HITS, C_SCENE_NODES, C_INSTANCES, C_MESH_AABB, C_MESH_QUERI
 
 constexpr int FLAG_MISS = 0, FLAG_HIT = 1, FLAG_TRANSPARENT = 2;
 
-// Ray-tree bookkeeping of scenes with Transparent materials (RT:586-702): heap node id and the refraction
-// index of the medium each ray travels in.  heap == 0: plain reflection chain, node == generation.
-struct TreeArgs {
-    int heap;
-    int cap;         // capacity of the next generation's ray buffers
-    int *overflow;   // set when a generation does not fit (the host retries the chunk with fewer paths)
-    const int *rayNode;
-    const float *rayRef;
-    int *nextNode;
-    float *nextRef;
-    float *lvlAlpha;
-};
+// One shaded hit of a generation: which ray found it, the path (pixel sample) it belongs to and its node in the
+// ray tree (== generation for a plain reflection chain).
+struct alignas(16) SlotRec { int ray, path, node, pad; };
 
-struct FrameBuffers {
-    xrt_ray *rays[2];
-    int *rayPath[2];
-    xrt_hit *hits;
-    xrt_ray *shadowRays;
-    xrt_hit *shadowHits;
-    int *shadowSrc;
-    f4 *lvlA, *lvlB;          // [(R+1) * P]
-    uint32_t *sampleColor;    // [P]
-    float *sampleF32;         // [3 P] or null
-    int *cnt;                 // ray count per level  [R+2]
-    int *scnt;                // shaded hits per level [R+1]
-    unsigned *queues;         // one per intersect launch [2 (R+1)]
+// k_shade: part A works on generation `level`, part B on generation level-1 (kernels.hip).
+struct ShadeArgs {
+    int level, doA, doB;
+    int maxReflections, P, heap;
+    int *overflow;            // set when a generation does not fit (the host retries the chunk with fewer paths)
+    // part A
+    const xrt_ray *rays; const xrt_hit *hits;
+    const int *nDev; int nHost, cap;
+    const int *index, *rayPath, *rayNode; const float *rayRef;
+    SlotRec *slotOut; int *scnt; int shadowCap; xrt_ray *shadowRays;
+    xrt_ray *nextRays; int *nextPath, *nextNode; float *nextRef; int *nextCnt; int nextCap;
+    // part B
+    const xrt_hit *hitsPrev; const SlotRec *slotPrev; const int *scntPrev; const xrt_hit *shadowHits;
+    f4 *lvlA, *lvlB; float *lvlAlpha;
 };
 
 int  intersect_stack_capacity(int needed);   // smallest compiled capacity >= needed, or -1
@@ -71,12 +68,7 @@ void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeede
 int  intersect_blocks_per_cu(int stackNeeded, int mode);
 void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long *counters, hipStream_t st);
 void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase, hipStream_t st, hipEvent_t startEvent = nullptr);
-void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
-                    const int *index, const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P, int level,
-                    int cap, int *overflow, hipStream_t st);
-void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath,
-                    const int *scnt, const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB, xrt_ray *nextRays,
-                    int *nextPath, int *nextCnt, int P, int level, int maxReflections, const TreeArgs &T, hipStream_t st);
+void launch_shade(const SceneView &S, const ShadeView &V, const ShadeArgs &X, hipStream_t st);
 void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections, uint32_t *sampleColor,
                          float *sampleF32, hipStream_t st);
 // compose can write the framebuffer itself when there is one sample per pixel

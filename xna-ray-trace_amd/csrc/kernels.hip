@@ -7,7 +7,7 @@
 //                 Branchy scalar fp32 — no MFMA by design.
 //   k_count       the REFERENCE algorithm's work counters, untimed.
 //   k_raygen      RayTracer.Render ray generation (RT:410-421) in 64x8 tile order.
-//   k_shade_a/b   CastRay shading (RT:516-584, 708-727), IsLightPathObstructed (RT:465-502), lights.
+//   k_shade       CastRay shading (RT:516-584, 708-727), IsLightPathObstructed (RT:465-502), lights.
 //   k_compose     the recursion's return path: per-level RGBA8 quantisation (RT:584,705,726,732).
 //   k_resolve     supersample averaging (RT:309) and the framebuffer write (RT:425).
 //
@@ -81,8 +81,13 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
     __shared__ unsigned stk[4 * T * 64];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     LdsStack st{&stk[wave * T * 64 + lane]};
-    int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
-    if (A.nCap > 0 && n > A.nCap) n = A.nCap;   // an overflowed generation is discarded by the host; stay inside the buffers
+    int n1 = A.nDev ? (*A.nDev) * A.nMul : A.n;
+    if (A.nCap > 0 && n1 > A.nCap) n1 = A.nCap;   // an overflowed generation is discarded by the host; stay inside the buffers
+    // optional second segment (the shadow rays of the previous generation ride in the same launch as this generation's
+    // closest-hit rays): ray g >= n1 is rays2[g - n1]
+    int n2 = A.nDev2 ? (*A.nDev2) * A.nMul2 : 0;
+    if (n2 > A.nCap2) n2 = A.nCap2;
+    const int n = n1 + n2;
     Lane L;
     L.state = ST_IDLE;
     // Work distribution.  The first 64 rays of every wave are static (no atomic: a grid-wide burst on one word
@@ -125,9 +130,12 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
                     const int take = min(nIdle, batchEnd - batchNext);
                     const int rank = lanes_below(idle);
                     if (L.state == ST_IDLE && rank < take) {
-                        const int idx = A.index ? A.index[batchNext + rank] : batchNext + rank;
+                        const int g = batchNext + rank;
+                        int idx = A.index ? A.index[g] : g;
+                        const xrt_ray *src = A.rays + idx;
+                        if (g >= n1) { src = A.rays2 + (g - n1); idx = ~(g - n1); }   // answers of segment 2 go to hits2
                         v3 o, d; int im, it;
-                        load_ray(A.rays + idx, o, d, im, it);
+                        load_ray(src, o, d, im, it);
                         if (im == DEAD_RAY) { L.rayIndex = idx; L.sfound = 0; L.state = ST_FINISH; }
                         else lane_begin(L, S, o, d, im, it, idx, M, A.meshId);
                     }
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
             if (L.state == ST_LEAF) advance_leaf(L, S);
         }
         if (L.state == ST_FINISH) {
-            store_hit(A.hits + L.rayIndex, lane_result(L, S, M));
+            store_hit(L.rayIndex < 0 ? A.hits2 + ~L.rayIndex : A.hits + L.rayIndex, lane_result(L, S, M));
             L.state = ST_IDLE;
         }
     }
@@ -456,49 +464,6 @@ __device__ __forceinline__ void light_dir(const LightRec &L, v3 world, v3 &dir, 
     }
 }
 
-// Stage A of CastRay for one generation of rays: misses terminate their path (RT:729-733); every hit
-// emits one shadow ray per light (RT:535-537 -> RT:482-485), compacted with one atomic per wave.
-__global__ __launch_bounds__(APPEND_BLOCK) void k_shade_a(SceneView S, ShadeView V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev,
-                                                 int nHost, const int *index, const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays,
-                                                 int *shadowSrc, int *scnt, int P, int level, int cap, int *overflow) {
-    __shared__ int ldsCounts[17];
-    int n = nDev ? *nDev : nHost;
-    if (n > cap) n = cap;
-    const int stride = (int)(gridDim.x * blockDim.x);
-    const int rounds = (n + stride - 1) / stride;
-    for (int it = 0; it < rounds; it++) {
-        const int j = it * stride + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-        int i = j;
-        int hit = 0, object, mesh = 0, tri = 0;
-        float u = 0, v = 0, d = 0;
-        v3 w = mk(0, 0, 0);
-        int p = 0;
-        if (j < n) {
-            if (index) i = index[j];   // generation 0: only the rays that reached the scene's root box were traced
-            load_hit(hits + i, hit, object, mesh, tri, u, v, d, w);
-            p = rayPath ? rayPath[i] : i;
-            const int node = rayNode ? rayNode[i] : level;   // chain of reflections: node == generation; ray tree: heap index
-            if (!hit) lvlB[(size_t)node * P + p] = f4{0, 0, 0, i2f(FLAG_MISS)};
-        }
-        const int slot = block_append(scnt, hit != 0, ldsCounts);
-        if (hit && slot >= cap) { *overflow = 1; hit = 0; }   // more rays than the chunk's buffers hold: the host retries with fewer paths
-        if (hit) {
-            shadowSrc[slot] = i;
-            for (int l = 0; l < V.nLights; l++) {
-                v3 dir; float dist;
-                light_dir(V.lights[l], w, dir, dist);
-                store_ray(shadowRays + (size_t)slot * V.nLights + l, w, dir, mesh, tri);   // ignore = shaded triangle (RT:485)
-            }
-        }
-    }
-}
-void launch_shade_a(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *nDev, int nHost,
-                    const int *index, const int *rayPath, const int *rayNode, f4 *lvlB, xrt_ray *shadowRays, int *shadowSrc, int *scnt, int P,
-                    int level, int cap, int *overflow, hipStream_t st) {
-    hipLaunchKernelGGL(k_shade_a, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, rays, hits, nDev, nHost, index, rayPath, rayNode, lvlB, shadowRays,
-                       shadowSrc, scnt, P, level, cap, overflow);
-}
-
 // MAT:71-160 LookupUV: address mode + point sample
 __device__ __forceinline__ v3 lookup_uv(const ShadeView &V, const MaterialRec &M, float ux, float uy) {
     if (V.addressMode == XRT_ADDRESS_WRAP) {   // MAT:125-136
@@ -546,39 +511,36 @@ __device__ __forceinline__ v3 lookup_uv(const ShadeView &V, const MaterialRec &M
     return mk((float)((argb >> 16) & 0xffu) * BYTE_RECIPROCAL, (float)((argb >> 8) & 0xffu) * BYTE_RECIPROCAL, (float)(argb & 0xffu) * BYTE_RECIPROCAL);
 }
 
-// Stage B: light accumulation with the shadow answers (RT:534-542), surface colour (RT:568-581 / 711-724),
-// the level record the return path needs, and the reflection ray of the next generation (RT:545-559).
-__global__ __launch_bounds__(APPEND_BLOCK) void k_shade_b(SceneView S, ShadeView V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath,
-                                                 const int *scnt, const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB,
-                                                 xrt_ray *nextRays, int *nextPath, int *nextCnt, int P, int level, int maxReflections,
-                                                 TreeArgs T) {
+// CastRay's shading for one step of the wavefront.  After intersect launch #k two independent pieces of work exist and
+// one kernel does both:
+//   part A, generation k   : the closest-hit answers.  Misses end their path (RT:729-733); every hit takes a slot, emits one
+//                            shadow ray per light (RT:535-537 -> RT:482-485) and -- the reflected / refracted directions
+//                            depend on the hit alone, not on the lighting -- the rays of generation k+1 (RT:545-559,
+//                            RT:656-698).  Launch #k+1 traces both sets together.
+//   part B, generation k-1 : the shadow answers of launch #k: light accumulation (RT:534-542), surface colour
+//                            (RT:568-581 / 711-724) and the level record the return path (k_compose) needs.
+__global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V, ShadeArgs X) {
     __shared__ int ldsCounts[17];
-    int n = *scnt;
-    if (n > T.cap) n = T.cap;
     const int stride = (int)(gridDim.x * blockDim.x);
-    const int rounds = (n + stride - 1) / stride;
-    for (int it = 0; it < rounds; it++) {
-        const int s = it * stride + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-        const bool valid = s < n;
-        v3 w = mk(0, 0, 0), normal = mk(0, 0, 0), rdir = mk(0, 0, 0), tdir = mk(0, 0, 0);
-        int mesh = 0, tri = 0, p = 0, node = level;
-        float curRef = 1.0f, n2 = 1.0f;
-        bool refracts = false;
-        if (valid) {
-            const int i = shadowSrc[s];
-            int hit, object; float u, v, d;
-            load_hit(hits + i, hit, object, mesh, tri, u, v, d, w);
-            p = rayPath ? rayPath[i] : i;
+    const int tid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const size_t P = (size_t)X.P;
+    if (X.doB) {
+        int n = *X.scntPrev;
+        if (n > X.shadowCap) n = X.shadowCap;
+        for (int s = tid; s < n; s += stride) {
+            const SlotRec rec = X.slotPrev[s];
+            int hit, object, mesh, tri; float u, v, d; v3 w;
+            load_hit(X.hitsPrev + rec.ray, hit, object, mesh, tri, u, v, d, w);
             const int gtri = V.meshes[mesh].triBase + tri;
             const MaterialRec M = V.materials[V.meshes[mesh].material];
-            normal = fragment_normal(V, gtri, M.flags, u, v);
+            const v3 normal = fragment_normal(V, gtri, M.flags, u, v);
             v3 lightResult = mk(0, 0, 0);
             for (int l = 0; l < V.nLights; l++) {
                 const LightRec &Lt = V.lights[l];
                 v3 dir; float dist;
                 light_dir(Lt, w, dir, dist);
                 int sh, sobj, smesh, stri; float su, sv, sd; v3 sw;
-                load_hit(shadowHits + (size_t)s * V.nLights + l, sh, sobj, smesh, stri, su, sv, sd, sw);
+                load_hit(X.shadowHits + (size_t)s * V.nLights + l, sh, sobj, smesh, stri, su, sv, sd, sw);
                 float lightAmount = 0.0f;   // RT:485-501
                 if (sh && sd < dist) {
                     const MaterialRec SM = V.materials[V.meshes[smesh].material];
@@ -599,54 +561,86 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade_b(SceneView S, ShadeView
                 f4 c = sr[3];
                 surf = mk(c.x, c.y, c.z);
             }
-            if (T.heap) { node = T.rayNode ? T.rayNode[i] : 0; curRef = T.rayRef ? T.rayRef[i] : 1.0f; }   // generation 0: root, in vacuum (RT:424)
             const bool transparent = (M.flags & MAT_TRANSPARENT) != 0;
-            lvlA[(size_t)node * P + p] = f4{lightResult.x, lightResult.y, lightResult.z, M.reflectiveness};
-            lvlB[(size_t)node * P + p] = f4{surf.x, surf.y, surf.z, i2f(FLAG_HIT | (transparent ? FLAG_TRANSPARENT : 0))};
-            if (T.heap) T.lvlAlpha[(size_t)node * P + p] = sr[3].w;   // triangle.color.W (RT:699)
-            if (level < maxReflections) {
-                v3 o, d; int im, itri;
-                load_ray(rays + i, o, d, im, itri);
-                rdir = normalize(reflect(d, normal));   // RT:549-550
-                if (T.heap && transparent) {   // RT:656-694: Snell refraction, the System.Math calls in double
+            const size_t at = (size_t)rec.node * P + (size_t)rec.path;
+            X.lvlA[at] = f4{lightResult.x, lightResult.y, lightResult.z, M.reflectiveness};
+            X.lvlB[at] = f4{surf.x, surf.y, surf.z, i2f(FLAG_HIT | (transparent ? FLAG_TRANSPARENT : 0))};
+            if (X.heap) X.lvlAlpha[at] = sr[3].w;   // triangle.color.W (RT:699)
+        }
+    }
+    if (!X.doA) return;
+    int n = X.nDev ? *X.nDev : X.nHost;
+    if (n > X.cap) n = X.cap;
+    const bool emitNext = X.level < X.maxReflections;   // grid-uniform
+    const int rounds = (n + stride - 1) / stride;
+    for (int it = 0; it < rounds; it++) {
+        const int j = it * stride + tid;
+        int i = j, hit = 0, object, mesh = 0, tri = 0, p = 0, node = X.level;
+        float u = 0, v = 0, d = 0, curRef = 1.0f, n2 = 1.0f;
+        v3 w = mk(0, 0, 0), rdir = mk(0, 0, 0), tdir = mk(0, 0, 0);
+        bool refracts = false;
+        if (j < n) {
+            if (X.index) i = X.index[j];   // generation 0: only the rays that reached the scene's root box were traced
+            load_hit(X.hits + i, hit, object, mesh, tri, u, v, d, w);
+            p = X.rayPath ? X.rayPath[i] : i;
+            if (X.heap) { node = X.rayNode ? X.rayNode[i] : 0; curRef = X.rayRef ? X.rayRef[i] : 1.0f; }   // generation 0: root, in vacuum (RT:424)
+            if (!hit) X.lvlB[(size_t)node * P + p] = f4{0, 0, 0, i2f(FLAG_MISS)};
+        }
+        const int slot = block_append(X.scnt, hit != 0, ldsCounts);
+        if (hit && slot >= X.shadowCap) { *X.overflow = 1; hit = 0; }   // more rays than the chunk's buffers hold: the host retries with fewer paths
+        if (hit) {
+            X.slotOut[slot] = SlotRec{i, p, node, 0};
+            for (int l = 0; l < V.nLights; l++) {
+                v3 dir; float dist;
+                light_dir(V.lights[l], w, dir, dist);
+                store_ray(X.shadowRays + (size_t)slot * V.nLights + l, w, dir, mesh, tri);   // ignore = shaded triangle (RT:485)
+            }
+            if (emitNext) {
+                const MaterialRec M = V.materials[V.meshes[mesh].material];
+                const v3 normal = fragment_normal(V, V.meshes[mesh].triBase + tri, M.flags, u, v);
+                v3 o, dd; int im, itri;
+                load_ray(X.rays + i, o, dd, im, itri);
+                rdir = normalize(reflect(dd, normal));   // RT:549-550
+                if (X.heap && (M.flags & MAT_TRANSPARENT)) {   // RT:656-694: Snell refraction, the System.Math calls in double
                     float n1;
                     if (curRef == M.refractionIndex) { n1 = 1.0f; n2 = curRef; }
                     else { n1 = M.refractionIndex; n2 = 1.0f; }
-                    const float cos1 = dot(normal, neg(d));
+                    const float cos1 = dot(normal, neg(dd));
                     const double ratio = (double)(n1 / n2), c1 = (double)cos1;
                     const float cos2 = (float)sqrt(1 - (ratio * ratio) * (1 - (c1 * c1)));   // Math.Pow(x, 2.0) == x*x exactly here
                     const float q = n1 / n2;
-                    const v3 a = scale(d, q), b = scale(normal, q * cos1 - cos2);
+                    const v3 a = scale(dd, q), b = scale(normal, q * cos1 - cos2);
                     tdir = normalize(cos1 >= 0 ? add(a, b) : sub(a, b));
                     refracts = true;
                 }
             }
         }
-        if (level < maxReflections) {   // grid-uniform
-            const int slot = block_append(nextCnt, valid, ldsCounts);
-            if (valid && slot >= T.cap) *T.overflow = 1;
-            else if (valid) {
-                store_ray(nextRays + slot, w, rdir, mesh, tri);   // origin = result.triangle (RT:559)
-                nextPath[slot] = p;
-                if (T.heap) { T.nextNode[slot] = 2 * node + 1; T.nextRef[slot] = curRef; }
+        if (!emitNext) continue;
+        if (!X.heap) {   // chain of reflections: the ray of generation k+1 sits at its parent's slot
+            if (hit) {
+                store_ray(X.nextRays + slot, w, rdir, mesh, tri);   // origin = result.triangle (RT:559)
+                X.nextPath[slot] = p;
             }
-            if (T.heap) {   // the refracted ray of RT:698 continues in the medium with index n2
-                const int slot2 = block_append(nextCnt, refracts, ldsCounts);
-                if (refracts && slot2 >= T.cap) *T.overflow = 1;
-                else if (refracts) {
-                    store_ray(nextRays + slot2, w, tdir, mesh, tri);
-                    nextPath[slot2] = p;
-                    T.nextNode[slot2] = 2 * node + 2; T.nextRef[slot2] = n2;
-                }
-            }
+            continue;
+        }
+        const int slot1 = block_append(X.nextCnt, hit != 0, ldsCounts);
+        if (hit && slot1 >= X.nextCap) *X.overflow = 1;
+        else if (hit) {
+            store_ray(X.nextRays + slot1, w, rdir, mesh, tri);
+            X.nextPath[slot1] = p;
+            X.nextNode[slot1] = 2 * node + 1; X.nextRef[slot1] = curRef;
+        }
+        const int slot2 = block_append(X.nextCnt, refracts, ldsCounts);   // the refracted ray of RT:698 continues in the medium with index n2
+        if (refracts && slot2 >= X.nextCap) *X.overflow = 1;
+        else if (refracts) {
+            store_ray(X.nextRays + slot2, w, tdir, mesh, tri);
+            X.nextPath[slot2] = p;
+            X.nextNode[slot2] = 2 * node + 2; X.nextRef[slot2] = n2;
         }
     }
 }
-void launch_shade_b(const SceneView &S, const ShadeView &V, const xrt_ray *rays, const xrt_hit *hits, const int *rayPath, const int *scnt,
-                    const int *shadowSrc, const xrt_hit *shadowHits, f4 *lvlA, f4 *lvlB, xrt_ray *nextRays, int *nextPath, int *nextCnt,
-                    int P, int level, int maxReflections, const TreeArgs &T, hipStream_t st) {
-    hipLaunchKernelGGL(k_shade_b, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, rays, hits, rayPath, scnt, shadowSrc, shadowHits, lvlA, lvlB, nextRays,
-                       nextPath, nextCnt, P, level, maxReflections, T);
+void launch_shade(const SceneView &S, const ShadeView &V, const ShadeArgs &X, hipStream_t st) {
+    hipLaunchKernelGGL(k_shade, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, X);
 }
 
 // The return path of the CastRay recursion: deepest generation first, one RGBA8 quantisation per level.

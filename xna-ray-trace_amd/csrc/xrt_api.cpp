@@ -85,8 +85,9 @@ struct xrt_scene {
     hipStream_t stream = nullptr;
     // per-frame work buffers
     DevBuf<xrt_ray> rays0, rays1, shadowRays, apiRays;
-    DevBuf<xrt_hit> hits, shadowHits, apiHits;
-    DevBuf<int> path0, path1, node0, node1, shadowSrc, cnts;
+    DevBuf<xrt_hit> hits, hits1, shadowHits, apiHits;
+    DevBuf<int> path0, path1, node0, node1, index0, cnts;
+    DevBuf<SlotRec> slot0, slot1;
     DevBuf<float> ref0, ref1, lvlAlpha;
     DevBuf<unsigned> queues;
     DevBuf<f4> lvlA, lvlB;
@@ -136,7 +137,7 @@ struct xrt_scene {
             childDfs.release(); srefs.release(); objMesh.release(); meshes.release();
             objects.release(); materials.release(); texels.release();
             rays0.release(); rays1.release(); shadowRays.release(); apiRays.release(); hits.release();
-            shadowHits.release(); apiHits.release(); path0.release(); path1.release(); shadowSrc.release();
+            shadowHits.release(); apiHits.release(); path0.release(); path1.release(); hits1.release(); slot0.release(); slot1.release(); index0.release();
             node0.release(); node1.release(); ref0.release(); ref1.release(); lvlAlpha.release();
             cnts.release(); queues.release(); lvlA.release(); lvlB.release(); sampleColor.release();
             outRGBA.release(); sampleF32.release(); outF32.release(); lights.release(); counters.release();
@@ -239,7 +240,7 @@ int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g
     return XRT_OK;
 }
 
-// The frame: for every chunk of paths  raygen -> [intersect -> shade_a -> intersect(shadow) -> shade_b] x (R+1) -> compose,
+// The frame: for every chunk of paths  raygen -> [intersect(closest k + shadow k-1) -> shade(A: k, B: k-1)] x (R+2) -> compose,
 // then resolve (pixel grid, fixed 16 sub-rays) or the quadrant levels of adaptive supersampling (RT:170-311).
 int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats);
 
@@ -295,7 +296,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const bool fuseResolve = !adaptive && !heap && g.samples == 1;   // k_compose writes the framebuffer itself
     // buffers
     if ((rc = s->rays0.ensure(rayCap)) || (rc = s->rays1.ensure(rayCap)) || (rc = s->hits.ensure(rayCap)) || (rc = s->path0.ensure(rayCap)) ||
-        (rc = s->path1.ensure(rayCap)) || (rc = s->shadowSrc.ensure(rayCap)) || (rc = s->shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
+        (rc = s->path1.ensure(rayCap)) || (rc = s->hits1.ensure(rayCap)) || (rc = s->slot0.ensure(rayCap)) ||
+        (rc = s->slot1.ensure(rayCap)) || (rc = s->index0.ensure(P)) || (rc = s->shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
         (rc = s->shadowHits.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = s->lvlA.ensure((size_t)P * nodes)) ||
         (rc = s->lvlB.ensure((size_t)P * nodes)) || (rc = s->sampleColor.ensure(P)) || (rc = s->lights.ensure(nL > 0 ? nL : 1)) ||
         (rc = s->counters.ensure(2 * C_COUNT + 8)))
@@ -353,45 +355,55 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // One pass = trace `total` paths produced by generator `gp`; after every chunk `post(Pc, pathBase)` consumes sampleColor.
     int *overflowFlag = reinterpret_cast<int *>(s->counters.p + 2 * C_COUNT) + 12;   // spare counter words (zeroed above)
 
-    // Enqueue one chunk of `Pc` paths starting at `pathBase`: raygen, the generations, compose.
+    // Enqueue one chunk of `Pc` paths starting at `pathBase`: raygen, R+2 rounds of (intersect, shade), compose.
+    // Intersect launch #k traces the closest-hit rays of generation k together with the shadow rays of generation k-1
+    // (both exist once k_shade has looked at the hits of generation k-1); k_shade #k then shades generation k-1 with the
+    // shadow answers and turns the hits of generation k into shadow rays and the rays of generation k+1.
     auto enqueue_chunk = [&](const RayGenParams &gp, int *cnt, unsigned *q, int Pc, long long pathBase) -> int {
         int *scnt = cnt + (R + 2);
-        // cnt[0] counts the primary rays that reach the scene's root box; paths[1] doubles as their index list
-        launch_raygen(gp, S, rays[0], s->lvlB.p, paths[1], cnt, Pc, pathBase, st, fast ? e0 : nullptr);
-        for (int k = 0; k <= R; k++) {
-            const int cur = k & 1, nxt = cur ^ 1;
-            IntersectArgs A;
-            A.rays = rays[cur]; A.hits = s->hits.p; A.index = k == 0 ? paths[1] : nullptr; A.nDev = cnt + k; A.nMul = 1; A.n = Pc;
-            A.nCap = (int)rayCap;
-            A.queue = q + 2 * k; A.mode = s->sceneMode; A.meshId = 0;
-            A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.firstBatch = s->firstBatch;
-            hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
-            if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
-            pairs.push_back({ev, ev + 1}); ev += 2;
-            launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st, a0, a1);
-            if (opts->collect_stats) launch_count(S, A, s->counters.p, st);   // generation 0: the live list; culled rays are added below
-            launch_shade_a(S, V, rays[cur], s->hits.p, cnt + k, Pc, k == 0 ? paths[1] : nullptr, k == 0 ? nullptr : paths[cur],
-                           (heap && k > 0) ? nodesOf[cur] : nullptr, s->lvlB.p, s->shadowRays.p, s->shadowSrc.p, scnt + k, P, k, (int)shadowCap,
-                           overflowFlag, st);
-            if (nL > 0) {
-                IntersectArgs B;
-                B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.index = nullptr; B.nDev = scnt + k; B.nMul = nL; B.n = 0;
-                B.nCap = (int)shadowCap * nL;
-                B.queue = q + 2 * k + 1; B.mode = s->sceneMode; B.meshId = 0;
-                B.refillMin = s->tune[0]; B.nodeBurst = s->tune[1]; B.leafBurst = s->tune[2]; B.firstBatch = s->firstBatch;
-                hipEvent_t b0 = get_event(F.events, ev), b1 = get_event(F.events, ev + 1);
-                if (!b0 || !b1) return fail(XRT_E_HIP, "hipEventCreate failed");
-                pairs.push_back({ev, ev + 1}); ev += 2;
-                launch_intersect(S, B, s->stackNeeded, persistent_grid(s, -1), st, b0, b1);
-                if (opts->collect_stats) launch_count(S, B, s->counters.p + C_COUNT, st);
+        // cnt[0] counts the primary rays that reach the scene's root box; index0 lists them
+        launch_raygen(gp, S, rays[0], s->lvlB.p, s->index0.p, cnt, Pc, pathBase, st, fast ? e0 : nullptr);
+        xrt_hit *hitsOf[2] = {s->hits.p, s->hits1.p};
+        SlotRec *slotOf[2] = {s->slot0.p, s->slot1.p};
+        for (int k = 0; k <= R + 1; k++) {
+            const int cur = k & 1, prv = cur ^ 1;
+            const bool hasClosest = k <= R, hasShadow = k >= 1 && nL > 0;
+            // a reflection chain keeps the ray of generation k at its parent's slot: their number is scnt[k-1]
+            const int *nClosest = (k == 0 || heap) ? cnt + k : scnt + (k - 1);
+            IntersectArgs C, B;   // closest-hit segment, shadow segment
+            C.rays = rays[cur]; C.hits = hitsOf[cur]; C.index = k == 0 ? s->index0.p : nullptr; C.nDev = nClosest; C.nMul = 1; C.n = Pc;
+            C.nCap = (int)rayCap;
+            B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.index = nullptr; B.nDev = hasShadow ? scnt + (k - 1) : nullptr; B.nMul = nL; B.n = 0;
+            B.nCap = (int)shadowCap * nL;
+            for (IntersectArgs *a : {&C, &B}) {
+                a->queue = q + k; a->mode = s->sceneMode; a->meshId = 0;
+                a->refillMin = s->tune[0]; a->nodeBurst = s->tune[1]; a->leafBurst = s->tune[2]; a->firstBatch = s->firstBatch;
             }
-            TreeArgs T;
-            T.heap = heap ? 1 : 0;
-            T.cap = (int)rayCap; T.overflow = overflowFlag;
-            T.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; T.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
-            T.nextNode = heap ? nodesOf[nxt] : nullptr; T.nextRef = heap ? refOf[nxt] : nullptr; T.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
-            launch_shade_b(S, V, rays[cur], s->hits.p, k == 0 ? nullptr : paths[cur], scnt + k, s->shadowSrc.p, s->shadowHits.p, s->lvlA.p,
-                           s->lvlB.p, rays[nxt], paths[nxt], cnt + k + 1, P, k, R, T, st);
+            if (hasClosest || hasShadow) {
+                IntersectArgs A = hasClosest ? C : B;
+                if (hasClosest && hasShadow) { A.rays2 = B.rays; A.hits2 = B.hits; A.nDev2 = B.nDev; A.nMul2 = B.nMul; A.nCap2 = B.nCap; }
+                hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
+                if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
+                pairs.push_back({ev, ev + 1}); ev += 2;
+                launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st, a0, a1);
+                if (opts->collect_stats) {   // generation 0: the live list; culled rays are added in frame_finish
+                    if (hasClosest) launch_count(S, C, s->counters.p, st);
+                    if (hasShadow) launch_count(S, B, s->counters.p + C_COUNT, st);
+                }
+            }
+            ShadeArgs X;
+            std::memset(&X, 0, sizeof(X));
+            X.level = k; X.doA = hasClosest ? 1 : 0; X.doB = k >= 1 ? 1 : 0;
+            X.maxReflections = R; X.P = P; X.heap = heap ? 1 : 0; X.overflow = overflowFlag;
+            X.rays = rays[cur]; X.hits = hitsOf[cur]; X.nDev = nClosest; X.nHost = Pc; X.cap = (int)rayCap;
+            X.index = k == 0 ? s->index0.p : nullptr; X.rayPath = k == 0 ? nullptr : paths[cur];
+            X.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; X.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
+            X.slotOut = slotOf[cur]; X.scnt = scnt + k; X.shadowCap = (int)shadowCap; X.shadowRays = s->shadowRays.p;
+            X.nextRays = rays[prv]; X.nextPath = paths[prv]; X.nextNode = heap ? nodesOf[prv] : nullptr; X.nextRef = heap ? refOf[prv] : nullptr;
+            X.nextCnt = cnt + k + 1; X.nextCap = (int)rayCap;
+            X.hitsPrev = hitsOf[prv]; X.slotPrev = slotOf[prv]; X.scntPrev = k >= 1 ? scnt + (k - 1) : nullptr; X.shadowHits = s->shadowHits.p;
+            X.lvlA = s->lvlA.p; X.lvlB = s->lvlB.p; X.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
+            launch_shade(S, V, X, st);
         }
         if (heap) launch_compose_tree(s->lvlA.p, s->lvlB.p, s->lvlAlpha.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
         else {
@@ -418,7 +430,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     auto tally = [&](const int *hc) {
         for (int k = 0; k <= R; k++) {
             shaded += (unsigned long long)hc[(R + 2) + k];
-            if (k > 0) closestDeep += (unsigned long long)hc[k];
+            if (k > 0) closestDeep += (unsigned long long)(heap ? hc[k] : hc[(R + 2) + k - 1]);   // reflection chain: one ray per parent hit
             else live0 += (unsigned long long)hc[0];
         }
     };
@@ -588,7 +600,7 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
             const int *hc = (const int *)F.pinned + (size_t)c * F.cntStride;
             for (int k = 0; k <= R; k++) {
                 F.shaded += (unsigned long long)hc[(R + 2) + k];
-                if (k > 0) F.closestDeep += (unsigned long long)hc[k];
+                if (k > 0) F.closestDeep += (unsigned long long)hc[(R + 2) + k - 1];   // single-pass frames have no ray tree
                 else F.live0 += (unsigned long long)hc[0];
             }
         }
