@@ -76,11 +76,66 @@ __device__ __forceinline__ int block_append(int *counter, bool flag, int *ldsCou
 // ---- the hot kernel ------------------------------------------------------------------------------------------
 constexpr int RAY_BATCH_MAX = 512; // largest guided batch a wave takes per queue atomic
 
+// Scene mode keeps the scene-level half of every lane's query (SceneLane, 28 words: world ray, scene cursor, best answer
+// so far) in LDS: only advance_scene and the final answer touch it, through these proxies, one word at a time where it
+// is needed.  The node and leaf loops then fit the 128-register budget of four waves per SIMD without scratch traffic.
+// Layout [word][lane] -- one bank per lane, like the traversal stack.
+template <class T>
+struct LdsField {
+    unsigned *p;
+    __device__ __forceinline__ operator T() const { T v; __builtin_memcpy(&v, p, 4); return v; }
+    __device__ __forceinline__ LdsField &operator=(T v) { __builtin_memcpy(p, &v, 4); return *this; }
+    __device__ __forceinline__ LdsField &operator=(const LdsField &o) { *p = *o.p; return *this; }
+    __device__ __forceinline__ T operator++(int) { T v = *this; *this = v + 1; return v; }
+    __device__ __forceinline__ T operator--() { T v = (T)(*this) - 1; *this = v; return v; }
+    __device__ __forceinline__ LdsField &operator&=(T m) { *this = (T)(*this) & m; return *this; }
+};
+struct LdsRay {
+    unsigned *p;   // 10 words, stride 64
+    __device__ __forceinline__ operator RayPre() const {
+        RayPre r;
+        r.o = mk(i2f((int)p[0]), i2f((int)p[64]), i2f((int)p[128]));
+        r.d = mk(i2f((int)p[192]), i2f((int)p[256]), i2f((int)p[320]));
+        r.inv = mk(i2f((int)p[384]), i2f((int)p[448]), i2f((int)p[512]));
+        r.par = (int)p[576];
+        return r;
+    }
+    __device__ __forceinline__ LdsRay &operator=(const RayPre &r) {
+        p[0] = (unsigned)f2i(r.o.x); p[64] = (unsigned)f2i(r.o.y); p[128] = (unsigned)f2i(r.o.z);
+        p[192] = (unsigned)f2i(r.d.x); p[256] = (unsigned)f2i(r.d.y); p[320] = (unsigned)f2i(r.d.z);
+        p[384] = (unsigned)f2i(r.inv.x); p[448] = (unsigned)f2i(r.inv.y); p[512] = (unsigned)f2i(r.inv.z);
+        p[576] = (unsigned)r.par;
+        return *this;
+    }
+};
+constexpr int PARK_WORDS = 28;
+struct ParkedScene {
+    LdsRay w;
+    LdsField<int> sblk, smask, ssp, sRef, sRefEnd;
+    LdsField<float> sKey;
+    LdsField<int> obj, mPtr, mEnd, sfound;
+    LdsField<float> sbKey, sbD, sbU, sbV;
+    LdsField<int> sbRef, sbLeaf, sbObj, sbMesh;
+    __device__ __forceinline__ explicit ParkedScene(unsigned *b)   // b = &park[wave][0][lane]
+        : w{b}, sblk{b + 10 * 64}, smask{b + 11 * 64}, ssp{b + 12 * 64}, sRef{b + 13 * 64}, sRefEnd{b + 14 * 64}, sKey{b + 15 * 64}, obj{b + 16 * 64},
+          mPtr{b + 17 * 64}, mEnd{b + 18 * 64}, sfound{b + 19 * 64}, sbKey{b + 20 * 64}, sbD{b + 21 * 64}, sbU{b + 22 * 64}, sbV{b + 23 * 64},
+          sbRef{b + 24 * 64}, sbLeaf{b + 25 * 64}, sbObj{b + 26 * 64}, sbMesh{b + 27 * 64} {}
+};
+// what the kernel instantiates the scene-level functions with: the LDS proxies in scene mode, plain registers otherwise
+template <int M> struct SceneHome { using type = SceneLane; };
+template <> struct SceneHome<MODE_SCENE> { using type = ParkedScene; };
+
 template <int T, int M>
 __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs A) {
     __shared__ unsigned stk[4 * T * 64];
+    __shared__ unsigned parkMem[M == MODE_SCENE ? 4 * PARK_WORDS * 64 : 64];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     LdsStack st{&stk[wave * T * 64 + lane]};
+    SceneLane plainScene;
+    auto &&C = [&]() -> decltype(auto) {
+        if constexpr (M == MODE_SCENE) return ParkedScene(&parkMem[wave * PARK_WORDS * 64 + lane]);
+        else return (plainScene);
+    }();
     int n1 = A.nDev ? (*A.nDev) * A.nMul : A.n;
     if (A.nCap > 0 && n1 > A.nCap) n1 = A.nCap;   // an overflowed generation is discarded by the host; stay inside the buffers
     // optional second segment (the shadow rays of the previous generation ride in the same launch as this generation's
@@ -136,8 +191,8 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
                         if (g >= n1) { src = A.rays2 + (g - n1); idx = ~(g - n1); }   // answers of segment 2 go to hits2
                         v3 o, d; int im, it;
                         load_ray(src, o, d, im, it);
-                        if (im == DEAD_RAY) { L.rayIndex = idx; L.sfound = 0; L.state = ST_FINISH; }
-                        else lane_begin(L, S, o, d, im, it, idx, M, A.meshId);
+                        if (im == DEAD_RAY) { L.rayIndex = idx; C.sfound = 0; L.mfound = 0; L.state = ST_FINISH; }
+                        else lane_begin(L, C, S, o, d, im, it, idx, M, A.meshId);
                     }
                     batchNext += take;
                 }
@@ -147,7 +202,7 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
         // while-while: lanes gather in the same phase before the wave pays for that phase's code
         if (M == MODE_SCENE) {
             while (__any(L.state == ST_SCENE)) {
-                if (L.state == ST_SCENE) advance_scene(L, S, st);
+                if (L.state == ST_SCENE) advance_scene(L, C, S, st);
             }
         }
         {   // the NaN-free box test is valid for the whole wave unless some live lane has a parallel axis or a non-finite ray
@@ -160,7 +215,7 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
             if (L.state == ST_LEAF) advance_leaf(L, S);
         }
         if (L.state == ST_FINISH) {
-            store_hit(L.rayIndex < 0 ? A.hits2 + ~L.rayIndex : A.hits + L.rayIndex, lane_result(L, S, M));
+            store_hit(L.rayIndex < 0 ? A.hits2 + ~L.rayIndex : A.hits + L.rayIndex, lane_result(L, C, S, M));
             L.state = ST_IDLE;
         }
     }
@@ -292,16 +347,16 @@ __global__ __launch_bounds__(256) void k_count(SceneView S, IntersectArgs A, uns
         const int cmode = (A.mode == MODE_MESH) ? MODE_MESH : MODE_SCENE;   // the counting pass always walks the general machine
         lane_begin(L, S, o, d, im, it, idx, cmode, A.meshId);
         run_query(L, S, stk, cmode);
-        if (L.sfound) c[C_HITS]++;
+        if (lane_found(L, cmode)) c[C_HITS]++;
         if (A.mode == MODE_MESH) {
             c[C_MESH_QUERIES]++;
-            count_mesh(S, L.w, A.meshId, L.ignoreId, L.mfound != 0, L.mKey, c, stk);
+            count_mesh(S, L.sc.w, A.meshId, L.ignoreId, L.mfound != 0, L.mKey, c, stk);
             continue;
         }
-        const bool sfound = L.sfound != 0;
-        const float sbKey = L.sbKey;
+        const bool sfound = L.sc.sfound != 0;
+        const float sbKey = L.sc.sbKey;
         const int ignoreId = L.ignoreId;
-        const RayPre w = L.w;
+        const RayPre w = L.sc.w;
         int sp = 0, blk = 0, mask = 1;
         for (;;) {
             if (mask == 0) {

@@ -37,19 +37,27 @@ enum : int { ST_IDLE = 0, ST_SCENE = 1, ST_NODE = 2, ST_LEAF = 3, ST_FINISH = 4 
 // the query's prologue and its registers disappear from the traversal loop.
 enum : int { MODE_SCENE = 0, MODE_MESH = 1, MODE_SINGLE = 2 };
 
+// Scene-level half of a query: what only the scene cursor (advance_scene) and the final answer need.  The hot kernel
+// keeps it in LDS in scene mode (kernels.hip, ParkedScene) so that the mesh loops fit the register budget; every
+// function that touches it is a template over its type.
+struct SceneLane {
+    RayPre w;            // world ray
+    int sblk, smask, ssp;
+    int sRef, sRefEnd;
+    float sKey;
+    int obj, mPtr, mEnd;
+    // scene best
+    int sfound;
+    float sbKey, sbD, sbU, sbV;
+    int sbRef, sbLeaf, sbObj, sbMesh;
+};
+
 struct Lane {
-    RayPre w;            // world ray (scene mode)
     RayPre r;            // object-space ray
     int ignoreId;        // global triangle id, -1 = none
     int weird;           // a non-finite ray component: only the NaN-exact box test may be used
     int rayIndex;
     int state;
-    // scene cursor
-    int sblk, smask, ssp;
-    int wmask;           // sign mask of the world direction (for the pre-cull box test)
-    int sRef, sRefEnd;
-    float sKey;
-    int obj, mPtr, mEnd;
     // mesh query: current block (children of the node whose own box is bmin..bmax)
     int mesh, dmask;
     int blk, mask, sp;       // mask: children still to test, bit p <-> child (p ^ dmask), front to back
@@ -64,10 +72,7 @@ struct Lane {
     int ref, refEnd, leafNode;
     float leafKey;
     int spec;            // the last leaf step met a front-facing triangle: fetch geometry together with the normals
-    // scene best
-    int sfound;
-    float sbKey, sbD, sbU, sbV;
-    int sbRef, sbLeaf, sbObj, sbMesh;
+    SceneLane sc;        // plain-register home of the scene-level half (unused where the kernel parks it in LDS)
 };
 
 XRT_HD int ctz32(unsigned x) { return __builtin_ctz(x); }
@@ -145,30 +150,30 @@ XRT_HD void begin_mesh_query(Lane &L, const SceneView &S, int mesh) {
 }
 
 // Start of a query.  ignore (mesh, tri) is the `ignoreTriangle` identity (MO:290).
-XRT_HD void lane_begin(Lane &L, const SceneView &S, v3 o, v3 d, int ignoreMesh, int ignoreTri, int rayIndex, int mode, int meshId) {
+template <class SC>
+XRT_HD void lane_begin(Lane &L, SC &C, const SceneView &S, v3 o, v3 d, int ignoreMesh, int ignoreTri, int rayIndex, int mode, int meshId) {
     L.rayIndex = rayIndex;
     L.weird = (is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(d.x) && is_finite(d.y) && is_finite(d.z)) ? 0 : 1;
     L.ignoreId = -1;
     if (ignoreTri >= 0 && ignoreMesh >= 0 && ignoreMesh < S.nMeshes && ignoreTri < S.meshes[ignoreMesh].ntri)
         L.ignoreId = S.meshes[ignoreMesh].triBase + ignoreTri;
-    L.sfound = 0;
-    L.sbKey = 0; L.sbD = 0; L.sbU = 0; L.sbV = 0; L.sbRef = 0; L.sbLeaf = 0; L.sbObj = -1; L.sbMesh = -1;
-    L.sRef = 0; L.sRefEnd = 0; L.mPtr = 0; L.mEnd = 0; L.ssp = 0; L.sKey = 0; L.obj = -1;
+    C.sfound = 0; L.mfound = 0;
+    C.sbKey = 0; C.sbD = 0; C.sbU = 0; C.sbV = 0; C.sbRef = 0; C.sbLeaf = 0; C.sbObj = -1; C.sbMesh = -1;
+    C.sRef = 0; C.sRefEnd = 0; C.mPtr = 0; C.mEnd = 0; C.ssp = 0; C.sKey = 0; C.obj = -1;
     if (is_nan(o.x) || is_nan(o.y) || is_nan(o.z) || is_nan(d.x) || is_nan(d.y) || is_nan(d.z)) {
         // A NaN component (e.g. the refracted direction of a total internal reflection, RT:676-694) poisons every
         // determinant of RE:42-75 (NaN * 0 is NaN): no triangle can be accepted, while the NaN-propagating box test
         // of the reference accepts EVERY box — the reference walks the whole scene to return "no intersection".
-        L.w = make_ray(o, d);   // (the counting pass reproduces that walk from L.w)
-        L.r = L.w;
+        L.r = make_ray(o, d);
+        C.w = L.r;   // (the counting pass reproduces that walk from the world ray)
         L.mfound = 0; L.mKey = 0;
         L.state = ST_FINISH;
         return;
     }
     L.spec = (L.ignoreId < 0) ? 1 : 0;   // rays leaving a surface (RT:485, RT:559) start among back faces
     if (mode == MODE_SCENE) {
-        L.w = make_ray(o, d);
-        L.wmask = dir_mask(d);
-        L.sblk = 0; L.smask = 1;   // root = slot 0 of block 0
+        C.w = make_ray(o, d);
+        C.sblk = 0; C.smask = 1;   // root = slot 0 of block 0
         L.state = ST_SCENE;
     } else if (mode == MODE_SINGLE) {
         // OSM:318 root box (a leaf holding the one body), OSM:349-364 ray transform, MESH:34-39, then MO:259
@@ -185,91 +190,110 @@ XRT_HD void lane_begin(Lane &L, const SceneView &S, v3 o, v3 d, int ignoreMesh, 
         L.r = make_ray(v1, dir);
         L.dmask = dir_mask(dir);
         if (!(is_finite(v1.x) && is_finite(v1.y) && is_finite(v1.z) && is_finite(dir.x) && is_finite(dir.y) && is_finite(dir.z))) L.weird = 1;
-        L.obj = 0;
-        L.sKey = key;
+        C.obj = 0;
+        C.sKey = key;
         const MeshRec &mr = S.meshes[0];
         float k;
         if (!slab(L.r, mr.bmin[0], mr.bmin[1], mr.bmin[2], mr.bmax[0], mr.bmax[1], mr.bmax[2], k)) return;
         begin_mesh_query(L, S, 0);
     } else {
-        L.w = make_ray(o, d);
-        L.r = L.w;
+        L.r = make_ray(o, d);
+        C.w = L.r;
         L.dmask = dir_mask(d);
-        L.sblk = 0; L.smask = 0;
-        L.obj = -1;
+        C.sblk = 0; C.smask = 0;
+        C.obj = -1;
         begin_mesh_query(L, S, meshId);
     }
 }
 
+XRT_HD void lane_begin(Lane &L, const SceneView &S, v3 o, v3 d, int ignoreMesh, int ignoreTri, int rayIndex, int mode, int meshId) {
+    lane_begin(L, L.sc, S, o, d, ignoreMesh, ignoreTri, rayIndex, mode, meshId);
+}
+
 // ---- scene level: one step of OSM:318 (node collection) / OSM:334-433 (bucket scan), DFS order ---------
-template <class Stack>
-XRT_HD void advance_scene(Lane &L, const SceneView &S, Stack &stk) {
-    if (L.mPtr < L.mEnd) {   // OSM:366-368: next mesh of the current SceneObject
-        int m = S.objMesh[L.mPtr++];
+// OSM:370-378: the answer of the mesh query that just ended competes with the scene's best so far, strict '<' on
+// the object-space distance inside one bucket.
+template <class SC>
+XRT_HD void merge_mesh_result(Lane &L, SC &C) {
+    bool accept = !C.sfound || C.sKey < C.sbKey || (C.sKey == C.sbKey && L.mDist < C.sbD);
+    if (accept) {
+        C.sfound = 1;
+        C.sbKey = C.sKey; C.sbD = L.mDist; C.sbU = L.mU; C.sbV = L.mV;
+        C.sbRef = L.mRef; C.sbLeaf = L.mLeaf; C.sbObj = C.obj; C.sbMesh = L.mesh;
+    }
+}
+
+template <class Stack, class SC>
+XRT_HD void advance_scene(Lane &L, SC &C, const SceneView &S, Stack &stk) {
+    if (L.mfound) {   // a mesh query ended with a hit since the last scene step (finish_mesh_query defers the merge to here)
+        merge_mesh_result(L, C);
+        L.mfound = 0;
+    }
+    if (C.mPtr < C.mEnd) {   // OSM:366-368: next mesh of the current SceneObject
+        int m = S.objMesh[C.mPtr++];
         const MeshRec &mr = S.meshes[m];
         float k;
         if (slab(L.r, mr.bmin[0], mr.bmin[1], mr.bmin[2], mr.bmax[0], mr.bmax[1], mr.bmax[2], k))   // MESH:34-39
             begin_mesh_query(L, S, m);
         return;
     }
-    while (L.sRef < L.sRefEnd) {   // OSM:341-364: next body of the current leaf, world -> object space
-        int o = S.srefs[L.sRef++];
+    while (C.sRef < C.sRefEnd) {   // OSM:341-364: next body of the current leaf, world -> object space
+        int o = S.srefs[C.sRef++];
         const ObjRec &ob = S.objects[o];
+        const RayPre w = C.w;
         if (ob.cullOk && !L.weird) {   // conservative world-space reject (xrt_core.h ObjRec): the visit would end at MESH:34-39 for every mesh
             float kc;
             const v3 cmn = mk(ob.cullMin[0], ob.cullMin[1], ob.cullMin[2]), cmx = mk(ob.cullMax[0], ob.cullMax[1], ob.cullMax[2]);
-            const bool hitBox = (L.w.par == 0) ? slab_fast(L.w, L.wmask, cmn, cmx, kc) : slab(L.w, cmn.x, cmn.y, cmn.z, cmx.x, cmx.y, cmx.z, kc);
+            const bool hitBox = (w.par == 0) ? slab_fast(w, dir_mask(w.d), cmn, cmx, kc) : slab(w, cmn.x, cmn.y, cmn.z, cmx.x, cmx.y, cmx.z, kc);
             if (!hitBox) continue;
         }
-        L.obj = o;
-        v3 rayDirPosition = add(L.w.o, L.w.d);                 // OSM:358
-        v3 v1 = transform(L.w.o, ob.invWorld);                  // OSM:360
+        C.obj = o;
+        v3 rayDirPosition = add(w.o, w.d);                 // OSM:358
+        v3 v1 = transform(w.o, ob.invWorld);                  // OSM:360
         v3 v2 = transform(rayDirPosition, ob.invWorld);         // OSM:361
         v3 dir = normalize(sub(v2, v1));                        // OSM:362-364
         L.r = make_ray(v1, dir);
         L.dmask = dir_mask(dir);
         if (!(is_finite(v1.x) && is_finite(v1.y) && is_finite(v1.z) && is_finite(dir.x) && is_finite(dir.y) && is_finite(dir.z))) L.weird = 1;
-        L.mPtr = ob.meshStart;
-        L.mEnd = ob.meshStart + ob.meshCount;
+        C.mPtr = ob.meshStart;
+        C.mEnd = ob.meshStart + ob.meshCount;
         return;
     }
-    if (L.smask == 0) {
-        if (L.ssp == 0) { L.state = ST_FINISH; return; }
-        unsigned wv = stk.get(--L.ssp);
-        L.sblk = (int)(wv >> 8);
-        L.smask = (int)(wv & 0xffu);
+    if (C.smask == 0) {
+        if (C.ssp == 0) { L.state = ST_FINISH; return; }
+        unsigned wv = stk.get(--C.ssp);
+        C.sblk = (int)(wv >> 8);
+        C.smask = (int)(wv & 0xffu);
         return;
     }
-    int c = ctz32((unsigned)L.smask);
-    L.smask &= L.smask - 1;
-    int node = L.sblk * 8 + c;
+    int c = ctz32((unsigned)C.smask);
+    C.smask &= C.smask - 1;
+    int node = C.sblk * 8 + c;
     f4 lo = S.snodes[2 * node], hi = S.snodes[2 * node + 1];
     float key;
-    if (!slab(L.w, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, key)) return;   // OSM:460
+    const RayPre w = C.w;
+    if (!slab(w, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, key)) return;   // OSM:460
     int a = f2i(lo.w), b = f2i(hi.w);
     if (b < 0) {   // leaf
         int cnt = b & 0x0fffffff;
         if (cnt == 0) return;
-        if (L.sfound && key > L.sbKey) return;   // a later bucket than the one that already has a hit (OSM:334)
-        L.sRef = a; L.sRefEnd = a + cnt; L.sKey = key;
+        if (C.sfound && key > C.sbKey) return;   // a later bucket than the one that already has a hit (OSM:334)
+        C.sRef = a; C.sRefEnd = a + cnt; C.sKey = key;
     } else {
-        if (L.smask) stk.set(L.ssp++, ((unsigned)L.sblk << 8) | (unsigned)L.smask);
-        L.sblk = a >> 3;
-        L.smask = 0xff;
+        if (C.smask) stk.set(C.ssp++, ((unsigned)C.sblk << 8) | (unsigned)C.smask);
+        C.sblk = a >> 3;
+        C.smask = 0xff;
     }
 }
 
-// End of one MeshOctree.GetRayIntersection: OSM:370-378 accept with strict '<' on the object-space d.
+template <class Stack>
+XRT_HD void advance_scene(Lane &L, const SceneView &S, Stack &stk) { advance_scene(L, L.sc, S, stk); }
+
+// End of one MeshOctree.GetRayIntersection.  Scene mode: back to the scene cursor, which merges the answer on its next
+// step -- the mesh phases never touch the scene-level half of the query.  MODE_MESH / MODE_SINGLE: the one mesh query
+// was the whole query and lane_result reads its answer directly.
 XRT_HD void finish_mesh_query(Lane &L, int mode) {
-    if (L.mfound) {
-        bool accept = !L.sfound || L.sKey < L.sbKey || (L.sKey == L.sbKey && L.mDist < L.sbD);
-        if (accept) {
-            L.sfound = 1;
-            L.sbKey = L.sKey; L.sbD = L.mDist; L.sbU = L.mU; L.sbV = L.mV;
-            L.sbRef = L.mRef; L.sbLeaf = L.mLeaf; L.sbObj = L.obj; L.sbMesh = L.mesh;
-        }
-    }
-    L.state = (mode == MODE_SCENE) ? ST_SCENE : ST_FINISH;   // MODE_SINGLE: the one body's one mesh was the whole scene
+    L.state = (mode == MODE_SCENE) ? ST_SCENE : ST_FINISH;
 }
 
 // Every triangle of a leaf is rejected by the back-face test (RE:48-51: N.D > 0 in binary32) when a lower bound
@@ -402,25 +426,31 @@ struct HitOut {
     int hit, object, mesh, tri, leaf;
     float u, v, d, wx, wy, wz;
 };
-XRT_HD HitOut lane_result(const Lane &L, const SceneView &S, int mode) {
+template <class SC>
+XRT_HD HitOut lane_result(const Lane &L, const SC &C, const SceneView &S, int mode) {
     HitOut h;
     h.hit = 0; h.object = -1; h.mesh = -1; h.tri = -1; h.leaf = -1;
     h.u = 0; h.v = 0; h.d = 0; h.wx = 0; h.wy = 0; h.wz = 0;
-    if (!L.sfound) return h;
-    g3 a = S.refG[3 * (size_t)L.sbRef], b = S.refG[3 * (size_t)L.sbRef + 1], c = S.refG[3 * (size_t)L.sbRef + 2];
+    const bool sc = mode == MODE_SCENE;
+    if (!(sc ? (int)C.sfound : L.mfound)) return h;
+    const int ref = sc ? (int)C.sbRef : L.mRef, mesh = sc ? (int)C.sbMesh : L.mesh, obj = sc ? (int)C.sbObj : 0;   // MODE_SINGLE: body 0
+    const float u = sc ? (float)C.sbU : L.mU, v = sc ? (float)C.sbV : L.mV;
+    g3 a = S.refG[3 * (size_t)ref], b = S.refG[3 * (size_t)ref + 1], c = S.refG[3 * (size_t)ref + 2];
     v3 v1 = mk(a.x, a.y, a.z), p1 = mk(b.x, b.y, b.z), p2 = mk(c.x, c.y, c.z);
-    v3 pos = add(add(v1, scale(p1, L.sbU)), scale(p2, L.sbV));   // MO:310-312
+    v3 pos = add(add(v1, scale(p1, u)), scale(p2, v));   // MO:310-312
     h.hit = 1;
-    h.mesh = L.sbMesh;
-    h.tri = f2i(S.refN[L.sbRef].w) - S.meshes[L.sbMesh].triBase;
-    h.leaf = node_dfs(S, L.sbLeaf);
-    h.u = L.sbU; h.v = L.sbV; h.d = L.sbD;
+    h.mesh = mesh;
+    h.tri = f2i(S.refN[ref].w) - S.meshes[mesh].triBase;
+    h.leaf = node_dfs(S, sc ? (int)C.sbLeaf : L.mLeaf);
+    h.u = u; h.v = v; h.d = sc ? (float)C.sbD : L.mDist;
     if (mode != MODE_MESH) {
-        h.object = L.sbObj;
-        pos = transform(pos, S.objects[L.sbObj].world);   // OSM:441-443
+        h.object = obj;
+        pos = transform(pos, S.objects[obj].world);   // OSM:441-443
     }
     h.wx = pos.x; h.wy = pos.y; h.wz = pos.z;
     return h;
 }
+XRT_HD HitOut lane_result(const Lane &L, const SceneView &S, int mode) { return lane_result(L, L.sc, S, mode); }
+XRT_HD bool lane_found(const Lane &L, int mode) { return (mode == MODE_SCENE ? L.sc.sfound : L.mfound) != 0; }
 
 }  // namespace xrt
