@@ -10,7 +10,7 @@ out = torch.zeros(spec.width * spec.height, dtype=torch.int32, device="cuda")
 fr = tracer.PrepareDevice(out.data_ptr())
 for _ in range(5):
     fr()
-N = 200
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 tb = te = 0.0
 t0 = time.perf_counter()
 prev = None

@@ -120,6 +120,32 @@ XRT_HD bool slab_fast(const RayPre &r, int dmask, v3 cmin, v3 cmax, float &key) 
     key = num;
     return !(num > num2);
 }
+// slab_fast for all eight children of the block whose parent box is (pmin, half): each axis has three planes
+// (p0 = pmin + half*0, p1 = pmin + half*1, p2 = p1 + half -- the very sums child_box forms), so nine products serve
+// the eight tests.  Returns the children the ray enters, bit p <-> child (p ^ dmask) like Lane::mask.  The visit of a
+// child repeats its own test (it needs the entry key anyway), so this only removes visits that would end at MO:331.
+XRT_HD int hit8_fast(const RayPre &r, int dmask, v3 pmin, v3 half) {
+    const float x0 = pmin.x + half.x * 0.0f, x1 = pmin.x + half.x * 1.0f, x2 = x1 + half.x;
+    const float y0 = pmin.y + half.y * 0.0f, y1 = pmin.y + half.y * 1.0f, y2 = y1 + half.y;
+    const float z0 = pmin.z + half.z * 0.0f, z1 = pmin.z + half.z * 1.0f, z2 = z1 + half.z;
+    const float tx0 = (x0 - r.o.x) * r.inv.x, tx1 = (x1 - r.o.x) * r.inv.x, tx2 = (x2 - r.o.x) * r.inv.x;
+    const float ty0 = (y0 - r.o.y) * r.inv.y, ty1 = (y1 - r.o.y) * r.inv.y, ty2 = (y2 - r.o.y) * r.inv.y;
+    const float tz0 = (z0 - r.o.z) * r.inv.z, tz1 = (z1 - r.o.z) * r.inv.z, tz2 = (z2 - r.o.z) * r.inv.z;
+    // child bit b on an axis spans planes b..b+1; the near plane is the upper one when the direction is negative
+    const bool nx = (dmask & 4) != 0, ny = (dmask & 2) != 0, nz = (dmask & 1) != 0;
+    const float nearX[2] = {nx ? tx1 : tx0, nx ? tx2 : tx1}, farX[2] = {nx ? tx0 : tx1, nx ? tx1 : tx2};
+    const float nearY[2] = {ny ? ty1 : ty0, ny ? ty2 : ty1}, farY[2] = {ny ? ty0 : ty1, ny ? ty1 : ty2};
+    const float nearZ[2] = {nz ? tz1 : tz0, nz ? tz2 : tz1}, farZ[2] = {nz ? tz0 : tz1, nz ? tz1 : tz2};
+    int m = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int i = (c >> 2) & 1, j = (c >> 1) & 1, k = c & 1;
+        const float num = fmaxf(fmaxf(fmaxf(nearX[i], 0.0f), nearY[j]), nearZ[k]);
+        const float num2 = fminf(fminf(fminf(farX[i], FLT_MAX), farY[j]), farZ[k]);
+        if (!(num > num2)) m |= 1 << (c ^ dmask);
+    }
+    return m;
+}
 XRT_HD bool is_finite(float x) { return fabsf(x) <= FLT_MAX; }
 XRT_HD int child_ref_offset(unsigned long long offLo, unsigned long long offHi, int c) {
     unsigned long long w = (c & 4) ? offHi : offLo;
@@ -147,6 +173,7 @@ XRT_HD void begin_mesh_query(Lane &L, const SceneView &S, int mesh) {
     L.half = half_of(L.bmin, mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]));
     load_block(L, S, mr.rootBlock);
     L.mask = permute_mask(0xff & ~((L.d2 >> 8) & 0xff), L.dmask);
+    if (L.r.par == 0 && !L.weird) L.mask &= hit8_fast(L.r, L.dmask, L.bmin, L.half);
 }
 
 // Start of a query.  ignore (mesh, tri) is the `ignoreTriangle` identity (MO:290).
@@ -368,6 +395,7 @@ XRT_HD void advance_node(Lane &L, const SceneView &S, Stack &stk, int mode, bool
     L.bmin = cmin; L.half = half_of(cmin, cmax);
     load_block(L, S, nb);
     L.mask = permute_mask(0xff & ~((L.d2 >> 8) & 0xff), L.dmask);
+    if (L.r.par == 0 && !L.weird) L.mask &= hit8_fast(L.r, L.dmask, L.bmin, L.half);
 }
 
 // ---- leaf: triangles of MO:288-304 --------------------------------------------------------------------------------
