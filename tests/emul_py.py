@@ -100,7 +100,7 @@ class EmulScene:
         assert rc == 0, rc
         return (hits, st) if steps else hits
 
-    def wave_sim(self, rays, mode=0, mesh=0, n_waves=64, tune=(24, 64, 32)):
+    def wave_sim(self, rays, mode=0, mesh=0, n_waves=64, tune=(24, 16, 48)):
         """Wave-level scheduling model of the traversal kernel: step and active-lane counts per phase."""
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
         out = np.zeros(16, dtype=np.int64)

@@ -119,7 +119,7 @@ struct xrt_scene {
     std::vector<LightRec> lightsOnDevice;   // what s->lights holds
     const void *lightsDevPtr = nullptr;
     int firstBatch = 64;
-    int tune[3] = {24, 64, 32};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
+    int tune[3] = {24, 16, 48};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
     std::atomic<bool> busy{false};
     std::atomic<float> progress{0.0f};
 
