@@ -256,60 +256,69 @@ XRT_HD void advance_scene(Lane &L, SC &C, const SceneView &S, Stack &stk) {
         merge_mesh_result(L, C);
         L.mfound = 0;
     }
-    if (C.mPtr < C.mEnd) {   // OSM:366-368: next mesh of the current SceneObject
-        int m = S.objMesh[C.mPtr++];
-        const MeshRec &mr = S.meshes[m];
-        float k;
-        if (slab(L.r, mr.bmin[0], mr.bmin[1], mr.bmin[2], mr.bmax[0], mr.bmax[1], mr.bmax[2], k))   // MESH:34-39
-            begin_mesh_query(L, S, m);
-        return;
-    }
-    while (C.sRef < C.sRefEnd) {   // OSM:341-364: next body of the current leaf, world -> object space
-        int o = S.srefs[C.sRef++];
-        const ObjRec &ob = S.objects[o];
-        const RayPre w = C.w;
-        if (ob.cullOk && !L.weird) {   // conservative world-space reject (xrt_core.h ObjRec): the visit would end at MESH:34-39 for every mesh
-            float kc;
-            const v3 cmn = mk(ob.cullMin[0], ob.cullMin[1], ob.cullMin[2]), cmx = mk(ob.cullMax[0], ob.cullMax[1], ob.cullMax[2]);
-            const bool hitBox = (w.par == 0) ? slab_fast(w, dir_mask(w.d), cmn, cmx, kc) : slab(w, cmn.x, cmn.y, cmn.z, cmx.x, cmx.y, cmx.z, kc);
-            if (!hitBox) continue;
+    // One step runs the scene cursor, in the reference's order, up to the next mesh query (or the end of the scene
+    // walk, or a pop): meshes of the current body, then the next bodies of the current leaf, then the next children of
+    // the current block.  Everything that is rejected on the way -- a mesh box, a pre-culled body, a child box the ray
+    // misses, an empty or later-bucket leaf -- is passed inside the step.
+    for (;;) {
+        while (C.mPtr < C.mEnd) {   // OSM:366-368: next mesh of the current SceneObject
+            const int m = S.objMesh[C.mPtr++];
+            const MeshRec &mr = S.meshes[m];
+            float k;
+            if (slab(L.r, mr.bmin[0], mr.bmin[1], mr.bmin[2], mr.bmax[0], mr.bmax[1], mr.bmax[2], k)) {   // MESH:34-39
+                begin_mesh_query(L, S, m);
+                return;
+            }
         }
-        C.obj = o;
-        v3 rayDirPosition = add(w.o, w.d);                 // OSM:358
-        v3 v1 = transform(w.o, ob.invWorld);                  // OSM:360
-        v3 v2 = transform(rayDirPosition, ob.invWorld);         // OSM:361
-        v3 dir = normalize(sub(v2, v1));                        // OSM:362-364
-        L.r = make_ray(v1, dir);
-        L.dmask = dir_mask(dir);
-        if (!(is_finite(v1.x) && is_finite(v1.y) && is_finite(v1.z) && is_finite(dir.x) && is_finite(dir.y) && is_finite(dir.z))) L.weird = 1;
-        C.mPtr = ob.meshStart;
-        C.mEnd = ob.meshStart + ob.meshCount;
-        return;
-    }
-    if (C.smask == 0) {
-        if (C.ssp == 0) { L.state = ST_FINISH; return; }
-        unsigned wv = stk.get(--C.ssp);
-        C.sblk = (int)(wv >> 8);
-        C.smask = (int)(wv & 0xffu);
-        return;
-    }
-    int c = ctz32((unsigned)C.smask);
-    C.smask &= C.smask - 1;
-    int node = C.sblk * 8 + c;
-    f4 lo = S.snodes[2 * node], hi = S.snodes[2 * node + 1];
-    float key;
-    const RayPre w = C.w;
-    if (!slab(w, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, key)) return;   // OSM:460
-    int a = f2i(lo.w), b = f2i(hi.w);
-    if (b < 0) {   // leaf
-        int cnt = b & 0x0fffffff;
-        if (cnt == 0) return;
-        if (C.sfound && key > C.sbKey) return;   // a later bucket than the one that already has a hit (OSM:334)
-        C.sRef = a; C.sRefEnd = a + cnt; C.sKey = key;
-    } else {
-        if (C.smask) stk.set(C.ssp++, ((unsigned)C.sblk << 8) | (unsigned)C.smask);
-        C.sblk = a >> 3;
-        C.smask = 0xff;
+        while (C.sRef < C.sRefEnd) {   // OSM:341-364: next body of the current leaf, world -> object space
+            const int o = S.srefs[C.sRef++];
+            const ObjRec &ob = S.objects[o];
+            const RayPre w = C.w;
+            if (ob.cullOk && !L.weird) {   // conservative world-space reject (xrt_core.h ObjRec): the visit would end at MESH:34-39 for every mesh
+                float kc;
+                const v3 cmn = mk(ob.cullMin[0], ob.cullMin[1], ob.cullMin[2]), cmx = mk(ob.cullMax[0], ob.cullMax[1], ob.cullMax[2]);
+                const bool hitBox = (w.par == 0) ? slab_fast(w, dir_mask(w.d), cmn, cmx, kc) : slab(w, cmn.x, cmn.y, cmn.z, cmx.x, cmx.y, cmx.z, kc);
+                if (!hitBox) continue;
+            }
+            C.obj = o;
+            v3 rayDirPosition = add(w.o, w.d);                      // OSM:358
+            v3 v1 = transform(w.o, ob.invWorld);                    // OSM:360
+            v3 v2 = transform(rayDirPosition, ob.invWorld);         // OSM:361
+            v3 dir = normalize(sub(v2, v1));                        // OSM:362-364
+            L.r = make_ray(v1, dir);
+            L.dmask = dir_mask(dir);
+            if (!(is_finite(v1.x) && is_finite(v1.y) && is_finite(v1.z) && is_finite(dir.x) && is_finite(dir.y) && is_finite(dir.z))) L.weird = 1;
+            C.mPtr = ob.meshStart;
+            C.mEnd = ob.meshStart + ob.meshCount;
+            return;   // its meshes on the next step
+        }
+        if (C.smask == 0) {   // block exhausted
+            if (C.ssp == 0) { L.state = ST_FINISH; return; }
+            unsigned wv = stk.get(--C.ssp);
+            C.sblk = (int)(wv >> 8);
+            C.smask = (int)(wv & 0xffu);
+            return;
+        }
+        int sm = C.smask;
+        const int c = ctz32((unsigned)sm);
+        sm &= sm - 1;
+        C.smask = sm;
+        const int node = C.sblk * 8 + c;
+        const f4 lo = S.snodes[2 * node], hi = S.snodes[2 * node + 1];
+        float key;
+        const RayPre w = C.w;
+        if (!slab(w, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, key)) continue;   // OSM:460
+        const int a_ = f2i(lo.w), b_ = f2i(hi.w);
+        if (b_ < 0) {   // leaf
+            const int cnt = b_ & 0x0fffffff;
+            if (cnt == 0) continue;
+            if (C.sfound && key > C.sbKey) continue;   // a later bucket than the one that already has a hit (OSM:334)
+            C.sRef = a_; C.sRefEnd = a_ + cnt; C.sKey = key;
+        } else {
+            if (sm) stk.set(C.ssp++, ((unsigned)C.sblk << 8) | (unsigned)sm);
+            C.sblk = a_ >> 3;
+            C.smask = 0xff;
+        }
     }
 }
 
