@@ -52,7 +52,7 @@ def test_no_contracted_fma_in_any_kernel(isa):
 
 def test_hot_kernel_resources(isa):
     """k_intersect must stay within 128 VGPRs without scratch (4 waves per SIMD, MI355X_MICROARCH.md register table).
-    Scene mode parks 28 words per lane in LDS, so its deep-stack variants trade a wave for that: (T + 28) KB per block."""
+    Scene mode parks 27 words per lane in LDS, so its deep-stack variants trade a wave for that: (T + 27) KB + 256 B per block."""
     usage = open(os.path.join(CSRC, "kernels.usage.txt")).read()
     blocks = re.findall(r"Function Name: (\S*k_intersectILi(\d+)ELi(\d)E\S*).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
                         usage, flags=re.S)
@@ -60,5 +60,5 @@ def test_hot_kernel_resources(isa):
     for name, cap, mode, vgprs, scratch, occ in blocks:
         want = 4
         if int(mode) == 0 and int(cap) > 12:
-            want = 160 // (int(cap) + 28)
+            want = 160 * 1024 // ((int(cap) + 27) * 1024 + (256 if int(cap) < 40 else 0))
         assert int(vgprs) <= 128 and int(scratch) == 0 and int(occ) >= want, (name, vgprs, scratch, occ)

@@ -30,6 +30,7 @@ struct IntersectArgs {
     int mode, meshId;
     int firstBatch;     // rays of the static first batch of every wave
     int refillMin, nodeBurst, leafBurst;   // scheduling knobs of the persistent loop (defaults in xrt_api.cpp; XRT_TUNE overrides)
+    int coopMax = 16;   // at most this many lanes in a leaf: their triangle lists are dealt to the whole wave
     // optional second segment traced by the same launch: rays2[0 .. (*nDev2) * nMul2) -> hits2 (no index list)
     const xrt_ray *rays2 = nullptr;
     xrt_hit *hits2 = nullptr;

@@ -76,7 +76,7 @@ __device__ __forceinline__ int block_append(int *counter, bool flag, int *ldsCou
 // ---- the hot kernel ------------------------------------------------------------------------------------------
 constexpr int RAY_BATCH_MAX = 512; // largest guided batch a wave takes per queue atomic
 
-// Scene mode keeps the scene-level half of every lane's query (SceneLane, 28 words: world ray, scene cursor, best answer
+// Scene mode keeps the scene-level half of every lane's query (SceneLane, 27 words: world ray, scene cursor, best answer
 // so far) in LDS: only advance_scene and the final answer touch it, through these proxies, one word at a time where it
 // is needed.  The node and leaf loops then fit the 128-register budget of four waves per SIMD without scratch traffic.
 // Layout [word][lane] -- one bank per lane, like the traversal stack.
@@ -91,24 +91,23 @@ struct LdsField {
     __device__ __forceinline__ LdsField &operator&=(T m) { *this = (T)(*this) & m; return *this; }
 };
 struct LdsRay {
-    unsigned *p;   // 10 words, stride 64
+    unsigned *p;   // 9 words, stride 64 (the parallel-axis bits are recomputed from the direction)
     __device__ __forceinline__ operator RayPre() const {
         RayPre r;
         r.o = mk(i2f((int)p[0]), i2f((int)p[64]), i2f((int)p[128]));
         r.d = mk(i2f((int)p[192]), i2f((int)p[256]), i2f((int)p[320]));
         r.inv = mk(i2f((int)p[384]), i2f((int)p[448]), i2f((int)p[512]));
-        r.par = (int)p[576];
+        r.par = (fabsf(r.d.x) < 1e-06f ? 1 : 0) | (fabsf(r.d.y) < 1e-06f ? 2 : 0) | (fabsf(r.d.z) < 1e-06f ? 4 : 0);   // as make_ray
         return r;
     }
     __device__ __forceinline__ LdsRay &operator=(const RayPre &r) {
         p[0] = (unsigned)f2i(r.o.x); p[64] = (unsigned)f2i(r.o.y); p[128] = (unsigned)f2i(r.o.z);
         p[192] = (unsigned)f2i(r.d.x); p[256] = (unsigned)f2i(r.d.y); p[320] = (unsigned)f2i(r.d.z);
         p[384] = (unsigned)f2i(r.inv.x); p[448] = (unsigned)f2i(r.inv.y); p[512] = (unsigned)f2i(r.inv.z);
-        p[576] = (unsigned)r.par;
         return *this;
     }
 };
-constexpr int PARK_WORDS = 28;
+constexpr int PARK_WORDS = 27;
 struct ParkedScene {
     LdsRay w;
     LdsField<int> sblk, smask, ssp, sRef, sRefEnd;
@@ -117,18 +116,107 @@ struct ParkedScene {
     LdsField<float> sbKey, sbD, sbU, sbV;
     LdsField<int> sbRef, sbLeaf, sbObj, sbMesh;
     __device__ __forceinline__ explicit ParkedScene(unsigned *b)   // b = &park[wave][0][lane]
-        : w{b}, sblk{b + 10 * 64}, smask{b + 11 * 64}, ssp{b + 12 * 64}, sRef{b + 13 * 64}, sRefEnd{b + 14 * 64}, sKey{b + 15 * 64}, obj{b + 16 * 64},
-          mPtr{b + 17 * 64}, mEnd{b + 18 * 64}, sfound{b + 19 * 64}, sbKey{b + 20 * 64}, sbD{b + 21 * 64}, sbU{b + 22 * 64}, sbV{b + 23 * 64},
-          sbRef{b + 24 * 64}, sbLeaf{b + 25 * 64}, sbObj{b + 26 * 64}, sbMesh{b + 27 * 64} {}
+        : w{b}, sblk{b + 9 * 64}, smask{b + 10 * 64}, ssp{b + 11 * 64}, sRef{b + 12 * 64}, sRefEnd{b + 13 * 64}, sKey{b + 14 * 64},
+          obj{b + 15 * 64}, mPtr{b + 16 * 64}, mEnd{b + 17 * 64}, sfound{b + 18 * 64}, sbKey{b + 19 * 64}, sbD{b + 20 * 64},
+          sbU{b + 21 * 64}, sbV{b + 22 * 64}, sbRef{b + 23 * 64}, sbLeaf{b + 24 * 64}, sbObj{b + 25 * 64}, sbMesh{b + 26 * 64} {}
 };
 // what the kernel instantiates the scene-level functions with: the LDS proxies in scene mode, plain registers otherwise
 template <int M> struct SceneHome { using type = SceneLane; };
 template <> struct SceneHome<MODE_SCENE> { using type = ParkedScene; };
 
+// ---- leaf phase, wave-cooperative ------------------------------------------------------------------------------------
+// The triangle lists of the lanes that are in a leaf (MO:288-304) are laid end to end and dealt to the 64 lanes of the
+// wave, one reference per lane and step: slot s tests reference ref_i + (s - first_i) of owner lane i with the owner's
+// ray.  A lane alone in a 40-triangle leaf is done in one step instead of twenty, and a step's arithmetic runs with
+// as many lanes as there are references left, not as there are lanes in a leaf.  Candidates go back to their owner in
+// slot order, which is list order per owner, so MO:293's strict '<' keeps the first of equal distances.
+// wave64 inclusive scans on the DPP network (row shifts, then the two row broadcasts): no LDS round trip
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int wave_scan_max(int v) {   // values >= 0
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+__device__ __forceinline__ void coop_leaf_step(Lane &L, const SceneView &S, unsigned char *own /* [64] of this wave */) {
+    const int lane = lane_id();
+    const bool inLeaf = L.state == ST_LEAF;
+    const int cnt = inLeaf ? L.refEnd - L.ref : 0;
+    const int incl = wave_scan_add(cnt);
+    const int excl = incl - cnt;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    // owner of slot s: the last lane whose list starts at or before s -- every owner drops its lane number at its
+    // first slot, a running maximum spreads it over the slots that follow
+    // (lanes talk to each other through `own`: wave-level fences, or the compiler forwards a lane's own zero to its read)
+    own[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (cnt > 0 && excl < 64) own[excl] = (unsigned char)lane;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int owner = wave_scan_max((int)own[lane]);
+    const bool valid = lane < total;
+    const int ref = __shfl(L.ref, owner) + (lane - __shfl(excl, owner));
+    const v3 o = mk(__shfl(L.r.o.x, owner), __shfl(L.r.o.y, owner), __shfl(L.r.o.z, owner));
+    const v3 d = mk(__shfl(L.r.d.x, owner), __shfl(L.r.d.y, owner), __shfl(L.r.d.z, owner));
+    const int ignoreId = __shfl(L.ignoreId, owner);
+    bool f = false, pass = false;
+    float u = 0, v = 0, t = 0;
+    if (valid) {
+        const f4 n = S.refN[ref];
+        const g3 ga = S.refG[3 * (size_t)ref], gb = S.refG[3 * (size_t)ref + 1], gc = S.refG[3 * (size_t)ref + 2];
+        f = !(facing(mk(n.x, n.y, n.z), d) > 0.0f) && f2i(n.w) != ignoreId;   // RE:48-51, MO:290
+        if (f) pass = tri_test_front(o, d, mk(ga.x, ga.y, ga.z), mk(gb.x, gb.y, gb.z), mk(gc.x, gc.y, gc.z), u, v, t) && t < FLT_MAX;   // MO:293
+    }
+    unsigned long long pm = __ballot(pass);
+    while (pm) {   // rare: hand each passing candidate to its owner, in list order
+        const int s = __builtin_ctzll(pm);
+        pm &= pm - 1;
+        const int so = __builtin_amdgcn_readlane(owner, s);
+        const int sr = __builtin_amdgcn_readlane(ref, s);
+        const float su = i2f(__builtin_amdgcn_readlane(f2i(u), s)), sv = i2f(__builtin_amdgcn_readlane(f2i(v), s)),
+                    sd = i2f(__builtin_amdgcn_readlane(f2i(t), s));
+        if (lane == so) leaf_candidate(L, S, sr, -2, true, su, sv, sd);   // (the ignored triangle was filtered above: -2 matches no id)
+    }
+    if (inLeaf) {
+        const int room = 64 - excl;
+        const int used = room <= 0 ? 0 : (cnt < room ? cnt : room);
+        const unsigned long long fm = __ballot(f);
+        if (used > 0) L.spec = ((fm >> excl) & ((used >= 64) ? ~0ull : ((1ull << used) - 1ull))) != 0ull ? 1 : 0;
+        L.ref += used;
+        if (L.ref >= L.refEnd) L.state = ST_NODE;
+    }
+}
+
+// LDS that only some variants need is declared where only they instantiate it: the deepest stack (40 levels, 40 KB a
+// block) leaves no room for anything else at four blocks per CU.
+template <int M> __device__ __forceinline__ unsigned *park_memory() {
+    if constexpr (M == MODE_SCENE) { __shared__ unsigned mem[4 * PARK_WORDS * 64]; return mem; }
+    else return nullptr;
+}
+template <int T> __device__ __forceinline__ unsigned char *coop_memory() {
+    if constexpr (T < 40) { __shared__ unsigned char mem[4 * 64]; return mem; }
+    else return nullptr;
+}
+
 template <int T, int M>
 __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs A) {
     __shared__ unsigned stk[4 * T * 64];
-    __shared__ unsigned parkMem[M == MODE_SCENE ? 4 * PARK_WORDS * 64 : 64];
+    unsigned *const parkMem = park_memory<M>();
+    unsigned char *const coopOwn = coop_memory<T>();
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     LdsStack st{&stk[wave * T * 64 + lane]};
     SceneLane plainScene;
@@ -211,8 +299,12 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
                 if (L.state == ST_NODE) advance_node(L, S, st, M, fast);
             }
         }
-        for (int it = 0; it < A.leafBurst && __any(L.state == ST_LEAF); it++) {
-            if (L.state == ST_LEAF) advance_leaf(L, S);
+        for (int it = 0; it < A.leafBurst; it++) {
+            const unsigned long long inLeaf = __ballot(L.state == ST_LEAF);
+            if (inLeaf == 0ull) break;
+            // many lanes in a leaf: two references per lane and step; few: their lists are dealt to the whole wave
+            if (T >= 40 || __popcll(inLeaf) > A.coopMax) { if (L.state == ST_LEAF) advance_leaf(L, S); }
+            else coop_leaf_step(L, S, &coopOwn[wave * 64]);
         }
         if (L.state == ST_FINISH) {
             store_hit(L.rayIndex < 0 ? A.hits2 + ~L.rayIndex : A.hits + L.rayIndex, lane_result(L, C, S, M));

@@ -119,7 +119,7 @@ struct xrt_scene {
     std::vector<LightRec> lightsOnDevice;   // what s->lights holds
     const void *lightsDevPtr = nullptr;
     int firstBatch = 64;
-    int tune[3] = {24, 16, 48};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
+    int tune[4] = {24, 16, 48, 16};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
     std::atomic<bool> busy{false};
     std::atomic<float> progress{0.0f};
 
@@ -377,7 +377,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             B.nCap = (int)shadowCap * nL;
             for (IntersectArgs *a : {&C, &B}) {
                 a->queue = q + k; a->mode = s->sceneMode; a->meshId = 0;
-                a->refillMin = s->tune[0]; a->nodeBurst = s->tune[1]; a->leafBurst = s->tune[2]; a->firstBatch = s->firstBatch;
+                a->refillMin = s->tune[0]; a->nodeBurst = s->tune[1]; a->leafBurst = s->tune[2]; a->coopMax = s->tune[3]; a->firstBatch = s->firstBatch;
             }
             if (hasClosest || hasShadow) {
                 IntersectArgs A = hasClosest ? C : B;
@@ -654,7 +654,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
     HIPCHECK(hipMemsetAsync(s->queues.p, 0, sizeof(unsigned), st));
     IntersectArgs A;
     A.rays = d_rays; A.hits = d_hits; A.index = nullptr; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.nCap = 0; A.queue = s->queues.p; A.mode = mode; A.meshId = meshId;
-    A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.firstBatch = s->firstBatch;
+    A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.coopMax = s->tune[3]; A.firstBatch = s->firstBatch;
     hipEvent_t a0 = nullptr, a1 = nullptr;
     if (stats) {
         a0 = get_event(s, 0); a1 = get_event(s, 1);
@@ -707,9 +707,11 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     }
     xrt_scene *s = new xrt_scene();
     s->device = device;
-    if (const char *t = getenv("XRT_TUNE")) {   // "refill,nodeBurst,leafBurst" — scheduling only, never results
-        int v[3];
-        if (sscanf(t, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3 && v[0] >= 1 && v[0] <= 64 && v[1] >= 1 && v[2] >= 1) { s->tune[0] = v[0]; s->tune[1] = v[1]; s->tune[2] = v[2]; }
+    if (const char *t = getenv("XRT_TUNE")) {   // "refill,nodeBurst,leafBurst[,coopMax]" — scheduling only, never results
+        int v[4] = {0, 0, 0, s->tune[3]};
+        if (sscanf(t, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) >= 3 && v[0] >= 1 && v[0] <= 64 && v[1] >= 1 && v[2] >= 1 && v[3] >= 0 && v[3] <= 64) {
+            for (int i = 0; i < 4; i++) s->tune[i] = v[i];
+        }
     }
     if (device >= 0) {
         hipDeviceProp_t prop;
