@@ -18,6 +18,13 @@ struct ShadeView {
     int addressMode, filtering;
 };
 
+// "long ray first" list of a producer kernel (kernels.hip, predict_heavy); list == nullptr: off
+struct HeavyArgs {
+    int *list = nullptr;    // indices (into the ray array) of the rays estimated to be long
+    int *count = nullptr;
+    float path = 0.0f;      // a ray is long when its stretch inside the scene's root box exceeds this
+};
+
 struct IntersectArgs {
     const xrt_ray *rays;
     xrt_hit *hits;
@@ -30,6 +37,8 @@ struct IntersectArgs {
     int mode, meshId;
     int firstBatch;     // rays of the static first batch of every wave
     int refillMin, nodeBurst, leafBurst;   // scheduling knobs of the persistent loop (defaults in xrt_api.cpp; XRT_TUNE overrides)
+    const int *heavyIdx = nullptr, *nHeavy = nullptr;   // rays of segment 1 to take first (marked in their records)
+    unsigned long long *debugTimes = nullptr;   // [3 * waves]: start / out-of-rays / exit clocks (100 MHz) per wave, development aid
     int coopMax = 16;   // at most this many lanes in a leaf: their triangle lists are dealt to the whole wave
     // optional second segment traced by the same launch: rays2[0 .. (*nDev2) * nMul2) -> hits2 (no index list)
     const xrt_ray *rays2 = nullptr;
@@ -61,6 +70,7 @@ struct ShadeArgs {
     // part B
     const xrt_hit *hitsPrev; const SlotRec *slotPrev; const int *scntPrev; const xrt_hit *shadowHits;
     f4 *lvlA, *lvlB; float *lvlAlpha;
+    HeavyArgs heavy;   // for the rays of generation level+1
 };
 
 int  intersect_stack_capacity(int needed);   // smallest compiled capacity >= needed, or -1
@@ -68,7 +78,8 @@ void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeede
                       hipEvent_t e1 = nullptr);
 int  intersect_blocks_per_cu(int stackNeeded, int mode);
 void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long *counters, hipStream_t st);
-void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase, hipStream_t st, hipEvent_t startEvent = nullptr);
+void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase,
+                   const HeavyArgs &H, hipStream_t st, hipEvent_t startEvent = nullptr);
 void launch_shade(const SceneView &S, const ShadeView &V, const ShadeArgs &X, hipStream_t st);
 void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections, uint32_t *sampleColor,
                          float *sampleF32, hipStream_t st);

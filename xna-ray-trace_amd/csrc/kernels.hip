@@ -52,6 +52,30 @@ __device__ __forceinline__ void store_ray(xrt_ray *dst, v3 o, v3 d, int im, int 
 }
 constexpr int DEAD_RAY = -2;   // ignore_mesh marker of a path without a pixel (edge tiles)
 
+// "Long ray first" scheduling.  One ray that skims a large mesh takes thousands of dependent steps, and a launch ends
+// when its slowest ray does; started last, such a ray keeps a single wave alive long after the other 4095 have
+// left.  Producers (k_raygen, k_shade) therefore estimate a ray's length inside the scene's root box, list the long
+// ones and mark them in the ray record (bit 30 of ignore_tri set to the opposite of its sign bit); the traversal
+// kernel takes the listed rays first and passes over them when it meets them again in the array.  Scheduling only:
+// every ray is traced exactly once, by the same code.
+constexpr int HEAVY_BIT = 0x40000000;
+__device__ __forceinline__ bool heavy_marked(int ignoreTri) { return (((ignoreTri >> 30) ^ (ignoreTri >> 31)) & 1) != 0; }
+__device__ __forceinline__ bool predict_heavy(const SceneView &S, v3 o, v3 d, float heavyPath) {
+    const f4 lo = S.snodes[0], hi = S.snodes[1];
+    float tmin = 0.0f, tmax = FLT_MAX;
+    const float ox[3] = {o.x, o.y, o.z}, dx[3] = {d.x, d.y, d.z}, bl[3] = {lo.x, lo.y, lo.z}, bh[3] = {hi.x, hi.y, hi.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (fabsf(dx[k]) > 1e-6f) {
+            const float inv = __frcp_rn(dx[k]);
+            const float t1 = (bl[k] - ox[k]) * inv, t2 = (bh[k] - ox[k]) * inv;
+            tmin = fmaxf(tmin, fminf(t1, t2));
+            tmax = fminf(tmax, fmaxf(t1, t2));
+        }
+    }
+    return (tmax - tmin) > heavyPath;   // NaN compares false: not listed
+}
+
 // Stream compaction with ONE global atomic per 1024-thread block and round (atomics on one word serialise at
 // ~11 ns each, MI355X_MICROARCH.md "dequeue"): waves post their ballot counts to LDS, thread 0 reserves the
 // block's range, every flagged lane gets base + (lanes of earlier waves) + (earlier lanes of its wave).
@@ -230,7 +254,10 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
     // closest-hit rays): ray g >= n1 is rays2[g - n1]
     int n2 = A.nDev2 ? (*A.nDev2) * A.nMul2 : 0;
     if (n2 > A.nCap2) n2 = A.nCap2;
-    const int n = n1 + n2;
+    // rays of segment 1 that their producer listed as long are taken first (work items 0 .. nH-1)
+    int nH = A.nHeavy ? *A.nHeavy : 0;
+    if (nH > n1) nH = n1;
+    const int n = nH + n1 + n2;
     Lane L;
     L.state = ST_IDLE;
     // Work distribution.  The first 64 rays of every wave are static (no atomic: a grid-wide burst on one word
@@ -247,6 +274,10 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
     int batchNext = (wave * (int)gridDim.x + (int)blockIdx.x) * first;
     int batchEnd = min(batchNext + first, n);
     bool exhausted = batchNext >= n;
+#ifdef XRT_WAVE_TIMES   // development aid (make WAVE_TIMES=1): when this wave ran out of new rays / ended
+    unsigned long long tStart = 0, tDry = 0;
+    if (A.debugTimes) tStart = wall_clock64();
+#endif
     auto guided = [&](int done) { int c = (n - done) / (nWaves * 2); c &= ~63; return c < 64 ? 64 : (c > RAY_BATCH_MAX ? RAY_BATCH_MAX : c); };
     unsigned pfBase = 0;
     int pfChunk = 0;
@@ -263,7 +294,12 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
                     const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pfBase) + qOffset;
                     batchNext = (int)base;
                     batchEnd = min((int)base + pfChunk, n);
-                    if (pfChunk == 0 || (int)base >= n || (int)base < 0) exhausted = true;
+                    if (pfChunk == 0 || (int)base >= n || (int)base < 0) {
+                        exhausted = true;
+#ifdef XRT_WAVE_TIMES
+                        if (A.debugTimes) tDry = wall_clock64();
+#endif
+                    }
                     else {
                         pfChunk = guided(batchEnd);
                         if (lane == 0) pfBase = atomicAdd(A.queue, (unsigned)pfChunk);
@@ -273,19 +309,32 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
                     const int take = min(nIdle, batchEnd - batchNext);
                     const int rank = lanes_below(idle);
                     if (L.state == ST_IDLE && rank < take) {
-                        const int g = batchNext + rank;
-                        int idx = A.index ? A.index[g] : g;
-                        const xrt_ray *src = A.rays + idx;
-                        if (g >= n1) { src = A.rays2 + (g - n1); idx = ~(g - n1); }   // answers of segment 2 go to hits2
+                        const int w = batchNext + rank, g = w - nH;
+                        int idx;
+                        const xrt_ray *src;
+                        if (w < nH) { idx = A.heavyIdx[w]; src = A.rays + idx; }
+                        else if (g < n1) { idx = A.index ? A.index[g] : g; src = A.rays + idx; }
+                        else { src = A.rays2 + (g - n1); idx = ~(g - n1); }   // answers of segment 2 go to hits2
                         v3 o, d; int im, it;
                         load_ray(src, o, d, im, it);
-                        if (im == DEAD_RAY) { L.rayIndex = idx; C.sfound = 0; L.mfound = 0; L.state = ST_FINISH; }
+                        bool skip = false;
+                        if (A.nHeavy && idx >= 0 && heavy_marked(it)) { it ^= HEAVY_BIT; skip = w >= nH; }   // listed: traced as work item < nH
+                        if (skip) {}
+                        else if (im == DEAD_RAY) { L.rayIndex = idx; C.sfound = 0; L.mfound = 0; L.state = ST_FINISH; }
                         else lane_begin(L, C, S, o, d, im, it, idx, M, A.meshId);
                     }
                     batchNext += take;
                 }
             }
-            if (exhausted && idle == ~0ull) break;
+            if (exhausted && idle == ~0ull) {
+#ifdef XRT_WAVE_TIMES
+                if (A.debugTimes && lane == 0) {
+                    unsigned long long *o = A.debugTimes + 3 * (size_t)((int)blockIdx.x * 4 + wave);
+                    o[0] = tStart; o[1] = tDry ? tDry : tStart; o[2] = wall_clock64();
+                }
+#endif
+                break;
+            }
         }
         // while-while: lanes gather in the same phase before the wave pays for that phase's code
         if (M == MODE_SCENE) {
@@ -433,6 +482,7 @@ __global__ __launch_bounds__(256) void k_count(SceneView S, IntersectArgs A, uns
     for (int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x); idx < n; idx += (int)(gridDim.x * blockDim.x)) {
         v3 o, d; int im, it;
         load_ray(A.rays + (A.index ? A.index[idx] : idx), o, d, im, it);
+        if (A.nHeavy && heavy_marked(it)) it ^= HEAVY_BIT;
         if (im == DEAD_RAY) continue;
         c[C_RAYS]++;
         Lane L;
@@ -522,14 +572,14 @@ __device__ __forceinline__ bool path_pixel(const RayGenParams &g, long long pix,
 // Rays that miss the scene octree's root box are answered here (OSM:318-320: no cuboid collected -> return
 // false) and the others are appended, wave by wave, to a compact index list for the traversal kernel.
 __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneView S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P,
-                                                         long long pathBase) {
+                                                         long long pathBase, HeavyArgs H) {
     __shared__ int ldsCounts[17];
     const f4 rlo = S.snodes[0], rhi = S.snodes[1];
     const int stride = (int)(gridDim.x * blockDim.x);
     const int rounds = (P + stride - 1) / stride;
     for (int it = 0; it < rounds; it++) {
         const int p = it * stride + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-        bool live = false;
+        bool live = false, heavy = false;
         if (p < P) {
             long long gp = pathBase + p;
             int s = (int)(gp % g.samples);
@@ -557,22 +607,27 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
                     float key;
                     live = slab(w, rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, key);   // OSM:460 on the root
                 }
-                if (live || !index) store_ray(rays + p, nearP, dir, -1, -1);   // a culled ray is never read again
+                heavy = live && H.list && predict_heavy(S, nearP, dir, H.path);
+                if (live || !index) store_ray(rays + p, nearP, dir, -1, heavy ? (-1 ^ HEAVY_BIT) : -1);   // a culled ray is never read again
             }
             if (index && !live) lvlB0[p] = f4{0, 0, 0, i2f(FLAG_MISS)};   // generation 0 ends here (RT:729-733)
         }
         if (index) {   // block-uniform
             const int slot = block_append(count, live, ldsCounts);
             if (live) index[slot] = p;
+            if (H.list) {
+                const int hs = block_append(H.count, heavy, ldsCounts);
+                if (heavy) H.list[hs] = p;
+            }
         }
     }
 }
 void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase,
-                   hipStream_t st, hipEvent_t startEvent) {
+                   const HeavyArgs &H, hipStream_t st, hipEvent_t startEvent) {
     int blocks = (P + APPEND_BLOCK - 1) / APPEND_BLOCK;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipExtLaunchKernelGGL(k_raygen, dim3(blocks), dim3(APPEND_BLOCK), 0, st, startEvent, nullptr, 0, g, S, rays, lvlB0, index, count, P, pathBase);
+    hipExtLaunchKernelGGL(k_raygen, dim3(blocks), dim3(APPEND_BLOCK), 0, st, startEvent, nullptr, 0, g, S, rays, lvlB0, index, count, P, pathBase, H);
 }
 
 // ---- shading ----------------------------------------------------------------------------------------------------------
@@ -764,9 +819,14 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
         }
         if (!emitNext) continue;
         if (!X.heap) {   // chain of reflections: the ray of generation k+1 sits at its parent's slot
+            const bool heavy = hit && X.heavy.list && predict_heavy(S, w, rdir, X.heavy.path);
             if (hit) {
-                store_ray(X.nextRays + slot, w, rdir, mesh, tri);   // origin = result.triangle (RT:559)
+                store_ray(X.nextRays + slot, w, rdir, mesh, heavy ? (tri ^ HEAVY_BIT) : tri);   // origin = result.triangle (RT:559)
                 X.nextPath[slot] = p;
+            }
+            if (X.heavy.list) {
+                const int hs = block_append(X.heavy.count, heavy, ldsCounts);
+                if (heavy) X.heavy.list[hs] = slot;
             }
             continue;
         }

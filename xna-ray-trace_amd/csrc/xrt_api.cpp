@@ -86,7 +86,7 @@ struct xrt_scene {
     // per-frame work buffers
     DevBuf<xrt_ray> rays0, rays1, shadowRays, apiRays;
     DevBuf<xrt_hit> hits, hits1, shadowHits, apiHits;
-    DevBuf<int> path0, path1, node0, node1, index0, cnts;
+    DevBuf<int> path0, path1, node0, node1, index0, heavyList, cnts;
     DevBuf<SlotRec> slot0, slot1;
     DevBuf<float> ref0, ref1, lvlAlpha;
     DevBuf<unsigned> queues;
@@ -95,6 +95,9 @@ struct xrt_scene {
     DevBuf<float> sampleF32, outF32;
     DevBuf<LightRec> lights;
     DevBuf<unsigned long long> counters;
+    float heavyPath = 0.0f;   // rays longer than this inside the root box are traced first (0: off); XRT_HEAVY=<fraction of the box diagonal>
+    std::string waveTimesPath;
+    DevBuf<unsigned long long> waveTimes;   // XRT_WAVE_TIMES=<file>: per-wave clocks of the last frame's launches (development aid)
     // Per-frame host state.  Two contexts so that the next frame can be enqueued while the previous one's counters
     // and timings are still on their way back (xrt_render_device_begin / _end).
     struct FrameCtx {
@@ -137,7 +140,7 @@ struct xrt_scene {
             childDfs.release(); srefs.release(); objMesh.release(); meshes.release();
             objects.release(); materials.release(); texels.release();
             rays0.release(); rays1.release(); shadowRays.release(); apiRays.release(); hits.release();
-            shadowHits.release(); apiHits.release(); path0.release(); path1.release(); hits1.release(); slot0.release(); slot1.release(); index0.release();
+            shadowHits.release(); apiHits.release(); path0.release(); path1.release(); hits1.release(); slot0.release(); slot1.release(); index0.release(); heavyList.release();
             node0.release(); node1.release(); ref0.release(); ref1.release(); lvlAlpha.release();
             cnts.release(); queues.release(); lvlA.release(); lvlB.release(); sampleColor.release();
             outRGBA.release(); sampleF32.release(); outF32.release(); lights.release(); counters.release();
@@ -297,16 +300,20 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // buffers
     if ((rc = s->rays0.ensure(rayCap)) || (rc = s->rays1.ensure(rayCap)) || (rc = s->hits.ensure(rayCap)) || (rc = s->path0.ensure(rayCap)) ||
         (rc = s->path1.ensure(rayCap)) || (rc = s->hits1.ensure(rayCap)) || (rc = s->slot0.ensure(rayCap)) ||
-        (rc = s->slot1.ensure(rayCap)) || (rc = s->index0.ensure(P)) || (rc = s->shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
+        (rc = s->slot1.ensure(rayCap)) || (rc = s->index0.ensure(P)) || (rc = s->heavyList.ensure(rayCap)) || (rc = s->shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
         (rc = s->shadowHits.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = s->lvlA.ensure((size_t)P * nodes)) ||
         (rc = s->lvlB.ensure((size_t)P * nodes)) || (rc = s->sampleColor.ensure(P)) || (rc = s->lights.ensure(nL > 0 ? nL : 1)) ||
         (rc = s->counters.ensure(2 * C_COUNT + 8)))
         return rc;
+    if (!s->waveTimesPath.empty() && !s->waveTimes.p) {
+        if ((rc = s->waveTimes.ensure((size_t)16 * 3 * 8192))) return rc;
+        HIPCHECK(hipMemset(s->waveTimes.p, 0, (size_t)16 * 3 * 8192 * sizeof(unsigned long long)));
+    }
     if (heap && ((rc = s->node0.ensure(rayCap)) || (rc = s->node1.ensure(rayCap)) || (rc = s->ref0.ensure(rayCap)) || (rc = s->ref1.ensure(rayCap)) ||
                  (rc = s->lvlAlpha.ensure((size_t)P * nodes))))
         return rc;
     if (wantF32 && (rc = s->sampleF32.ensure((size_t)P * 3))) return rc;
-    const int cntStride = 2 * (R + 2);          // per chunk: cnt[R+2] then scnt[R+2]
+    const int cntStride = 3 * (R + 2);          // per chunk: cnt[R+2], scnt[R+2], then the long-ray list lengths [R+2]
     const int qStride = 2 * (R + 1);
     // The common frame (one chunk, no supersampling levels, no ray tree, no counting pass) puts nothing but its kernels
     // on the stream: counters come back through k_compose's epilogue and the frame's events ride on raygen / compose.
@@ -360,9 +367,12 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // (both exist once k_shade has looked at the hits of generation k-1); k_shade #k then shades generation k-1 with the
     // shadow answers and turns the hits of generation k into shadow rays and the rays of generation k+1.
     auto enqueue_chunk = [&](const RayGenParams &gp, int *cnt, unsigned *q, int Pc, long long pathBase) -> int {
-        int *scnt = cnt + (R + 2);
+        int *scnt = cnt + (R + 2), *hcnt = cnt + 2 * (R + 2);
+        // "long ray first" (kernels.hip): the producer of generation k lists its long rays, launch #k takes them first
+        const bool listLong = s->heavyPath > 0.0f;
+        auto heavy_for = [&](int k) { HeavyArgs H; if (listLong && (k == 0 || !heap)) { H.list = s->heavyList.p; H.count = hcnt + k; H.path = s->heavyPath; } return H; };
         // cnt[0] counts the primary rays that reach the scene's root box; index0 lists them
-        launch_raygen(gp, S, rays[0], s->lvlB.p, s->index0.p, cnt, Pc, pathBase, st, fast ? e0 : nullptr);
+        launch_raygen(gp, S, rays[0], s->lvlB.p, s->index0.p, cnt, Pc, pathBase, heavy_for(0), st, fast ? e0 : nullptr);
         xrt_hit *hitsOf[2] = {s->hits.p, s->hits1.p};
         SlotRec *slotOf[2] = {s->slot0.p, s->slot1.p};
         for (int k = 0; k <= R + 1; k++) {
@@ -373,6 +383,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             IntersectArgs C, B;   // closest-hit segment, shadow segment
             C.rays = rays[cur]; C.hits = hitsOf[cur]; C.index = k == 0 ? s->index0.p : nullptr; C.nDev = nClosest; C.nMul = 1; C.n = Pc;
             C.nCap = (int)rayCap;
+            { const HeavyArgs H = heavy_for(k); C.heavyIdx = H.list; C.nHeavy = H.count; }
             B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.index = nullptr; B.nDev = hasShadow ? scnt + (k - 1) : nullptr; B.nMul = nL; B.n = 0;
             B.nCap = (int)shadowCap * nL;
             for (IntersectArgs *a : {&C, &B}) {
@@ -385,6 +396,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 pairs.push_back({ev, ev + 1}); ev += 2;
+                if (s->waveTimes.p && k < 16) A.debugTimes = s->waveTimes.p + (size_t)k * 3 * 8192;
                 launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st, a0, a1);
                 if (opts->collect_stats) {   // generation 0: the live list; culled rays are added in frame_finish
                     if (hasClosest) launch_count(S, C, s->counters.p, st);
@@ -403,6 +415,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             X.nextCnt = cnt + k + 1; X.nextCap = (int)rayCap;
             X.hitsPrev = hitsOf[prv]; X.slotPrev = slotOf[prv]; X.scntPrev = k >= 1 ? scnt + (k - 1) : nullptr; X.shadowHits = s->shadowHits.p;
             X.lvlA = s->lvlA.p; X.lvlB = s->lvlB.p; X.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
+            if (k < R) X.heavy = heavy_for(k + 1);
             launch_shade(S, V, X, st);
         }
         if (heap) launch_compose_tree(s->lvlA.p, s->lvlB.p, s->lvlAlpha.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
@@ -593,6 +606,11 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
     F.pending = false;
     HIPCHECK(hipEventSynchronize(F.fast ? F.events[1] : F.done));
     s->progress.store(1.0f);
+    if (s->waveTimes.p) {   // development aid: launch k of the frame occupies rows [k*8192, (k+1)*8192) x 3 clocks
+        std::vector<unsigned long long> h((size_t)16 * 3 * 8192);
+        HIPCHECK(hipMemcpy(h.data(), s->waveTimes.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(s->waveTimesPath.c_str(), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+    }
     const int R = F.R;
     if (F.tallyChunks > 0) {   // single-pass frame: the read-back was left in flight
         const size_t nb = (size_t)F.tallyChunks * F.cntStride * sizeof(int);
@@ -707,6 +725,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     }
     xrt_scene *s = new xrt_scene();
     s->device = device;
+    s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
     if (const char *t = getenv("XRT_TUNE")) {   // "refill,nodeBurst,leafBurst[,coopMax]" — scheduling only, never results
         int v[4] = {0, 0, 0, s->tune[3]};
         if (sscanf(t, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) >= 3 && v[0] >= 1 && v[0] <= 64 && v[1] >= 1 && v[2] >= 1 && v[3] >= 0 && v[3] <= 64) {
@@ -784,6 +803,20 @@ int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_thre
     scene->blocksPerCU = intersect_blocks_per_cu(scene->stackNeeded, scene->sceneMode);
     scene->blocksPerCUMesh = intersect_blocks_per_cu(scene->stackNeeded, MODE_MESH);
     scene->firstBatch = (A.meshDepth == 0) ? 256 : 64;   // every mesh is a single leaf: rays are cheap, avoid queue traffic
+    {   // "long ray first": worth it only where rays can be long, i.e. where some mesh has a real octree
+        float frac = 0.25f;
+        if (const char *e = getenv("XRT_HEAVY")) frac = (float)atof(e);
+        scene->heavyPath = 0.0f;
+        // (measured: +24 % on the 1M-triangle heightfield, whose stragglers are rays skimming the terrain; nothing on the
+        //  instanced grid, whose rays are all about as long as the box -- XRT_HEAVY forces it on for any scene)
+        const bool wanted = getenv("XRT_HEAVY") != nullptr || scene->sceneMode == MODE_SINGLE;
+        if (wanted && frac > 0.0f && A.meshDepth > 0 && A.snodes.size() >= 2) {
+            const f4 lo = A.snodes[0], hi = A.snodes[1];
+            const double dx = (double)hi.x - lo.x, dy = (double)hi.y - lo.y, dz = (double)hi.z - lo.z;
+            const double diag = std::sqrt(dx * dx + dy * dy + dz * dz);
+            if (diag > 0.0 && diag < 1e30) scene->heavyPath = (float)(frac * diag);
+        }
+    }
     scene->resident = true;
     return XRT_OK;
 }
@@ -933,7 +966,7 @@ int xrt_generate_primary_rays(xrt_scene *scene, const xrt_camera *camera, xrt_ra
     if (slots > MAX_CHUNK_PATHS * 8LL) return fail(XRT_E_INVALID_ARG, "frame too large");
     if ((rc = scene->apiRays.ensure((size_t)slots))) return rc;
     hipStream_t st = scene->stream;
-    launch_raygen(g, scene->view, scene->apiRays.p, nullptr, nullptr, nullptr, (int)slots, 0, st);
+    launch_raygen(g, scene->view, scene->apiRays.p, nullptr, nullptr, nullptr, (int)slots, 0, HeavyArgs(), st);
     HIPCHECK(hipGetLastError());
     std::vector<xrt_ray> tmp((size_t)slots);
     HIPCHECK(hipMemcpyAsync(tmp.data(), scene->apiRays.p, (size_t)slots * sizeof(xrt_ray), hipMemcpyDeviceToHost, st));
