@@ -563,7 +563,8 @@ __device__ __forceinline__ bool path_pixel(const RayGenParams &g, long long pix,
     int within = (int)(pix & 511);
     long long t = slot * g.shardCount + g.shardRank;
     if (t >= (long long)g.tilesX * g.tilesY) return false;
-    int tx = (int)(t % g.tilesX), ty = (int)(t / g.tilesX);
+    const unsigned ti = (unsigned)t;   // tilesX * tilesY < 2^31: one 32-bit division instead of two 64-bit ones
+    const int ty = (int)(ti / (unsigned)g.tilesX), tx = (int)(ti - (unsigned)ty * (unsigned)g.tilesX);
     x = tx * XRT_TILE_W + (within & 63);
     y = ty * XRT_TILE_H + (within >> 6);
     return x < g.width && y < g.height;
@@ -579,14 +580,17 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
     const int rounds = (P + stride - 1) / stride;
     for (int it = 0; it < rounds; it++) {
         const int p = it * stride + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-        bool live = false, heavy = false;
+        bool live = false, heavy = false, record = true;
         if (p < P) {
             long long gp = pathBase + p;
-            int s = (int)(gp % g.samples);
+            const int sshift = g.samples == 16 ? 4 : (g.samples == 4 ? 2 : 0);   // samples is 1, 4 or 16
+            int s = (int)(gp & (long long)(g.samples - 1));
             int x = 0, y = 0;
             const bool listed = g.quadLevel > 0;   // quadrant centres come from a list, every entry is valid
-            if (!listed && !path_pixel(g, gp / g.samples, x, y)) {
+            if (!listed && !path_pixel(g, gp >> sshift, x, y)) {
                 if (!index) store_ray(rays + p, mk(0, 0, 0), mk(0, 0, 0), DEAD_RAY, -1);
+            } else if (index && !listed && (x < g.cullX0 || x > g.cullX1 || y < g.cullY0 || y > g.cullY1)) {
+                record = g.cullSkipsRecord == 0;   // cannot reach the root box (RayGenParams): live stays false
             } else {
                 float sx = (float)x, sy = (float)y;
                 if (g.quadLevel >= 0) {   // RT:218-276: four rays at centre -+ size/4, order UL, UR, LL, LR
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
                 heavy = live && H.list && predict_heavy(S, nearP, dir, H.path);
                 if (live || !index) store_ray(rays + p, nearP, dir, -1, heavy ? (-1 ^ HEAVY_BIT) : -1);   // a culled ray is never read again
             }
-            if (index && !live) lvlB0[p] = f4{0, 0, 0, i2f(FLAG_MISS)};   // generation 0 ends here (RT:729-733)
+            if (index && !live && record) lvlB0[p] = f4{0, 0, 0, i2f(FLAG_MISS)};   // generation 0 ends here (RT:729-733)
         }
         if (index) {   // block-uniform
             const int slot = block_append(count, live, ldsCounts);
@@ -861,10 +865,17 @@ __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB,
         }
         __threadfence_system();
     }
+    const int sshift = RA.g.samples == 16 ? 4 : (RA.g.samples == 4 ? 2 : 0);
     for (int p = (int)(blockIdx.x * blockDim.x + threadIdx.x); p < count; p += (int)(gridDim.x * blockDim.x)) {
         int kd = 0;
-        int flag;
-        for (;;) {
+        int flag = FLAG_MISS;
+        bool culled = false;
+        if (RA.g.cullSkipsRecord && RA.g.quadLevel <= 0) {   // k_raygen left no record for pixels that cannot reach the root box
+            int cx, cy;
+            if (path_pixel(RA.g, (RA.pixelBase + p) >> sshift, cx, cy))
+                culled = cx < RA.g.cullX0 || cx > RA.g.cullX1 || cy < RA.g.cullY0 || cy > RA.g.cullY1;
+        }
+        while (!culled) {
             flag = f2i(lvlB[(size_t)kd * P + p].w);
             if (!(flag & FLAG_HIT) || kd == maxReflections) break;
             kd++;
@@ -1107,13 +1118,21 @@ __global__ __launch_bounds__(256) void k_detile(int width, int height, int shard
                                                 const uint32_t *gathered, uint32_t *out) {
     const long long total = (long long)shardCount * tilesPerRank * 512;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        int rank = (int)(i / ((long long)tilesPerRank * 512));
-        long long rem = i % ((long long)tilesPerRank * 512);
+        int rank;
+        long long rem;
+        if (total <= 0x7fffffffLL) {   // every real frame: one 32-bit division
+            const unsigned per = (unsigned)tilesPerRank * 512u, q = (unsigned)i / per;
+            rank = (int)q; rem = (long long)((unsigned)i - q * per);
+        } else {
+            rank = (int)(i / ((long long)tilesPerRank * 512));
+            rem = i % ((long long)tilesPerRank * 512);
+        }
         long long slot = rem >> 9;
         int within = (int)(rem & 511);
         long long t = slot * shardCount + rank;
         if (t >= (long long)tilesX * tilesY) continue;
-        int x = (int)(t % tilesX) * XRT_TILE_W + (within & 63), y = (int)(t / tilesX) * XRT_TILE_H + (within >> 6);
+        const unsigned ti = (unsigned)t, tyq = ti / (unsigned)tilesX;
+        int x = (int)(ti - tyq * (unsigned)tilesX) * XRT_TILE_W + (within & 63), y = (int)tyq * XRT_TILE_H + (within >> 6);
         if (x < width && y < height) out[(size_t)y * width + x] = gathered[i];
     }
 }

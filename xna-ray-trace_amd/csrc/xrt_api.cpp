@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -225,7 +226,7 @@ LightRec make_light(const xrt_light &l) {
     return r;
 }
 
-int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g) {
+int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g, const float *rootBox = nullptr /* min xyz, max xyz */) {
     if (cam->vp_width <= 0 || cam->vp_height <= 0) return fail(XRT_E_INVALID_ARG, "viewport must be positive");
     float wv[16], wvp[16], ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     mat_multiply(ident, cam->view, wv);     // Matrix.Multiply(world = Identity, view)   (Viewport.Unproject, RT:415)
@@ -239,7 +240,42 @@ int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g
     g.shardRank = o->shard_count > 1 ? o->shard_rank : 0;
     g.samples = (o->use_multisampling == XRT_MS_FIXED16) ? 16 : 1;
     g.quadLevel = -1; g.quadCx = nullptr; g.quadCy = nullptr; g.quadSize = 1.0f;
+    g.cullX0 = 0; g.cullY0 = 0; g.cullX1 = g.width - 1; g.cullY1 = g.height - 1;
+    g.cullSkipsRecord = 0;
     if (g.shardRank < 0 || g.shardRank >= g.shardCount) return fail(XRT_E_INVALID_ARG, "shard_rank out of range");
+    if (rootBox && !getenv("XRT_NO_RECT_CULL")) {
+        // Screen rectangle of the scene's root box.  A ray through pixel (x, y) that reaches the box at a point P has P
+        // projecting onto (x, y); the box is convex, so with all eight corners in front of the eye every such pixel lies
+        // inside the corners' bounding rectangle.  Evaluated in double from the same float matrices; used only when
+        // every corner has a clearly positive w and comes back through the inverse matrix k_raygen uses (its pixel and
+        // depth unprojected again) to within a thousandth of the box diagonal.
+        bool ok = true;
+        double x0 = 1e300, y0 = 1e300, x1 = -1e300, y1 = -1e300;
+        for (int c = 0; c < 8 && ok; c++) {
+            const double p[3] = {rootBox[(c & 1) ? 3 : 0], rootBox[(c & 2) ? 4 : 1], rootBox[(c & 4) ? 5 : 2]};
+            double v[4];
+            for (int j = 0; j < 4; j++) v[j] = p[0] * wvp[j] + p[1] * wvp[4 + j] + p[2] * wvp[8 + j] + wvp[12 + j];
+            const double scale = std::fabs(v[0]) + std::fabs(v[1]) + std::fabs(v[2]) + std::fabs(v[3]);
+            if (!(v[3] > 1e-3 * scale) || !(scale < 1e30)) { ok = false; break; }
+            const double sx = (v[0] / v[3] + 1.0) * 0.5 * g.vpW + g.vpX, sy = (1.0 - v[1] / v[3]) * 0.5 * g.vpH + g.vpY;
+            {   // round trip through g.m
+                const double n[4] = {v[0] / v[3], v[1] / v[3], v[2] / v[3], 1.0};
+                double u[4];
+                for (int j = 0; j < 4; j++) u[j] = n[0] * g.m[j] + n[1] * g.m[4 + j] + n[2] * g.m[8 + j] + g.m[12 + j];
+                const double ddx = rootBox[3] - (double)rootBox[0], ddy = rootBox[4] - (double)rootBox[1], ddz = rootBox[5] - (double)rootBox[2];
+                const double tol = 1e-3 * std::sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+                if (!(std::fabs(u[3]) > 1e-30) || !(std::fabs(u[0] / u[3] - p[0]) <= tol && std::fabs(u[1] / u[3] - p[1]) <= tol && std::fabs(u[2] / u[3] - p[2]) <= tol)) { ok = false; break; }
+            }
+            x0 = std::min(x0, sx); x1 = std::max(x1, sx); y0 = std::min(y0, sy); y1 = std::max(y1, sy);
+        }
+        if (ok && x0 <= x1 && y0 <= y1) {
+            const double mx = 2.0 + 1e-3 * g.vpW, my = 2.0 + 1e-3 * g.vpH;
+            // (k_raygen's pixel coordinates are the screen coordinates Viewport.Unproject is given, RT:415)
+            const double fx0 = std::floor(x0 - mx), fy0 = std::floor(y0 - my), fx1 = std::ceil(x1 + mx), fy1 = std::ceil(y1 + my);
+            g.cullX0 = (int)std::max(0.0, std::min(fx0, (double)g.width)); g.cullY0 = (int)std::max(0.0, std::min(fy0, (double)g.height));
+            g.cullX1 = (int)std::min((double)g.width - 1, std::max(fx1, -1.0)); g.cullY1 = (int)std::min((double)g.height - 1, std::max(fy1, -1.0));
+        }
+    }
     return XRT_OK;
 }
 
@@ -268,9 +304,16 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const int quality = adaptive ? opts->multisample_quality : 0;
     if (adaptive && (quality < 0 || quality > 6)) return fail(XRT_E_UNSUPPORTED, "MultisampleQuality above 6 (4^7 sub-quadrants per pixel)");
     RayGenParams g;
-    int rc = make_raygen(cam, opts, g);
+    float rootBox[6] = {0, 0, 0, 0, 0, 0};
+    const bool haveRoot = s->hs.arrays.snodes.size() >= 2;
+    if (haveRoot) {
+        const f4 lo = s->hs.arrays.snodes[0], hi = s->hs.arrays.snodes[1];
+        rootBox[0] = lo.x; rootBox[1] = lo.y; rootBox[2] = lo.z; rootBox[3] = hi.x; rootBox[4] = hi.y; rootBox[5] = hi.z;
+    }
+    int rc = make_raygen(cam, opts, g, haveRoot ? rootBox : nullptr);
     if (rc != XRT_OK) return rc;
     if (adaptive) g.samples = 4;
+    g.cullSkipsRecord = heap ? 0 : 1;   // (k_compose_tree reads every root record)
     const int R = opts->max_reflections;
     const int nL = nLights;
     const long long totalTiles = (long long)g.tilesX * g.tilesY;

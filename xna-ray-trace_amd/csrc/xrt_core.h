@@ -270,6 +270,11 @@ struct RayGenParams {
     int   quadLevel;               // adaptive supersampling (RT:215-311): -1 off; level 0 quadrants are the pixels,
     const float *quadCx, *quadCy;  // deeper ones are listed (centre per quadrant)
     float quadSize;                // 1, 0.5, 0.25 ... (RT:195, RT:290 size / 2.0f)
+    // Pixels outside this rectangle cannot reach the scene's root box (its eight corners projected to the screen, two
+    // pixels of margin; the whole viewport when a corner is not safely in front of the eye): k_raygen answers them
+    // (OSM:318-320) without building their rays.
+    int   cullX0, cullY0, cullX1, cullY1;
+    int   cullSkipsRecord;         // k_compose knows the rectangle too: no generation-0 record is written or read for those pixels
 };
 
 // One Viewport.Unproject (RT:415 / RT:419) given the hoisted inverse matrix.
