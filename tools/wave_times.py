@@ -11,7 +11,7 @@ spec = xrt.configs.config(name)
 scene, tracer = xrt.configs.build_product(spec)
 out = torch.zeros(spec.width * spec.height, dtype=torch.int32, device="cuda")
 fr = tracer.PrepareDevice(out.data_ptr())
-for _ in range(3):
+for _ in range(int(os.environ.get("XRT_FRAMES", "12"))):
     fr()
 t = np.fromfile(path, dtype=np.uint64).reshape(16, 8192, 3).astype(np.int64)
 for k in range(16):

@@ -22,7 +22,11 @@ struct ShadeView {
 struct HeavyArgs {
     int *list = nullptr;    // indices (into the ray array) of the rays estimated to be long
     int *count = nullptr;
-    float path = 0.0f;      // a ray is long when its stretch inside the scene's root box exceeds this
+    float path = 0.0f;      // geometric estimate: long when the stretch inside the scene's root box exceeds this (0: off)
+    // feedback estimate: what the ray of the same path and generation cost in a recent frame (kernels.hip, cost map)
+    const unsigned *costMap = nullptr;   // [paths] of this generation: (frame number << 16) | cost
+    unsigned epoch = 0;                  // this frame's number
+    int costThreshold = 0;               // long when the remembered cost exceeds this
 };
 
 struct IntersectArgs {
@@ -71,6 +75,8 @@ struct ShadeArgs {
     const xrt_hit *hitsPrev; const SlotRec *slotPrev; const int *scntPrev; const xrt_hit *shadowHits;
     f4 *lvlA, *lvlB; float *lvlAlpha;
     HeavyArgs heavy;   // for the rays of generation level+1
+    unsigned *costOut = nullptr;   // cost map of generation `level` (part A writes what its rays cost), tagged with `epoch`
+    unsigned epoch = 0;
 };
 
 int  intersect_stack_capacity(int needed);   // smallest compiled capacity >= needed, or -1

@@ -35,7 +35,7 @@ __device__ __forceinline__ void store_hit(xrt_hit *dst, const HitOut &h) {
     Hit16 *p = reinterpret_cast<Hit16 *>(dst);
     p[0] = Hit16{h.hit, h.object, h.mesh, h.tri};
     p[1] = Hit16{h.leaf, f2i(h.u), f2i(h.v), f2i(h.d)};
-    p[2] = Hit16{f2i(h.wx), f2i(h.wy), f2i(h.wz), 0};
+    p[2] = Hit16{f2i(h.wx), f2i(h.wy), f2i(h.wz), h.cost};   // (reserved word: scheduling feedback)
 }
 __device__ __forceinline__ void load_ray(const xrt_ray *src, v3 &o, v3 &d, int &im, int &it) {
     const f4 *p = reinterpret_cast<const f4 *>(src);
@@ -74,6 +74,17 @@ __device__ __forceinline__ bool predict_heavy(const SceneView &S, v3 o, v3 d, fl
         }
     }
     return (tmax - tmin) > heavyPath;   // NaN compares false: not listed
+}
+// Feedback: a frame remembers, per path and generation, how many rounds of the traversal loop its ray was in flight
+// (the hit record's reserved word -> k_shade -> the cost map).  The next frames list a ray as long when the ray that
+// stood in its place cost more than a threshold the host steers to a few percent of the rays.  A camera that moves
+// makes the memory slightly stale, never wrong: the list only decides which rays start first.
+__device__ __forceinline__ bool long_ray(const SceneView &S, const HeavyArgs &H, int path, v3 o, v3 d) {
+    if (H.costMap) {
+        const unsigned e = H.costMap[path];
+        if (((H.epoch - (e >> 16)) & 0xffffu) - 1u < 4u) return (int)(e & 0xffffu) > H.costThreshold;   // written one to four frames ago
+    }
+    return H.path > 0.0f && predict_heavy(S, o, d, H.path);
 }
 
 // Stream compaction with ONE global atomic per 1024-thread block and round (atomics on one word serialise at
@@ -286,6 +297,7 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
         if (lane == 0) pfBase = atomicAdd(A.queue, (unsigned)pfChunk);
     }
     for (;;) {
+        if (L.state != ST_IDLE) L.cost++;
         const unsigned long long idle = __ballot(L.state == ST_IDLE);
         if (idle != 0ull) {
             const int nIdle = __popcll(idle);
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
                         bool skip = false;
                         if (A.nHeavy && idx >= 0 && heavy_marked(it)) { it ^= HEAVY_BIT; skip = w >= nH; }   // listed: traced as work item < nH
                         if (skip) {}
-                        else if (im == DEAD_RAY) { L.rayIndex = idx; C.sfound = 0; L.mfound = 0; L.state = ST_FINISH; }
+                        else if (im == DEAD_RAY) { L.rayIndex = idx; L.cost = 0; C.sfound = 0; L.mfound = 0; L.state = ST_FINISH; }
                         else lane_begin(L, C, S, o, d, im, it, idx, M, A.meshId);
                     }
                     batchNext += take;
@@ -611,7 +623,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
                     float key;
                     live = slab(w, rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, key);   // OSM:460 on the root
                 }
-                heavy = live && H.list && predict_heavy(S, nearP, dir, H.path);
+                heavy = live && H.list && long_ray(S, H, p, nearP, dir);
                 if (live || !index) store_ray(rays + p, nearP, dir, -1, heavy ? (-1 ^ HEAVY_BIT) : -1);   // a culled ray is never read again
             }
             if (index && !live && record) lvlB0[p] = f4{0, 0, 0, i2f(FLAG_MISS)};   // generation 0 ends here (RT:729-733)
@@ -789,6 +801,10 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
             if (X.index) i = X.index[j];   // generation 0: only the rays that reached the scene's root box were traced
             load_hit(X.hits + i, hit, object, mesh, tri, u, v, d, w);
             p = X.rayPath ? X.rayPath[i] : i;
+            if (X.costOut) {
+                const int c = reinterpret_cast<const Hit16 *>(X.hits + i)[2].i3;
+                X.costOut[p] = (X.epoch << 16) | (unsigned)(c > 0xffff ? 0xffff : (c < 0 ? 0 : c));
+            }
             if (X.heap) { node = X.rayNode ? X.rayNode[i] : 0; curRef = X.rayRef ? X.rayRef[i] : 1.0f; }   // generation 0: root, in vacuum (RT:424)
             if (!hit) X.lvlB[(size_t)node * P + p] = f4{0, 0, 0, i2f(FLAG_MISS)};
         }
@@ -823,7 +839,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
         }
         if (!emitNext) continue;
         if (!X.heap) {   // chain of reflections: the ray of generation k+1 sits at its parent's slot
-            const bool heavy = hit && X.heavy.list && predict_heavy(S, w, rdir, X.heavy.path);
+            const bool heavy = hit && X.heavy.list && long_ray(S, X.heavy, p, w, rdir);
             if (hit) {
                 store_ray(X.nextRays + slot, w, rdir, mesh, heavy ? (tri ^ HEAVY_BIT) : tri);   // origin = result.triangle (RT:559)
                 X.nextPath[slot] = p;

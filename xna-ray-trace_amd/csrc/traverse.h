@@ -71,7 +71,8 @@ struct Lane {
     // leaf scan
     int ref, refEnd, leafNode;
     float leafKey;
-    int spec;            // the last leaf step met a front-facing triangle: fetch geometry together with the normals
+    int spec;            // the last leaf step met a triangle facing the ray: fetch geometry together with the normals
+    int cost;            // rounds of the kernel's outer loop this ray has been in flight (scheduling feedback, not a result)
     SceneLane sc;        // plain-register home of the scene-level half (unused where the kernel parks it in LDS)
 };
 
@@ -180,6 +181,7 @@ XRT_HD void begin_mesh_query(Lane &L, const SceneView &S, int mesh) {
 template <class SC>
 XRT_HD void lane_begin(Lane &L, SC &C, const SceneView &S, v3 o, v3 d, int ignoreMesh, int ignoreTri, int rayIndex, int mode, int meshId) {
     L.rayIndex = rayIndex;
+    L.cost = 0;
     L.weird = (is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(d.x) && is_finite(d.y) && is_finite(d.z)) ? 0 : 1;
     L.ignoreId = -1;
     if (ignoreTri >= 0 && ignoreMesh >= 0 && ignoreMesh < S.nMeshes && ignoreTri < S.meshes[ignoreMesh].ntri)
@@ -462,12 +464,14 @@ XRT_HD void advance_leaf(Lane &L, const SceneView &S) {
 struct HitOut {
     int hit, object, mesh, tri, leaf;
     float u, v, d, wx, wy, wz;
+    int cost;
 };
 template <class SC>
 XRT_HD HitOut lane_result(const Lane &L, const SC &C, const SceneView &S, int mode) {
     HitOut h;
     h.hit = 0; h.object = -1; h.mesh = -1; h.tri = -1; h.leaf = -1;
     h.u = 0; h.v = 0; h.d = 0; h.wx = 0; h.wy = 0; h.wz = 0;
+    h.cost = L.cost;
     const bool sc = mode == MODE_SCENE;
     if (!(sc ? (int)C.sfound : L.mfound)) return h;
     const int ref = sc ? (int)C.sbRef : L.mRef, mesh = sc ? (int)C.sbMesh : L.mesh, obj = sc ? (int)C.sbObj : 0;   // MODE_SINGLE: body 0

@@ -96,6 +96,13 @@ struct xrt_scene {
     DevBuf<float> sampleF32, outF32;
     DevBuf<LightRec> lights;
     DevBuf<unsigned long long> counters;
+    // cost feedback (kernels.hip long_ray): per path and generation, what the ray cost in the last frames
+    DevBuf<unsigned> costMap;
+    size_t costMapPaths = 0;
+    unsigned epoch = 100;
+    int costT[66];            // per generation: rays that cost more than this are started first; steered in frame_finish
+    int longFracLo = 2, longFracHi = 6;   // percent of a generation's rays the list is steered to (XRT_LONG_FRAC=lo,hi)
+    bool deepMeshes = false;  // some mesh has a real octree: rays can be long
     float heavyPath = 0.0f;   // rays longer than this inside the root box are traced first (0: off); XRT_HEAVY=<fraction of the box diagonal>
     std::string waveTimesPath;
     DevBuf<unsigned long long> waveTimes;   // XRT_WAVE_TIMES=<file>: per-wave clocks of the last frame's launches (development aid)
@@ -362,6 +369,17 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // on the stream: counters come back through k_compose's epilogue and the frame's events ride on raygen / compose.
     const bool fast = !adaptive && !heap && firstPaths <= chunkPaths && !opts->collect_stats;
     F.fast = fast;
+    if (fast && s->deepMeshes && !getenv("XRT_NO_FEEDBACK")) {
+        const size_t need = (size_t)(R + 1) * (size_t)P;
+        if (s->costMapPaths != (size_t)P || s->costMap.cap < need) {   // new frame geometry: forget
+            if ((rc = s->costMap.ensure(need))) return rc;
+            HIPCHECK(hipMemsetAsync(s->costMap.p, 0, s->costMap.cap * sizeof(unsigned), st));
+            s->costMapPaths = (size_t)P;
+        }
+        s->epoch++;
+    } else if (s->costMap.p) {
+        s->costMap.release(); s->costMapPaths = 0;
+    }
     if (!fast) {
         s->cntsClean = false;
         HIPCHECK(hipMemsetAsync(s->counters.p, 0, (2 * C_COUNT + 8) * sizeof(unsigned long long), st));
@@ -412,8 +430,16 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     auto enqueue_chunk = [&](const RayGenParams &gp, int *cnt, unsigned *q, int Pc, long long pathBase) -> int {
         int *scnt = cnt + (R + 2), *hcnt = cnt + 2 * (R + 2);
         // "long ray first" (kernels.hip): the producer of generation k lists its long rays, launch #k takes them first
-        const bool listLong = s->heavyPath > 0.0f;
-        auto heavy_for = [&](int k) { HeavyArgs H; if (listLong && (k == 0 || !heap)) { H.list = s->heavyList.p; H.count = hcnt + k; H.path = s->heavyPath; } return H; };
+        const bool feedback = fast && s->deepMeshes && s->costMap.p != nullptr;
+        const bool listLong = s->heavyPath > 0.0f || feedback;
+        auto heavy_for = [&](int k) {
+            HeavyArgs H;
+            if (listLong && (k == 0 || !heap)) {
+                H.list = s->heavyList.p; H.count = hcnt + k; H.path = s->heavyPath;
+                if (feedback) { H.costMap = s->costMap.p + (size_t)k * P; H.epoch = s->epoch & 0xffffu; H.costThreshold = s->costT[k]; }
+            }
+            return H;
+        };
         // cnt[0] counts the primary rays that reach the scene's root box; index0 lists them
         launch_raygen(gp, S, rays[0], s->lvlB.p, s->index0.p, cnt, Pc, pathBase, heavy_for(0), st, fast ? e0 : nullptr);
         xrt_hit *hitsOf[2] = {s->hits.p, s->hits1.p};
@@ -459,6 +485,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             X.hitsPrev = hitsOf[prv]; X.slotPrev = slotOf[prv]; X.scntPrev = k >= 1 ? scnt + (k - 1) : nullptr; X.shadowHits = s->shadowHits.p;
             X.lvlA = s->lvlA.p; X.lvlB = s->lvlB.p; X.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
             if (k < R) X.heavy = heavy_for(k + 1);
+            if (feedback && hasClosest) { X.costOut = s->costMap.p + (size_t)k * P; X.epoch = s->epoch & 0xffffu; }
             launch_shade(S, V, X, st);
         }
         if (heap) launch_compose_tree(s->lvlA.p, s->lvlB.p, s->lvlAlpha.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
@@ -666,6 +693,17 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
             }
         }
         if (!F.fast) std::memcpy(F.hcnt, (char *)F.pinned + nb, sizeof(F.hcnt));
+        if (F.fast && s->costMap.p) {   // steer the "long ray" thresholds towards 2-6 % of each generation's rays
+            const int *hc = (const int *)F.pinned;
+            for (int k = 0; k <= R && k < 66; k++) {
+                const long long rays = k == 0 ? hc[0] : hc[(R + 2) + k - 1], listed = hc[2 * (R + 2) + k];
+                if (rays < 4096) continue;
+                if (listed * 100 > rays * s->longFracHi) s->costT[k] = s->costT[k] + s->costT[k] / 4 + 1;
+                else if (listed * 100 < rays * s->longFracLo && s->costT[k] > 1) s->costT[k] = s->costT[k] - s->costT[k] / 5 - (s->costT[k] < 5 ? 1 : 0);
+                if (s->costT[k] < 1) s->costT[k] = 1;
+                if (s->costT[k] > 60000) s->costT[k] = 60000;
+            }
+        }
         F.tallyChunks = 0;
     }
     if (stats) {
@@ -850,6 +888,9 @@ int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_thre
         float frac = 0.25f;
         if (const char *e = getenv("XRT_HEAVY")) frac = (float)atof(e);
         scene->heavyPath = 0.0f;
+        scene->deepMeshes = A.meshDepth > 0;
+        for (int &t : scene->costT) t = 24;
+        if (const char *e = getenv("XRT_LONG_FRAC")) { int lo = 0, hi = 0; if (sscanf(e, "%d,%d", &lo, &hi) == 2 && lo >= 0 && hi > lo && hi <= 100) { scene->longFracLo = lo; scene->longFracHi = hi; } }
         // (measured: +24 % on the 1M-triangle heightfield, whose stragglers are rays skimming the terrain; nothing on the
         //  instanced grid, whose rays are all about as long as the box -- XRT_HEAVY forces it on for any scene)
         const bool wanted = getenv("XRT_HEAVY") != nullptr || scene->sceneMode == MODE_SINGLE;
