@@ -113,7 +113,7 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
     W, H = spec.width, spec.height
     tx, ty, tpr = xrt.dist.shard_layout(W, H, world)
     n_out = tpr * 512 if world > 1 else W * H
-    outs = [torch.zeros(n_out, dtype=torch.int32, device="cuda") for _ in range(2 if world > 1 else 1)] * (1 if world > 1 else 2)
+    outs = [torch.zeros(n_out, dtype=torch.int32, device="cuda") for _ in range(2)]   # two frames are in flight (one per frame context / stream)
     final = torch.zeros(W * H, dtype=torch.int32, device="cuda") if (world > 1 and rank == 0) else None
     # untimed: exact reference-work counters of this rank's shard (algorithmic bytes, ray counts)
     tracer.collect_stats = with_stats

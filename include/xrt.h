@@ -234,13 +234,16 @@ int xrt_render_device(xrt_scene *scene, const xrt_camera *camera, const xrt_ligh
                       int32_t n_lights, const xrt_render_opts *opts, void *d_rgba_out,
                       void *stream, xrt_stats *stats_out /* nullable */);
 
-/* Pipelined form of xrt_render_device.  _begin enqueues the frame on `stream` and returns a ticket while the GPU is
- * still working; _end waits for that frame and fills stats_out (may be NULL).  Up to two frames may be in flight on the
- * same stream, so the host side of frame i+1 (argument marshalling, ~50 launches) overlaps the GPU side of frame i --
- * the reference's game loop does the same with RenderAsync (RT:92-104) and one frame of latency.  d_rgba_out of a frame
- * is complete when its _end returns (or, on the device, for work enqueued on `stream` after _begin).  Frames that need
- * host decisions between passes (adaptive supersampling, Transparent materials, more than one chunk) finish inside
- * _begin.  While a ticket is open every other call that renders or mutates the scene returns XRT_E_BUSY. */
+/* Pipelined form of xrt_render_device.  _begin enqueues the frame and returns a ticket while the GPU is still working;
+ * _end waits for that frame and fills stats_out (may be NULL).  Up to two frames may be in flight, so the host side of
+ * frame i+1 (argument marshalling, ~25 launches) overlaps the GPU side of frame i -- the reference's game loop does the
+ * same with RenderAsync (RT:92-104) and one frame of latency.  With stream == NULL each of the two frame contexts runs
+ * on a stream of its own and the two frames also overlap ON the GPU: a launch of persistent waves leaves the machine
+ * half empty while its last rays finish, and the other frame's kernels fill it (a given stream serialises them
+ * instead).  d_rgba_out of a frame is complete when its _end returns; give the two frames in flight different output
+ * buffers.  Frames that need host decisions between passes (adaptive supersampling, Transparent materials, more than
+ * one chunk) finish inside _begin and never overlap another frame.  While a ticket is open every other call that renders
+ * or mutates the scene returns XRT_E_BUSY. */
 int xrt_render_device_begin(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights,
                             int32_t n_lights, const xrt_render_opts *opts, void *d_rgba_out, void *stream,
                             int32_t *ticket_out);

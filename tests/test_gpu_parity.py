@@ -429,3 +429,22 @@ def test_pipelined_frames_begin_end(xrt):
             assert st[k] == st_want[k], (k, st[k], st_want[k])
         assert st["ms_total"] > 0 and st["ms_intersect"] > 0
     assert np.array_equal(tracer.Render(), want)   # the blocking call works again
+
+
+def test_multi_chunk_frames(xrt, monkeypatch):
+    """Frames larger than one chunk of paths (33.5 M by default) are rendered chunk by chunk; XRT_CHUNK_PATHS forces the
+    same path at a testable size: same frame and same accounting as the single-chunk render, for 1 and 16 sub-rays."""
+    for ms in (False, True):
+        spec = xrt.configs.config("C3", 0.2)
+        spec.multisampling = xrt.abi.MS_FIXED16 if ms else xrt.abi.MS_OFF   # (configs.build_product reads it)
+        scene, tracer = xrt.configs.build_product(spec)
+        want = tracer.Render().copy()
+        st_want = dict(tracer.last_stats)
+        monkeypatch.setenv("XRT_CHUNK_PATHS", "16384")
+        scene2, tracer2 = xrt.configs.build_product(spec)
+        monkeypatch.delenv("XRT_CHUNK_PATHS")
+        got = tracer2.Render()
+        assert np.array_equal(got, want)
+        for k in ("rays_closest", "rays_shadow", "shaded_hits", "pixels"):
+            assert tracer2.last_stats[k] == st_want[k], (k, tracer2.last_stats[k], st_want[k])
+        assert tracer2.last_stats["intersect_launches"] > st_want["intersect_launches"]

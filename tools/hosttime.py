@@ -6,8 +6,9 @@ xrt = importlib.import_module("xna-ray-trace_amd")
 name = sys.argv[1] if len(sys.argv) > 1 else "C2"
 spec = xrt.configs.config(name)
 scene, tracer = xrt.configs.build_product(spec)
-out = torch.zeros(spec.width * spec.height, dtype=torch.int32, device="cuda")
-fr = tracer.PrepareDevice(out.data_ptr())
+outs = [torch.zeros(spec.width * spec.height, dtype=torch.int32, device="cuda") for _ in range(2)]
+frs = [tracer.PrepareDevice(o.data_ptr()) for o in outs]
+fr = frs[0]
 for _ in range(5):
     fr()
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
@@ -16,15 +17,15 @@ t0 = time.perf_counter()
 prev = None
 for i in range(N):
     a = time.perf_counter()
-    t = fr.begin()
+    t = frs[i % 2].begin()
     b = time.perf_counter()
     if prev is not None:
-        st = fr.end(prev)
+        st = frs[(i - 1) % 2].end(prev)
     c = time.perf_counter()
     tb += b - a
     te += c - b
     prev = t
-st = fr.end(prev)
+st = frs[(N - 1) % 2].end(prev)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print("%s: frame %.1f us  begin %.1f us  end(wait) %.1f us  gpu ms_total %.1f us  intersect %.1f us (%d launches)" % (

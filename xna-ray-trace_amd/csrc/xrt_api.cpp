@@ -39,7 +39,11 @@ int fail(int code, const char *fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                                            \
     } while (0)
 
-constexpr int MAX_CHUNK_PATHS = 1 << 22;   // paths in flight per chunk (multiple of 512 * 16)
+// Paths in flight per chunk (multiple of 512 * 16).  ~400 bytes of work buffers per path: 1920x1080 at 16 samples per
+// pixel (33.2 M paths) is one chunk of 13 GB per frame context -- sized for 288 GB of HBM, so that whole frames take the
+// single-chunk path (no host round trips, two frames overlapping).
+constexpr int MAX_CHUNK_PATHS = 1 << 25;
+constexpr int HEAP_RAY_CAP = 1 << 22;      // rays per generation of a ray-tree chunk
 
 template <class T>
 struct DevBuf {
@@ -85,17 +89,38 @@ struct xrt_scene {
     int sceneMode = MODE_SCENE;   // MODE_SINGLE when the scene is one SceneObject with one Mesh
     hipStream_t stream = nullptr;
     // per-frame work buffers
-    DevBuf<xrt_ray> rays0, rays1, shadowRays, apiRays;
-    DevBuf<xrt_hit> hits, hits1, shadowHits, apiHits;
-    DevBuf<int> path0, path1, node0, node1, index0, heavyList, cnts;
-    DevBuf<SlotRec> slot0, slot1;
+    DevBuf<xrt_ray> apiRays;
+    DevBuf<xrt_hit> apiHits;
+    DevBuf<int> node0, node1;           // ray-tree frames only (they run alone)
     DevBuf<float> ref0, ref1, lvlAlpha;
     DevBuf<unsigned> queues;
-    DevBuf<f4> lvlA, lvlB;
-    DevBuf<uint32_t> sampleColor, outRGBA;
-    DevBuf<float> sampleF32, outF32;
-    DevBuf<LightRec> lights;
+    DevBuf<uint32_t> outRGBA;
+    DevBuf<float> outF32;
     DevBuf<unsigned long long> counters;
+    // Work buffers of one frame in flight.  Two sets (FrameCtx) so that two frames on two streams can overlap: a launch
+    // of persistent waves leaves the machine half empty while its last rays finish, and the other frame's launches fill it.
+    struct WorkBufs {
+        DevBuf<xrt_ray> rays0, rays1, shadowRays;
+        DevBuf<xrt_hit> hits, hits1, shadowHits;
+        DevBuf<int> path0, path1, index0, heavyList, cnts;
+        DevBuf<SlotRec> slot0, slot1;
+        DevBuf<f4> lvlA, lvlB;
+        DevBuf<uint32_t> sampleColor;
+        DevBuf<float> sampleF32;
+        DevBuf<LightRec> lights;
+        bool cntsClean = false;                 // cnts is all zero (the previous frame's epilogue cleared what it counted)
+        std::vector<LightRec> lightsOnDevice;   // what `lights` holds
+        const void *lightsDevPtr = nullptr;
+        hipStream_t stream = nullptr;           // the context's own stream (used when the caller passes none)
+        hipStream_t lastStream = nullptr;       // the stream the context's last frame ran on
+        void release() {
+            rays0.release(); rays1.release(); shadowRays.release(); hits.release(); hits1.release(); shadowHits.release();
+            path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); slot0.release(); slot1.release();
+            lvlA.release(); lvlB.release(); sampleColor.release(); sampleF32.release(); lights.release();
+            if (stream) (void)hipStreamDestroy(stream);
+            stream = nullptr;
+        }
+    };
     // cost feedback (kernels.hip long_ray): per path and generation, what the ray cost in the last frames
     DevBuf<unsigned> costMap;
     size_t costMapPaths = 0;
@@ -124,12 +149,13 @@ struct xrt_scene {
         bool collect = false;
         unsigned long long shaded = 0, closestDeep = 0, livePaths = 0, live0 = 0, validPixels = 0;
         unsigned long long hcnt[2 * C_COUNT] = {0};
+        WorkBufs w;
     } frames[2];
     std::vector<hipEvent_t> events;   // xrt_scene_intersect timing
-    bool cntsClean = false;           // cnts is all zero (the previous frame's epilogue cleared what it counted)
-    std::vector<LightRec> lightsOnDevice;   // what s->lights holds
-    const void *lightsDevPtr = nullptr;
     int firstBatch = 64;
+    long long maxChunkPaths = MAX_CHUNK_PATHS;   // XRT_CHUNK_PATHS=<n> (multiple of 8192) forces smaller chunks (tests of the multi-chunk path)
+    float lastFrameMs = 0.0f;    // GPU time of the last finished frame
+    float overlapMinMs = 0.5f;   // frames at least this long run on per-context streams
     int tune[4] = {24, 16, 48, 16};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
     std::atomic<bool> busy{false};
     std::atomic<float> progress{0.0f};
@@ -142,16 +168,15 @@ struct xrt_scene {
                 for (auto e : f.events) (void)hipEventDestroy(e);
                 if (f.done) (void)hipEventDestroy(f.done);
                 if (f.pinned) (void)hipHostFree(f.pinned);
+                f.w.release();
             }
             if (stream) (void)hipStreamDestroy(stream);
             blocks.release(); leafNB.release(); refN.release(); refG.release(); snodes.release(); shade.release();
             childDfs.release(); srefs.release(); objMesh.release(); meshes.release();
             objects.release(); materials.release(); texels.release();
-            rays0.release(); rays1.release(); shadowRays.release(); apiRays.release(); hits.release();
-            shadowHits.release(); apiHits.release(); path0.release(); path1.release(); hits1.release(); slot0.release(); slot1.release(); index0.release(); heavyList.release();
+            apiRays.release(); apiHits.release();
             node0.release(); node1.release(); ref0.release(); ref1.release(); lvlAlpha.release();
-            cnts.release(); queues.release(); lvlA.release(); lvlB.release(); sampleColor.release();
-            outRGBA.release(); sampleF32.release(); outF32.release(); lights.release(); counters.release();
+            queues.release(); outRGBA.release(); outF32.release(); counters.release(); costMap.release(); waveTimes.release();
         }
     }
 };
@@ -296,6 +321,7 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats);
 int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts,
                 uint32_t *d_out, float *d_outF32, hipStream_t st) {
     const bool stats = true;   // the read-back is two small pinned copies; always taken
+    xrt_scene::WorkBufs &W = F.w;
     if (!cam || !opts || (!lights && nLights > 0) || nLights < 0) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
     if (opts->max_reflections < 0 || opts->max_reflections > 64) return fail(XRT_E_INVALID_ARG, "max_reflections out of range");
     if (opts->address_mode < XRT_ADDRESS_CLAMP || opts->address_mode > XRT_ADDRESS_MIRROR)
@@ -329,10 +355,11 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     if (adaptive && totalPixels * 4 > 0x7fffffffLL) return fail(XRT_E_UNSUPPORTED, "frame too large for adaptive supersampling");
     const long long firstPaths = totalPixels * g.samples;
     // Chunking.  Without refraction a path owns one ray per generation.  With Transparent materials it may own up to
-    // 2^k in generation k, but few paths do: chunks are sized optimistically (ray buffers of MAX_CHUNK_PATHS rays,
+    // 2^k in generation k, but few paths do: chunks are sized optimistically (ray buffers of HEAP_RAY_CAP rays,
     // level records bounded by 8 GB) and a chunk whose generation overflows is retried with a quarter of the paths.
     const size_t nodes = heap ? (((size_t)1 << (R + 1)) - 1) : (size_t)(R + 1);
-    long long maxPaths = MAX_CHUNK_PATHS;
+    long long maxPaths = s->maxChunkPaths;
+    if (nL > 1 && maxPaths > (1LL << 30) / nL) maxPaths = ((1LL << 30) / nL) & ~8191LL;   // shadow rays of a generation are counted in an int
     if (heap) {
         maxPaths = 262144;
         const long long byRecords = (long long)((8ull << 30) / (nodes * 36ull));
@@ -343,16 +370,16 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const long long chunkPaths = firstPaths < maxPaths ? firstPaths : maxPaths;
     const int P = (int)chunkPaths;
     size_t rayCap = (size_t)P;
-    if (heap) { rayCap = (R < 20 && ((size_t)P << R) < (size_t)MAX_CHUNK_PATHS) ? ((size_t)P << R) : (size_t)MAX_CHUNK_PATHS; if (rayCap < (size_t)P) rayCap = (size_t)P; }
+    if (heap) { rayCap = (R < 20 && ((size_t)P << R) < (size_t)HEAP_RAY_CAP) ? ((size_t)P << R) : (size_t)HEAP_RAY_CAP; if (rayCap < (size_t)P) rayCap = (size_t)P; }
     const size_t shadowCap = rayCap;   // hits of one generation (each emits nL shadow rays)
     const bool wantF32 = d_outF32 != nullptr && !adaptive && g.samples == 1;
     const bool fuseResolve = !adaptive && !heap && g.samples == 1;   // k_compose writes the framebuffer itself
     // buffers
-    if ((rc = s->rays0.ensure(rayCap)) || (rc = s->rays1.ensure(rayCap)) || (rc = s->hits.ensure(rayCap)) || (rc = s->path0.ensure(rayCap)) ||
-        (rc = s->path1.ensure(rayCap)) || (rc = s->hits1.ensure(rayCap)) || (rc = s->slot0.ensure(rayCap)) ||
-        (rc = s->slot1.ensure(rayCap)) || (rc = s->index0.ensure(P)) || (rc = s->heavyList.ensure(rayCap)) || (rc = s->shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
-        (rc = s->shadowHits.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = s->lvlA.ensure((size_t)P * nodes)) ||
-        (rc = s->lvlB.ensure((size_t)P * nodes)) || (rc = s->sampleColor.ensure(P)) || (rc = s->lights.ensure(nL > 0 ? nL : 1)) ||
+    if ((rc = W.rays0.ensure(rayCap)) || (rc = W.rays1.ensure(rayCap)) || (rc = W.hits.ensure(rayCap)) || (rc = W.path0.ensure(rayCap)) ||
+        (rc = W.path1.ensure(rayCap)) || (rc = W.hits1.ensure(rayCap)) || (rc = W.slot0.ensure(rayCap)) ||
+        (rc = W.slot1.ensure(rayCap)) || (rc = W.index0.ensure(P)) || (rc = W.heavyList.ensure(rayCap)) || (rc = W.shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
+        (rc = W.shadowHits.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = W.lvlA.ensure((size_t)P * nodes)) ||
+        (rc = W.lvlB.ensure((size_t)P * nodes)) || (rc = W.sampleColor.ensure(P)) || (rc = W.lights.ensure(nL > 0 ? nL : 1)) ||
         (rc = s->counters.ensure(2 * C_COUNT + 8)))
         return rc;
     if (!s->waveTimesPath.empty() && !s->waveTimes.p) {
@@ -362,13 +389,31 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     if (heap && ((rc = s->node0.ensure(rayCap)) || (rc = s->node1.ensure(rayCap)) || (rc = s->ref0.ensure(rayCap)) || (rc = s->ref1.ensure(rayCap)) ||
                  (rc = s->lvlAlpha.ensure((size_t)P * nodes))))
         return rc;
-    if (wantF32 && (rc = s->sampleF32.ensure((size_t)P * 3))) return rc;
+    if (wantF32 && (rc = W.sampleF32.ensure((size_t)P * 3))) return rc;
     const int cntStride = 3 * (R + 2);          // per chunk: cnt[R+2], scnt[R+2], then the long-ray list lengths [R+2]
     const int qStride = 2 * (R + 1);
     // The common frame (one chunk, no supersampling levels, no ray tree, no counting pass) puts nothing but its kernels
     // on the stream: counters come back through k_compose's epilogue and the frame's events ride on raygen / compose.
     const bool fast = !adaptive && !heap && firstPaths <= chunkPaths && !opts->collect_stats;
     F.fast = fast;
+    if (!st) {
+        // No stream given.  Single-chunk frames that keep the GPU busy for a while get a stream per context, so that two
+        // frames in flight overlap on the GPU; everything else stays on the scene's one stream (measured on MI355X /
+        // ROCm 7.2: enqueueing on a stream that has gone idle costs ~15 us a launch, on one that still has work ~4 us --
+        // alternating two streams with 60-200 us frames makes the host the bottleneck).
+        if (fast && s->lastFrameMs >= s->overlapMinMs && !getenv("XRT_ONE_STREAM")) {
+            if (!W.stream) HIPCHECK(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+            st = W.stream;
+        } else st = s->stream;
+    }
+    {   // The other context's frame may still be running on another stream.  Two single-chunk frames share nothing they
+        // write except scheduling hints; anything else (counting pass, supersampling levels, ray tree, a cost map
+        // about to be reallocated) runs alone.
+        xrt_scene::FrameCtx &O = s->frames[&F == &s->frames[0] ? 1 : 0];
+        const bool remap = fast && s->deepMeshes && (s->costMapPaths != (size_t)P || s->costMap.cap < (size_t)(R + 1) * (size_t)P);
+        if (O.pending && O.w.lastStream != st && (!fast || !O.fast || remap)) HIPCHECK(hipEventSynchronize(O.fast ? O.events[1] : O.done));
+        W.lastStream = st;
+    }
     if (fast && s->deepMeshes && !getenv("XRT_NO_FEEDBACK")) {
         const size_t need = (size_t)(R + 1) * (size_t)P;
         if (s->costMapPaths != (size_t)P || s->costMap.cap < need) {   // new frame geometry: forget
@@ -381,7 +426,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         s->costMap.release(); s->costMapPaths = 0;
     }
     if (!fast) {
-        s->cntsClean = false;
+        W.cntsClean = false;
         HIPCHECK(hipMemsetAsync(s->counters.p, 0, (2 * C_COUNT + 8) * sizeof(unsigned long long), st));
     }
     std::vector<LightRec> &hl = F.hostLights;   // must outlive the asynchronous upload
@@ -390,19 +435,19 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         if (lights[i].kind != XRT_LIGHT_SPOT && lights[i].kind != XRT_LIGHT_DIRECTIONAL) return fail(XRT_E_INVALID_ARG, "unknown light kind");
         hl[i] = make_light(lights[i]);
     }
-    const bool sameLights = s->lightsOnDevice.size() == (size_t)nL && s->lightsDevPtr == s->lights.p &&
-                            (nL == 0 || std::memcmp(s->lightsOnDevice.data(), hl.data(), nL * sizeof(LightRec)) == 0);
+    const bool sameLights = W.lightsOnDevice.size() == (size_t)nL && W.lightsDevPtr == W.lights.p &&
+                            (nL == 0 || std::memcmp(W.lightsOnDevice.data(), hl.data(), nL * sizeof(LightRec)) == 0);
     if (nL > 0 && !sameLights) {
-        HIPCHECK(hipMemcpyAsync(s->lights.p, hl.data(), nL * sizeof(LightRec), hipMemcpyHostToDevice, st));
-        s->lightsOnDevice.assign(hl.begin(), hl.begin() + nL);
-        s->lightsDevPtr = s->lights.p;
+        HIPCHECK(hipMemcpyAsync(W.lights.p, hl.data(), nL * sizeof(LightRec), hipMemcpyHostToDevice, st));
+        W.lightsOnDevice.assign(hl.begin(), hl.begin() + nL);
+        W.lightsDevPtr = W.lights.p;
     }
     ShadeView V;
     V.shade = s->shade.p; V.materials = s->materials.p; V.texels = s->texels.p; V.meshes = s->meshes.p;
-    V.lights = s->lights.p; V.nLights = nL; V.addressMode = opts->address_mode; V.filtering = opts->filtering;
+    V.lights = W.lights.p; V.nLights = nL; V.addressMode = opts->address_mode; V.filtering = opts->filtering;
     const SceneView &S = s->view;
-    xrt_ray *rays[2] = {s->rays0.p, s->rays1.p};
-    int *paths[2] = {s->path0.p, s->path1.p};
+    xrt_ray *rays[2] = {W.rays0.p, W.rays1.p};
+    int *paths[2] = {W.path0.p, W.path1.p};
     int *nodesOf[2] = {s->node0.p, s->node1.p};
     float *refOf[2] = {s->ref0.p, s->ref1.p};
     size_t &ev = F.ev;
@@ -435,25 +480,25 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         auto heavy_for = [&](int k) {
             HeavyArgs H;
             if (listLong && (k == 0 || !heap)) {
-                H.list = s->heavyList.p; H.count = hcnt + k; H.path = s->heavyPath;
+                H.list = W.heavyList.p; H.count = hcnt + k; H.path = s->heavyPath;
                 if (feedback) { H.costMap = s->costMap.p + (size_t)k * P; H.epoch = s->epoch & 0xffffu; H.costThreshold = s->costT[k]; }
             }
             return H;
         };
         // cnt[0] counts the primary rays that reach the scene's root box; index0 lists them
-        launch_raygen(gp, S, rays[0], s->lvlB.p, s->index0.p, cnt, Pc, pathBase, heavy_for(0), st, fast ? e0 : nullptr);
-        xrt_hit *hitsOf[2] = {s->hits.p, s->hits1.p};
-        SlotRec *slotOf[2] = {s->slot0.p, s->slot1.p};
+        launch_raygen(gp, S, rays[0], W.lvlB.p, W.index0.p, cnt, Pc, pathBase, heavy_for(0), st, fast ? e0 : nullptr);
+        xrt_hit *hitsOf[2] = {W.hits.p, W.hits1.p};
+        SlotRec *slotOf[2] = {W.slot0.p, W.slot1.p};
         for (int k = 0; k <= R + 1; k++) {
             const int cur = k & 1, prv = cur ^ 1;
             const bool hasClosest = k <= R, hasShadow = k >= 1 && nL > 0;
             // a reflection chain keeps the ray of generation k at its parent's slot: their number is scnt[k-1]
             const int *nClosest = (k == 0 || heap) ? cnt + k : scnt + (k - 1);
             IntersectArgs C, B;   // closest-hit segment, shadow segment
-            C.rays = rays[cur]; C.hits = hitsOf[cur]; C.index = k == 0 ? s->index0.p : nullptr; C.nDev = nClosest; C.nMul = 1; C.n = Pc;
+            C.rays = rays[cur]; C.hits = hitsOf[cur]; C.index = k == 0 ? W.index0.p : nullptr; C.nDev = nClosest; C.nMul = 1; C.n = Pc;
             C.nCap = (int)rayCap;
             { const HeavyArgs H = heavy_for(k); C.heavyIdx = H.list; C.nHeavy = H.count; }
-            B.rays = s->shadowRays.p; B.hits = s->shadowHits.p; B.index = nullptr; B.nDev = hasShadow ? scnt + (k - 1) : nullptr; B.nMul = nL; B.n = 0;
+            B.rays = W.shadowRays.p; B.hits = W.shadowHits.p; B.index = nullptr; B.nDev = hasShadow ? scnt + (k - 1) : nullptr; B.nMul = nL; B.n = 0;
             B.nCap = (int)shadowCap * nL;
             for (IntersectArgs *a : {&C, &B}) {
                 a->queue = q + k; a->mode = s->sceneMode; a->meshId = 0;
@@ -477,23 +522,23 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             X.level = k; X.doA = hasClosest ? 1 : 0; X.doB = k >= 1 ? 1 : 0;
             X.maxReflections = R; X.P = P; X.heap = heap ? 1 : 0; X.overflow = overflowFlag;
             X.rays = rays[cur]; X.hits = hitsOf[cur]; X.nDev = nClosest; X.nHost = Pc; X.cap = (int)rayCap;
-            X.index = k == 0 ? s->index0.p : nullptr; X.rayPath = k == 0 ? nullptr : paths[cur];
+            X.index = k == 0 ? W.index0.p : nullptr; X.rayPath = k == 0 ? nullptr : paths[cur];
             X.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; X.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
-            X.slotOut = slotOf[cur]; X.scnt = scnt + k; X.shadowCap = (int)shadowCap; X.shadowRays = s->shadowRays.p;
+            X.slotOut = slotOf[cur]; X.scnt = scnt + k; X.shadowCap = (int)shadowCap; X.shadowRays = W.shadowRays.p;
             X.nextRays = rays[prv]; X.nextPath = paths[prv]; X.nextNode = heap ? nodesOf[prv] : nullptr; X.nextRef = heap ? refOf[prv] : nullptr;
             X.nextCnt = cnt + k + 1; X.nextCap = (int)rayCap;
-            X.hitsPrev = hitsOf[prv]; X.slotPrev = slotOf[prv]; X.scntPrev = k >= 1 ? scnt + (k - 1) : nullptr; X.shadowHits = s->shadowHits.p;
-            X.lvlA = s->lvlA.p; X.lvlB = s->lvlB.p; X.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
+            X.hitsPrev = hitsOf[prv]; X.slotPrev = slotOf[prv]; X.scntPrev = k >= 1 ? scnt + (k - 1) : nullptr; X.shadowHits = W.shadowHits.p;
+            X.lvlA = W.lvlA.p; X.lvlB = W.lvlB.p; X.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
             if (k < R) X.heavy = heavy_for(k + 1);
             if (feedback && hasClosest) { X.costOut = s->costMap.p + (size_t)k * P; X.epoch = s->epoch & 0xffffu; }
             launch_shade(S, V, X, st);
         }
-        if (heap) launch_compose_tree(s->lvlA.p, s->lvlB.p, s->lvlAlpha.p, Pc, P, R, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, st);
+        if (heap) launch_compose_tree(W.lvlA.p, W.lvlB.p, s->lvlAlpha.p, Pc, P, R, W.sampleColor.p, wantF32 ? W.sampleF32.p : nullptr, st);
         else {
             ResolveArgs RA;
             RA.fused = fuseResolve ? 1 : 0; RA.g = gp; RA.pixelBase = pathBase; RA.out = d_out; RA.outF32 = d_outF32;
             if (fast) { RA.cntSrc = cnt; RA.hostCnt = F.pinnedDev; RA.cntWords = cntStride; RA.zeroWords = cntStride + qStride; }
-            launch_compose(s->lvlA.p, s->lvlB.p, Pc, P, R, s->sampleColor.p, (wantF32 && !fuseResolve) ? s->sampleF32.p : nullptr, RA, st,
+            launch_compose(W.lvlA.p, W.lvlB.p, Pc, P, R, W.sampleColor.p, (wantF32 && !fuseResolve) ? W.sampleF32.p : nullptr, RA, st,
                            (fast && fuseResolve) ? e1 : nullptr);
         }
         return XRT_OK;
@@ -525,16 +570,16 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         if (heap) {
             // ray-tree mode: one chunk at a time, checked for overflow, retried with fewer paths when a generation did not fit
             const size_t words = (size_t)cntStride + (size_t)qStride;
-            if ((rc2 = s->cnts.ensure(words)) || (rc2 = ensure_pinned(words * sizeof(int) + nb2 + 64))) return rc2;
-            unsigned *q = reinterpret_cast<unsigned *>(s->cnts.p + cntStride);
+            if ((rc2 = W.cnts.ensure(words)) || (rc2 = ensure_pinned(words * sizeof(int) + nb2 + 64))) return rc2;
+            unsigned *q = reinterpret_cast<unsigned *>(W.cnts.p + cntStride);
             long long pathBase = 0, curChunk = chunkPaths;
             while (pathBase < total) {
                 const int Pc = (int)((total - pathBase) < curChunk ? (total - pathBase) : curChunk);
-                HIPCHECK(hipMemsetAsync(s->cnts.p, 0, words * sizeof(int), st));
+                HIPCHECK(hipMemsetAsync(W.cnts.p, 0, words * sizeof(int), st));
                 const size_t pairsMark = pairs.size(), evMark = ev;
-                if ((rc2 = enqueue_chunk(gp, s->cnts.p, q, Pc, pathBase))) return rc2;
+                if ((rc2 = enqueue_chunk(gp, W.cnts.p, q, Pc, pathBase))) return rc2;
                 char *pin = (char *)F.pinned;
-                HIPCHECK(hipMemcpyAsync(pin, s->cnts.p, (size_t)cntStride * sizeof(int), hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipMemcpyAsync(pin, W.cnts.p, (size_t)cntStride * sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipMemcpyAsync(pin + (size_t)cntStride * sizeof(int), overflowFlag, sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipMemcpyAsync(pin + (size_t)cntStride * sizeof(int) + 64, s->counters.p, nb2, hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipStreamSynchronize(st));
@@ -561,16 +606,16 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         const int nChunks = (int)((total + chunkPaths - 1) / chunkPaths);
         // ray counts and queue heads of all chunks live in one allocation: one memset per pass
         const size_t cntWords = (size_t)nChunks * cntStride, qWords = (size_t)nChunks * qStride;
-        const int *cntsBefore = s->cnts.p;
-        if ((rc2 = s->cnts.ensure(cntWords + qWords))) return rc2;
-        unsigned *queuesBase = reinterpret_cast<unsigned *>(s->cnts.p + cntWords);
+        const int *cntsBefore = W.cnts.p;
+        if ((rc2 = W.cnts.ensure(cntWords + qWords))) return rc2;
+        unsigned *queuesBase = reinterpret_cast<unsigned *>(W.cnts.p + cntWords);
         if (fast && (rc2 = ensure_pinned(cntWords * sizeof(int)))) return rc2;
-        if (!fast || !s->cntsClean || s->cnts.p != cntsBefore) HIPCHECK(hipMemsetAsync(s->cnts.p, 0, s->cnts.cap * sizeof(int), st));
-        s->cntsClean = false;
+        if (!fast || !W.cntsClean || W.cnts.p != cntsBefore) HIPCHECK(hipMemsetAsync(W.cnts.p, 0, W.cnts.cap * sizeof(int), st));
+        W.cntsClean = false;
         for (int c = 0; c < nChunks; c++) {
             const long long pathBase = (long long)c * chunkPaths;
             const int Pc = (int)((total - pathBase) < chunkPaths ? (total - pathBase) : chunkPaths);
-            if ((rc2 = enqueue_chunk(gp, s->cnts.p + (size_t)c * cntStride, queuesBase + (size_t)c * qStride, Pc, pathBase))) return rc2;
+            if ((rc2 = enqueue_chunk(gp, W.cnts.p + (size_t)c * cntStride, queuesBase + (size_t)c * qStride, Pc, pathBase))) return rc2;
             if (!fuseResolve && (rc2 = post(Pc, pathBase))) return rc2;
             if (nChunks > 1) {   // frames of more than MAX_CHUNK_PATHS rays: xrt_progress follows the chunks
                 HIPCHECK(hipStreamSynchronize(st));
@@ -579,7 +624,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         }
         if (fast) {   // counters arrive with k_compose; frame_finish tallies them
             if (!fuseResolve) HIPCHECK(hipEventRecord(e1, st));   // fixed 16 sub-rays: k_resolve is the last kernel
-            s->cntsClean = true;
+            W.cntsClean = true;
             F.tallyChunks = 1;
             return XRT_OK;
         }
@@ -587,7 +632,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         if (stats) {   // per-pass ray accounting (the counter block is reused by the next pass): one pinned read-back
             const size_t nb = (size_t)nChunks * cntStride * sizeof(int);
             if ((rc2 = ensure_pinned(nb + nb2))) return rc2;
-            HIPCHECK(hipMemcpyAsync(F.pinned, s->cnts.p, nb, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipMemcpyAsync(F.pinned, W.cnts.p, nb, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipMemcpyAsync((char *)F.pinned + nb, s->counters.p, nb2, hipMemcpyDeviceToHost, st));
             if (finalPass) { F.tallyChunks = nChunks; return XRT_OK; }   // frame_finish tallies after the frame's done event
             HIPCHECK(hipStreamSynchronize(st));
@@ -610,7 +655,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     if (!adaptive) {
         livePaths = validPixels * (unsigned long long)g.samples;
         rc = run_pass(g, firstPaths, [&](int Pc, long long pathBase) -> int {
-            launch_resolve(g, s->sampleColor.p, wantF32 ? s->sampleF32.p : nullptr, Pc / g.samples, pathBase / g.samples, d_out, d_outF32, st);
+            launch_resolve(g, W.sampleColor.p, wantF32 ? W.sampleF32.p : nullptr, Pc / g.samples, pathBase / g.samples, d_out, d_outF32, st);
             return XRT_OK;
         }, 0.0f, 1.0f, true);
         if (rc != XRT_OK) return rc;
@@ -632,7 +677,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             gl.quadLevel = l; gl.quadSize = size; gl.quadCx = L.cx.p; gl.quadCy = L.cy.p;
             livePaths += (l == 0 ? validPixels : (unsigned long long)L.n) * 4ull;
             rc = run_pass(gl, L.n * 4, [&](int Pc, long long pathBase) -> int {
-                HIPCHECK(hipMemcpyAsync(L.color.p + pathBase, s->sampleColor.p, (size_t)Pc * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+                HIPCHECK(hipMemcpyAsync(L.color.p + pathBase, W.sampleColor.p, (size_t)Pc * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
                 return XRT_OK;
             }, (float)l / (float)(quality + 1), (float)(l + 1) / (float)(quality + 1), false);
             if (rc != XRT_OK) break;
@@ -705,6 +750,11 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
             }
         }
         F.tallyChunks = 0;
+    }
+    {
+        float frameMs = 0;
+        if (hipEventElapsedTime(&frameMs, F.events[0], F.events[1]) == hipSuccess) s->lastFrameMs = frameMs;
+        else (void)hipGetLastError();
     }
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
@@ -807,6 +857,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     xrt_scene *s = new xrt_scene();
     s->device = device;
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
+    if (const char *e = getenv("XRT_CHUNK_PATHS")) { long long v = atoll(e); if (v >= 8192 && v <= MAX_CHUNK_PATHS && v % 8192 == 0) s->maxChunkPaths = v; }
     if (const char *t = getenv("XRT_TUNE")) {   // "refill,nodeBurst,leafBurst[,coopMax]" — scheduling only, never results
         int v[4] = {0, 0, 0, s->tune[3]};
         if (sscanf(t, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) >= 3 && v[0] >= 1 && v[0] <= 64 && v[1] >= 1 && v[2] >= 1 && v[3] >= 0 && v[3] <= 64) {
@@ -1001,7 +1052,7 @@ int xrt_render_device_begin(xrt_scene *scene, const xrt_camera *camera, const xr
     if (!guard.owned) return fail(XRT_E_BUSY, "Current render operation not finished.");
     const int slot = !scene->frames[0].pending ? 0 : (!scene->frames[1].pending ? 1 : -1);
     if (slot < 0) return fail(XRT_E_BUSY, "two frames are already in flight; call xrt_render_device_end first");
-    hipStream_t st = stream ? (hipStream_t)stream : scene->stream;
+    hipStream_t st = (hipStream_t)stream;
     if ((rc = frame_begin(scene, scene->frames[slot], camera, lights, n_lights, opts, (uint32_t *)d_rgba_out, nullptr, st))) return rc;
     *ticket_out = slot;
     return XRT_OK;
@@ -1047,7 +1098,7 @@ int xrt_generate_primary_rays(xrt_scene *scene, const xrt_camera *camera, xrt_ra
     RayGenParams g;
     if ((rc = make_raygen(camera, &o, g))) return rc;
     const long long slots = (long long)g.tilesX * g.tilesY * 512;
-    if (slots > MAX_CHUNK_PATHS * 8LL) return fail(XRT_E_INVALID_ARG, "frame too large");
+    if (slots > (1LL << 25)) return fail(XRT_E_INVALID_ARG, "frame too large");
     if ((rc = scene->apiRays.ensure((size_t)slots))) return rc;
     hipStream_t st = scene->stream;
     launch_raygen(g, scene->view, scene->apiRays.p, nullptr, nullptr, nullptr, (int)slots, 0, HeavyArgs(), st);
