@@ -60,5 +60,5 @@ def test_hot_kernel_resources(isa):
     for name, cap, mode, vgprs, scratch, occ in blocks:
         want = 4
         if int(mode) == 0 and int(cap) > 12:
-            want = 160 * 1024 // ((int(cap) + 27) * 1024 + (256 if int(cap) < 40 else 0))
+            want = 160 * 1024 // ((int(cap) + 27) * 1024 + (512 if int(cap) < 40 else 0))
         assert int(vgprs) <= 128 and int(scratch) == 0 and int(occ) >= want, (name, vgprs, scratch, occ)

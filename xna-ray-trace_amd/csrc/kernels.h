@@ -43,7 +43,7 @@ struct IntersectArgs {
     int refillMin, nodeBurst, leafBurst;   // scheduling knobs of the persistent loop (defaults in xrt_api.cpp; XRT_TUNE overrides)
     const int *heavyIdx = nullptr, *nHeavy = nullptr;   // rays of segment 1 to take first (marked in their records)
     unsigned long long *debugTimes = nullptr;   // [3 * waves]: start / out-of-rays / exit clocks (100 MHz) per wave, development aid
-    int coopMax = 16;   // at most this many lanes in a leaf: their triangle lists are dealt to the whole wave
+    int coopMax = 32;   // at most this many lanes in a leaf: their triangle lists are dealt to the whole wave
     // optional second segment traced by the same launch: rays2[0 .. (*nDev2) * nMul2) -> hits2 (no index list)
     const xrt_ray *rays2 = nullptr;
     xrt_hit *hits2 = nullptr;

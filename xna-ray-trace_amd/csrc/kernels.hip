@@ -185,7 +185,9 @@ __device__ __forceinline__ int wave_scan_max(int v) {   // values >= 0
     return v;
 }
 
-__device__ __forceinline__ void coop_leaf_step(Lane &L, const SceneView &S, unsigned char *own /* [64] of this wave */) {
+constexpr int COOP_ROUNDS = 2;   // references per lane and cooperative step
+__device__ __forceinline__ void coop_leaf_step(Lane &L, const SceneView &S, unsigned char *own /* [64 * COOP_ROUNDS] of this wave */) {
+    constexpr int CAP = 64 * COOP_ROUNDS;
     const int lane = lane_id();
     const bool inLeaf = L.state == ST_LEAF;
     const int cnt = inLeaf ? L.refEnd - L.ref : 0;
@@ -195,42 +197,57 @@ __device__ __forceinline__ void coop_leaf_step(Lane &L, const SceneView &S, unsi
     // owner of slot s: the last lane whose list starts at or before s -- every owner drops its lane number at its
     // first slot, a running maximum spreads it over the slots that follow
     // (lanes talk to each other through `own`: wave-level fences, or the compiler forwards a lane's own zero to its read)
-    own[lane] = 0;
+#pragma unroll
+    for (int r = 0; r < COOP_ROUNDS; r++) own[lane + 64 * r] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (cnt > 0 && excl < 64) own[excl] = (unsigned char)lane;
+    if (cnt > 0 && excl < CAP) own[excl] = (unsigned char)lane;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int owner = wave_scan_max((int)own[lane]);
-    const bool valid = lane < total;
-    const int ref = __shfl(L.ref, owner) + (lane - __shfl(excl, owner));
-    const v3 o = mk(__shfl(L.r.o.x, owner), __shfl(L.r.o.y, owner), __shfl(L.r.o.z, owner));
-    const v3 d = mk(__shfl(L.r.d.x, owner), __shfl(L.r.d.y, owner), __shfl(L.r.d.z, owner));
-    const int ignoreId = __shfl(L.ignoreId, owner);
-    bool f = false, pass = false;
-    float u = 0, v = 0, t = 0;
-    if (valid) {
-        const f4 n = S.refN[ref];
-        const g3 ga = S.refG[3 * (size_t)ref], gb = S.refG[3 * (size_t)ref + 1], gc = S.refG[3 * (size_t)ref + 2];
-        f = !(facing(mk(n.x, n.y, n.z), d) > 0.0f) && f2i(n.w) != ignoreId;   // RE:48-51, MO:290
-        if (f) pass = tri_test_front(o, d, mk(ga.x, ga.y, ga.z), mk(gb.x, gb.y, gb.z), mk(gc.x, gc.y, gc.z), u, v, t) && t < FLT_MAX;   // MO:293
-    }
-    unsigned long long pm = __ballot(pass);
-    while (pm) {   // rare: hand each passing candidate to its owner, in list order
-        const int s = __builtin_ctzll(pm);
-        pm &= pm - 1;
-        const int so = __builtin_amdgcn_readlane(owner, s);
-        const int sr = __builtin_amdgcn_readlane(ref, s);
-        const float su = i2f(__builtin_amdgcn_readlane(f2i(u), s)), sv = i2f(__builtin_amdgcn_readlane(f2i(v), s)),
-                    sd = i2f(__builtin_amdgcn_readlane(f2i(t), s));
-        if (lane == so) leaf_candidate(L, S, sr, -2, true, su, sv, sd);   // (the ignored triangle was filtered above: -2 matches no id)
-    }
-    if (inLeaf) {
-        const int room = 64 - excl;
-        const int used = room <= 0 ? 0 : (cnt < room ? cnt : room);
+    const int used = inLeaf ? ((CAP - excl) <= 0 ? 0 : (cnt < CAP - excl ? cnt : CAP - excl)) : 0;
+    int carry = 0, spec = 0;
+#pragma unroll
+    for (int r = 0; r < COOP_ROUNDS; r++) {
+        if (r > 0 && total <= 64 * r) break;   // wave-uniform
+        const int s = lane + 64 * r;
+        int owner = wave_scan_max((int)own[s]);
+        owner = owner > carry ? owner : carry;
+        carry = __builtin_amdgcn_readlane(owner, 63);
+        const bool valid = s < total;
+        const int ref = __shfl(L.ref, owner) + (s - __shfl(excl, owner));
+        const v3 o = mk(__shfl(L.r.o.x, owner), __shfl(L.r.o.y, owner), __shfl(L.r.o.z, owner));
+        const v3 d = mk(__shfl(L.r.d.x, owner), __shfl(L.r.d.y, owner), __shfl(L.r.d.z, owner));
+        const int ignoreId = __shfl(L.ignoreId, owner);
+        bool f = false, pass = false;
+        float u = 0, v = 0, t = 0;
+        if (valid) {
+            const f4 n = S.refN[ref];
+            const g3 ga = S.refG[3 * (size_t)ref], gb = S.refG[3 * (size_t)ref + 1], gc = S.refG[3 * (size_t)ref + 2];
+            f = !(facing(mk(n.x, n.y, n.z), d) > 0.0f) && f2i(n.w) != ignoreId;   // RE:48-51, MO:290
+            if (f) pass = tri_test_front(o, d, mk(ga.x, ga.y, ga.z), mk(gb.x, gb.y, gb.z), mk(gc.x, gc.y, gc.z), u, v, t) && t < FLT_MAX;   // MO:293
+        }
+        unsigned long long pm = __ballot(pass);
+        while (pm) {   // rare: hand each passing candidate to its owner, in list order
+            const int ps = __builtin_ctzll(pm);
+            pm &= pm - 1;
+            const int so = __builtin_amdgcn_readlane(owner, ps);
+            const int sr = __builtin_amdgcn_readlane(ref, ps);
+            const float su = i2f(__builtin_amdgcn_readlane(f2i(u), ps)), sv = i2f(__builtin_amdgcn_readlane(f2i(v), ps)),
+                        sd = i2f(__builtin_amdgcn_readlane(f2i(t), ps));
+            if (lane == so) leaf_candidate(L, S, sr, -2, true, su, sv, sd);   // (the ignored triangle was filtered above: -2 matches no id)
+        }
+        // did one of this lane's own references face its ray?  (hint for the whole-leaf back-face skip)
         const unsigned long long fm = __ballot(f);
-        if (used > 0) L.spec = ((fm >> excl) & ((used >= 64) ? ~0ull : ((1ull << used) - 1ull))) != 0ull ? 1 : 0;
+        const int a0 = excl - 64 * r, b0 = excl + used - 64 * r;
+        const int sa = a0 < 0 ? 0 : a0, sb = b0 > 64 ? 64 : b0;
+        if (sa < sb) {
+            const unsigned long long hi = sb >= 64 ? ~0ull : ((1ull << sb) - 1ull), lo = (1ull << sa) - 1ull;
+            if (fm & hi & ~lo) spec = 1;
+        }
+    }
+    if (used > 0) {
+        L.spec = spec;
         L.ref += used;
         if (L.ref >= L.refEnd) L.state = ST_NODE;
     }
@@ -243,7 +260,7 @@ template <int M> __device__ __forceinline__ unsigned *park_memory() {
     else return nullptr;
 }
 template <int T> __device__ __forceinline__ unsigned char *coop_memory() {
-    if constexpr (T < 40) { __shared__ unsigned char mem[4 * 64]; return mem; }
+    if constexpr (T < 40) { __shared__ unsigned char mem[4 * 64 * COOP_ROUNDS]; return mem; }
     else return nullptr;
 }
 
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs
             if (inLeaf == 0ull) break;
             // many lanes in a leaf: two references per lane and step; few: their lists are dealt to the whole wave
             if (T >= 40 || __popcll(inLeaf) > A.coopMax) { if (L.state == ST_LEAF) advance_leaf(L, S); }
-            else coop_leaf_step(L, S, &coopOwn[wave * 64]);
+            else coop_leaf_step(L, S, &coopOwn[wave * 64 * COOP_ROUNDS]);
         }
         if (L.state == ST_FINISH) {
             store_hit(L.rayIndex < 0 ? A.hits2 + ~L.rayIndex : A.hits + L.rayIndex, lane_result(L, C, S, M));

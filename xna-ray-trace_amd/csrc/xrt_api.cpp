@@ -156,7 +156,7 @@ struct xrt_scene {
     long long maxChunkPaths = MAX_CHUNK_PATHS;   // XRT_CHUNK_PATHS=<n> (multiple of 8192) forces smaller chunks (tests of the multi-chunk path)
     float lastFrameMs = 0.0f;    // GPU time of the last finished frame
     float overlapMinMs = 0.5f;   // frames at least this long run on per-context streams
-    int tune[4] = {24, 16, 48, 16};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
+    int tune[4] = {24, 16, 48, 32};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
     std::atomic<bool> busy{false};
     std::atomic<float> progress{0.0f};
 
