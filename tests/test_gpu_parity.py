@@ -448,3 +448,38 @@ def test_multi_chunk_frames(xrt, monkeypatch):
         for k in ("rays_closest", "rays_shadow", "shaded_hits", "pixels"):
             assert tracer2.last_stats[k] == st_want[k], (k, tracer2.last_stats[k], st_want[k])
         assert tracer2.last_stats["intersect_launches"] > st_want["intersect_launches"]
+
+
+def test_overlapping_frames_on_two_streams(xrt, monkeypatch):
+    """Frames that run long enough get one stream per frame context and overlap on the GPU (XRT_OVERLAP_MS=0 forces it
+    for a test-sized frame): two different cameras in flight at once give the frames of the blocking renders, over
+    many alternations, with the long-ray list and its cost feedback active (deep meshes)."""
+    import torch
+    monkeypatch.setenv("XRT_OVERLAP_MS", "0")
+    monkeypatch.setenv("XRT_HEAVY", "0.2")
+    spec = xrt.configs.config("C3", 0.25)
+    scene, tracer = xrt.configs.build_product(spec)
+    monkeypatch.delenv("XRT_OVERLAP_MS")
+    monkeypatch.delenv("XRT_HEAVY")
+    n = spec.width * spec.height
+    cams = [tracer.CurrentCamera, xrt.api.Camera((40, 60, 90), (0, 8, 0), (0.0, 1.0, 0.0), 0.7853981852531433,
+                                                 xrt.xna.aspect_ratio(spec.width, spec.height), 1.0, 1000.0)]
+    want, outs, frs = [], [], []
+    for c in cams:
+        tracer.CurrentCamera = c
+        want.append(tracer.Render().copy())
+        outs.append(torch.zeros(n, dtype=torch.int32, device="cuda"))
+        frs.append(tracer.PrepareDevice(outs[-1].data_ptr()))     # stream None: the library picks the context's stream
+    assert not np.array_equal(want[0], want[1])
+    open_t = None
+    for i in range(24):
+        t = frs[i % 2].begin()
+        if open_t is not None:
+            frs[(i - 1) % 2].end(open_t)
+            got = outs[(i - 1) % 2].cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, want[(i - 1) % 2]), i
+            outs[(i - 1) % 2].zero_()
+            torch.cuda.current_stream().synchronize()   # (only torch's stream: the other frame stays in flight)
+        open_t = t
+    frs[23 % 2].end(open_t)
+    assert np.array_equal(outs[23 % 2].cpu().numpy().view(np.uint32), want[23 % 2])

@@ -857,6 +857,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     xrt_scene *s = new xrt_scene();
     s->device = device;
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
+    if (const char *e = getenv("XRT_OVERLAP_MS")) s->overlapMinMs = (float)atof(e);   // 0: every single-chunk frame gets its context's stream
     if (const char *e = getenv("XRT_CHUNK_PATHS")) { long long v = atoll(e); if (v >= 8192 && v <= MAX_CHUNK_PATHS && v % 8192 == 0) s->maxChunkPaths = v; }
     if (const char *t = getenv("XRT_TUNE")) {   // "refill,nodeBurst,leafBurst[,coopMax]" — scheduling only, never results
         int v[4] = {0, 0, 0, s->tune[3]};
