@@ -67,6 +67,10 @@ namespace RayTraceProject.Native
                                                                      [Out] XrtHit[] hits, IntPtr stats);
         [DllImport(Lib)] public static extern unsafe int xrt_render(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,
                                                                    ref XrtRenderOpts opts, uint* rgbaOut, float* rgbF32Out, IntPtr stats);
+        // pipelined form (two frames in flight; device output): RenderAsync / RenderCompleted without a host round trip
+        [DllImport(Lib)] public static extern int xrt_render_device_begin(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,
+                                                                            ref XrtRenderOpts opts, IntPtr dRgbaOut, IntPtr stream, out int ticket);
+        [DllImport(Lib)] public static extern int xrt_render_device_end(IntPtr scene, int ticket, IntPtr statsOut);
         [DllImport(Lib)] public static extern float xrt_progress(IntPtr scene);
 
         // error convention of the reference: InvalidOperationException when busy (RayTracer.cs:26-27,62-63),

@@ -6,10 +6,11 @@
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/final
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py > $OUT/bench_under_rocprof.log 2>&1
-tail -1 $OUT/bench_under_rocprof.log > $OUT/bench_line_under_rocprof.json
+grep '^{"metric"' $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_line_under_rocprof.json
 for c in C2 C3 C5_1spp; do
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$c -- python3 $R/bench.py --config $c --no-extra --no-cpu --steps 10 --warmup 2 > $OUT/pmc_fetch_$c.log 2>&1
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$c -- python3 $R/bench.py --config $c --no-extra --no-cpu --steps 10 --warmup 2 > $OUT/pmc_write_$c.log 2>&1
