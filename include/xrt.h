@@ -84,7 +84,7 @@ typedef struct xrt_hit {
     int32_t leaf;
     float   u, v, d;
     float   wx, wy, wz;
-    int32_t reserved;
+    int32_t reserved;   /* not part of the answer: scheduling feedback (rounds of the traversal loop the ray was in flight) */
 } xrt_hit;
 
 /* Material (MAT:25-69, 234-268). tex_argb = the locked Format32bppArgb bitmap (MAT:65): row-major,

@@ -4,10 +4,14 @@
 //                 ISpatialManager.GetRayIntersection query (OSM:312 -> MO:259 -> RE:42); per-lane octree
 //                 stack in LDS ([level][lane], bank == lane, conflict free); lanes that finish are refilled
 //                 in groups chosen with __ballot so the wave stays populated (active-lane compaction).
-//                 Branchy scalar fp32 — no MFMA by design.
+//                 One launch traces two ray arrays (closest-hit rays of a generation + shadow rays of the
+//                 previous one) and takes the rays listed as long first; the scene-level half of a query
+//                 lives in LDS; children a ray misses are filtered eight at a time; with few lanes in a leaf
+//                 their triangle lists are dealt to the whole wave.  Branchy scalar fp32 — no MFMA by design.
 //   k_count       the REFERENCE algorithm's work counters, untimed.
 //   k_raygen      RayTracer.Render ray generation (RT:410-421) in 64x8 tile order.
-//   k_shade       CastRay shading (RT:516-584, 708-727), IsLightPathObstructed (RT:465-502), lights.
+//   k_shade       CastRay shading (RT:516-584, 708-727), IsLightPathObstructed (RT:465-502), lights: hits of
+//                 generation k -> shadow rays + rays of generation k+1, shadow answers of k-1 -> level records.
 //   k_compose     the recursion's return path: per-level RGBA8 quantisation (RT:584,705,726,732).
 //   k_resolve     supersample averaging (RT:309) and the framebuffer write (RT:425).
 //
