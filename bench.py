@@ -61,6 +61,10 @@ def time_frames(tracer, outs, steps, warmup, rank, world, width, height, gathere
     def finish():
         while pending:
             g = pending.pop(0)()
+            if nccl:
+                # work.wait() only makes torch's stream wait for the collective; the next frame is rendered on libxrt's
+                # own stream, so the host must know the tile buffer has been read before it is rendered into again
+                torch.cuda.current_stream().synchronize()
             if rank == 0:
                 xrt.dist.detile_device(g if nccl else g.cuda(), width, height, world, gathered_out)
 
