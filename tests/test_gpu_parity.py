@@ -483,3 +483,25 @@ def test_overlapping_frames_on_two_streams(xrt, monkeypatch):
         open_t = t
     frs[23 % 2].end(open_t)
     assert np.array_equal(outs[23 % 2].cpu().numpy().view(np.uint32), want[23 % 2])
+
+
+@pytest.mark.parametrize("env", [{"XRT_TUNE": "8,4,4,0"}, {"XRT_TUNE": "40,64,64,64"}, {"XRT_HEAVY": "0.02"}, {"XRT_HEAVY": "0.02", "XRT_NO_FEEDBACK": "1"},
+                                 {"XRT_NO_RECT_CULL": "1"}, {"XRT_NO_SINGLE": "1"}, {"XRT_LONG_FRAC": "40,60"}])
+def test_scheduling_switches_never_change_results(xrt, monkeypatch, env):
+    """Knobs of the persistent loop, the cooperative leaf step, the long-ray list (geometric estimate and cost
+    feedback), the screen-rectangle cull and the single-object mode are scheduling / work-avoidance only: hits of a
+    secondary-ray population and three consecutive frames (the feedback needs history) are those of the default build."""
+    spec = xrt.configs.heightfield_scene(320, 180, m=96)
+    scene, tracer = xrt.configs.build_product(spec)
+    rays = tracer.GeneratePrimaryRays()
+    hits = scene.IntersectBatch(rays)
+    sec = secondary_rays(xrt, hits, seed=3)
+    want_hits, want_sec = hits, scene.IntersectBatch(sec)
+    want = tracer.Render().copy()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    scene2, tracer2 = xrt.configs.build_product(spec)
+    assert hits_equal(want_hits, scene2.IntersectBatch(rays)) == {}
+    assert hits_equal(want_sec, scene2.IntersectBatch(sec)) == {}
+    for _ in range(3):
+        assert np.array_equal(tracer2.Render(), want)
