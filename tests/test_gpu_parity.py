@@ -505,3 +505,63 @@ def test_scheduling_switches_never_change_results(xrt, monkeypatch, env):
     assert hits_equal(want_sec, scene2.IntersectBatch(sec)) == {}
     for _ in range(3):
         assert np.array_equal(tracer2.Render(), want)
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606])
+def test_random_scenes_against_the_oracle(xrt, orc, seed):
+    """Fuzz: random bodies (1-7) of random triangle soups (one to three meshes each, 20-600 triangles, leaf thresholds
+    2-40) under random rotations, non-uniform scales and translations; rays from outside, from inside the boxes, exactly
+    axis-parallel, with zero and non-finite components, and the secondary rays of the hits.  Hit triangle, leaf, u/v/d
+    and world position bit for bit; one small frame with every shading term."""
+    rng = np.random.default_rng(seed)
+    s = xrt.configs.SceneSpec("fuzz%d" % seed)
+    n_mesh = int(rng.integers(1, 4))
+    for m in range(n_mesh):
+        soup = triangle_soup(int(rng.integers(20, 600)), seed + m, float(rng.uniform(0.1, 1.2)))
+        s.meshes.append((soup, xrt.configs.material(float(rng.uniform(0, 1)), interpolate_normals=bool(rng.integers(0, 2)))))
+    for b in range(int(rng.integers(1, 8))):
+        ids = sorted(set(int(i) for i in rng.integers(0, n_mesh, size=int(rng.integers(1, 4)))))
+        s.objects.append((ids, tuple(float(x) for x in rng.uniform(-4, 4, 3)), tuple(float(x) for x in rng.uniform(-3.2, 3.2, 3)),
+                          tuple(float(x) for x in rng.uniform(1.0, 4.0, 3))))
+    s.mesh_threshold = int(rng.integers(2, 41))
+    s.scene_threshold = int(rng.integers(1, 5))
+    s.camera = xrt.configs.camera((0, 9, 17), (0, 0, 0))
+    s.lights = [xrt.configs.spot((3, 20, 12)), xrt.configs.directional((0.2, 0.9, 0.3), (0.5, 0.5, 0.4), 0.6)]
+    s.max_reflections = 2
+    s = s.with_size(96, 54)
+    scene, tracer = xrt.configs.build_product(s)
+    o = orc.OracleScene(s)
+    # mesh ids are handles: the host mirror numbers meshes by first use in the bodies (OctreeSpatialManager.Build), the
+    # oracle wrapper by their position in the spec
+    first_use = []
+    for ids, _, _, _ in s.objects:
+        first_use += [i for i in ids if i not in first_use]
+    to_spec = np.array(first_use + [-1], dtype=np.int32)
+
+    def product_hits(r):
+        h = scene.IntersectBatch(r).copy()
+        h["mesh"] = np.where(h["hit"] != 0, to_spec[np.clip(h["mesh"], 0, len(first_use))], h["mesh"])
+        return h
+    n = 6000
+    O = rng.uniform(-9, 9, size=(n, 3)).astype(np.float32)
+    D = rng.normal(size=(n, 3)).astype(np.float32)
+    D /= np.linalg.norm(D, axis=1, keepdims=True).astype(np.float32)
+    O[: n // 3] *= 0.25                                     # origins inside the bodies' boxes
+    ax = rng.integers(0, 3, size=n // 6)
+    D[n // 3: n // 3 + n // 6] = 0.0                        # exactly axis-parallel
+    D[np.arange(n // 3, n // 3 + n // 6), ax] = rng.choice([-1.0, 1.0], size=n // 6)
+    D[-8:-6] = 0.0                                          # zero direction
+    D[-6, 0] = np.nan; D[-5, 1] = np.inf; O[-4, 2] = np.nan; O[-3, 0] = -np.inf; D[-2] = (1e-7, -1.0, 1e-7); O[-1] = (1e30, 0, 0)
+    rays = xrt.rays_array(O, D)
+    o_hits = o.intersect(rays)
+    assert hits_equal(o_hits, product_hits(rays)) == {}
+    inv = {v: k for k, v in enumerate(first_use)}
+    sec = secondary_rays(xrt, o_hits, seed)                 # ignore (mesh, tri) in the oracle's numbering
+    sec_p = sec.copy()
+    sec_p["ignore_mesh"] = np.array([inv.get(int(m), -1) for m in sec["ignore_mesh"]], dtype=np.int32)
+    assert hits_equal(o.intersect(sec), product_hits(sec_p)) == {}
+    prim = o.primary_rays()
+    assert hits_equal(o.intersect(prim), product_hits(prim)) == {}
+    rgba, rgbf = tracer.Render(want_float=True)
+    o_rgba, o_rgbf, _ = o.render(nthreads=8)
+    assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
