@@ -565,3 +565,25 @@ def test_random_scenes_against_the_oracle(xrt, orc, seed):
     rgba, rgbf = tracer.Render(want_float=True)
     o_rgba, o_rgbf, _ = o.render(nthreads=8)
     assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+    # the same bodies in the other frame modes: fixed 16 sub-rays, adaptive quadrants, a ray tree through glass
+    for mode in ("ms16", "adaptive", "glass"):
+        s2 = xrt.configs.SceneSpec("fuzz%d_%s" % (seed, mode))
+        s2.meshes = [(d, dict(m)) for d, m in s.meshes]
+        s2.objects, s2.camera, s2.lights = s.objects, s.camera, s.lights
+        s2.mesh_threshold, s2.scene_threshold = s.mesh_threshold, s.scene_threshold
+        s2.max_reflections = int(rng.integers(1, 4))
+        if mode == "ms16":
+            s2.multisampling = xrt.abi.MS_FIXED16
+        elif mode == "adaptive":
+            s2.multisampling, s2.multisample_quality = xrt.abi.MS_ADAPTIVE, int(rng.integers(0, 3))
+        else:
+            for _, m in s2.meshes[::2]:
+                m["transparent"], m["refraction_index"] = True, float(rng.uniform(1.1, 1.8))
+        s2 = s2.with_size(64, 36)
+        _, tracer2 = xrt.configs.build_product(s2)
+        rgba, rgbf = tracer2.Render(want_float=True)
+        o_rgba, o_rgbf, _ = orc.OracleScene(s2).render(nthreads=8)
+        if mode == "glass":
+            assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+        else:
+            assert np.array_equal(rgba, o_rgba), (seed, mode)   # (no fp32 colour vector in the supersampled modes)
