@@ -47,68 +47,120 @@ def intersect_bytes(st):
     return st["algorithmic_bytes"] - 80 * st["shaded_hits"] - 4 * st["pixels"]
 
 
-def time_frames(tracer, outs, steps, warmup, rank, world, width, height, gathered_out, stream=None):
-    """W warm-up frames, then K timed frames bracketed by barrier + synchronize on both sides.
-    N > 1: the gather of frame i (RCCL, its own stream) overlaps the rendering of frame i+1 (double-buffered tile
-    buffers); every frame is gathered and de-tiled before the closing barrier."""
-    # stream None: libxrt decides (frames of >= 0.5 ms of GPU time run on one stream per frame context and overlap on the
-    # GPU; shorter ones share one stream).  A given stream serialises the frames: used for per-launch timings.
-    renders = [tracer.PrepareDevice(o.data_ptr(), stream=stream, shard_rank=rank, shard_count=world) for o in outs]   # camera / lights marshalled once
-    nccl = world > 1 and dist.get_backend() == "nccl"
-    recv = [torch.empty(world * outs[0].numel(), dtype=outs[0].dtype, device="cuda" if nccl else "cpu") for _ in outs] if (world > 1 and rank == 0) else [None, None]
-    pending = []
+GATHER_EVERY = 4   # N > 1: one RCCL gather moves the tiles of this many frames (the collective's fixed cost is ~a frame's GPU time)
 
-    def finish():
-        while pending:
-            g = pending.pop(0)()
-            if nccl:
-                # work.wait() only makes torch's stream wait for the collective; the next frame is rendered on libxrt's
-                # own stream, so the host must know the tile buffer has been read before it is rendered into again
-                torch.cuda.current_stream().synchronize()
-            if rank == 0:
-                xrt.dist.detile_device(g if nccl else g.cuda(), width, height, world, gathered_out)
 
-    open_frame = []                                # at most one (ticket, index): frame i is enqueued before frame i-1 is waited for
+def time_frames_sharded(tracer, outs, steps, warmup, rank, world, width, height, gathered_out):
+    """N > 1.  W warm-up frames, then K timed frames bracketed by barrier + synchronize on both sides.  Each rank renders
+    its tiles of frame i into slot i % M of a group of M tile buffers (two groups); when a group is full (or at the end)
+    ONE gather moves it to rank 0 -- the path's exchange step, RCCL over xGMI -- while the next group is being rendered,
+    and rank 0 de-tiles its M frames.  Every frame is gathered and de-tiled before the closing barrier."""
+    M, n_out = GATHER_EVERY, outs[0].numel()
+    nccl = dist.get_backend() == "nccl"
+    groups = [torch.zeros(M * n_out, dtype=outs[0].dtype, device="cuda") for _ in range(2)]
+    renders = [[tracer.PrepareDevice(g[m * n_out:(m + 1) * n_out].data_ptr(), shard_rank=rank, shard_count=world) for m in range(M)] for g in groups]
+    recv = [torch.empty(world * M * n_out, dtype=outs[0].dtype, device="cuda" if nccl else "cpu") if rank == 0 else None for _ in groups]
+    pending = [None, None]           # per group: (wait function of its gather, frames in it)
+    open_frames, acc = [], [0.0, 0]
+
+    def finish(g):                   # group g's gather is done (its buffers are free again) and its frames are de-tiled
+        if pending[g] is None:
+            return
+        wait, count = pending[g]
+        pending[g] = None
+        got = wait()
+        if nccl:
+            # work.wait() only makes torch's stream wait for the collective; the next frames are rendered on libxrt's own
+            # stream, so the host must know the tile buffers have been read before they are rendered into again
+            torch.cuda.current_stream().synchronize()
+        if rank == 0:
+            dev = got if nccl else got.cuda()          # gloo: rehearsal on a box with fewer GPUs than ranks
+            for m in range(count):
+                xrt.dist.detile_device(dev, width, height, world, gathered_out, rank_stride=M * n_out, offset=m * n_out)
+
+    def flush(g, count):
+        src = groups[g] if nccl else groups[g].cpu()
+        pending[g] = (xrt.dist.gather_frame_async(src, recv=recv[g]), count)
 
     def complete():
-        t, j = open_frame.pop()
-        st = renders[j % 2].end(t)                 # blocking: this rank's tiles of frame j are in HBM
-        if world > 1:
-            src = outs[j % 2] if nccl else outs[j % 2].cpu()   # gloo: rehearsal on a box with fewer GPUs than ranks
-            pending.append(xrt.dist.gather_frame_async(src, recv=recv[j % 2]))   # the path's exchange step (RCCL gather over xGMI)
-        return st
+        t, j = open_frames.pop(0)
+        st = renders[(j // M) % 2][j % M].end(t)   # blocking: this rank's tiles of frame j are in HBM
+        acc[0] += st["ms_intersect"]
+        acc[1] += st["intersect_launches"]
+        if j % M == M - 1:
+            flush((j // M) % 2, M)
+        return j
 
     def frame(i):
-        finish()                                   # frame i-2's gather is done: its tile buffer is free again
-        t = renders[i % 2].begin()                 # host side of frame i overlaps the GPU side of frame i-1 (and its gather)
-        st = complete() if open_frame else None
-        open_frame.append((t, i))
-        return st
+        g, m = (i // M) % 2, i % M
+        if m == 0:
+            finish(g)
+        open_frames.append((renders[g][m].begin(), i))   # host side of frame i overlaps the GPU side of frame i-1
+        while len(open_frames) >= 2:
+            complete()
 
     def drain():
-        st = complete() if open_frame else None
-        finish()
-        return st
+        j = -1
+        while open_frames:
+            j = complete()
+        if j >= 0 and j % M != M - 1:
+            flush((j // M) % 2, j % M + 1)               # the last, partly filled group
+        finish(0)
+        finish(1)
     for i in range(warmup):
         frame(i)
     drain()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist.barrier()
     torch.cuda.synchronize()
+    acc[0], acc[1] = 0.0, 0
     t0 = time.perf_counter()
-    ms_intersect, launches = 0.0, 0
-    for i in range(steps + 1):
-        st = frame(i) if i < steps else drain()
-        if st is not None:
-            ms_intersect += st["ms_intersect"]
-            launches += st["intersect_launches"]
+    for i in range(steps):
+        frame(i)
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return dt, ms_intersect, launches
+    return dt, acc[0], acc[1]
+
+
+def time_frames(tracer, outs, steps, warmup, rank, world, width, height, gathered_out, stream=None):
+    if world > 1:
+        return time_frames_sharded(tracer, outs, steps, warmup, rank, world, width, height, gathered_out)
+    """One GPU.  W warm-up frames, then K timed frames bracketed by synchronize on both sides; frame i is enqueued before
+    frame i-1 is waited for."""
+    # stream None: libxrt decides (frames of >= 0.5 ms of GPU time alternate between two streams of its own and overlap on
+    # the GPU; shorter ones share one stream).  A given stream serialises the frames: used for per-launch timings.
+    renders = [tracer.PrepareDevice(o.data_ptr(), stream=stream) for o in outs]   # camera / lights marshalled once
+    open_frames, acc = [], [0.0, 0]
+
+    def complete():
+        t, j = open_frames.pop(0)
+        st = renders[j % 2].end(t)                 # blocking: frame j is in HBM
+        acc[0] += st["ms_intersect"]
+        acc[1] += st["intersect_launches"]
+
+    def frame(i):
+        open_frames.append((renders[i % 2].begin(), i))   # host side of frame i overlaps the GPU side of frame i-1
+        while len(open_frames) >= 2:
+            complete()
+
+    def drain():
+        while open_frames:
+            complete()
+    for i in range(warmup):
+        frame(i)
+    drain()
+    torch.cuda.synchronize()
+    acc[0], acc[1] = 0.0, 0
+    t0 = time.perf_counter()
+    for i in range(steps):
+        frame(i)
+    drain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt, acc[0], acc[1]
 
 
 def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=True):
@@ -126,6 +178,12 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
     st0 = tracer.RenderDevice(outs[0].data_ptr(), shard_rank=rank, shard_count=world)
     tracer.collect_stats = False
     dt, ms_int, launches = time_frames(tracer, outs, steps, warmup, rank, world, W, H, final)
+    if world > 1 and rank == 0 and os.environ.get("XRT_BENCH_VERIFY"):   # rehearsals: the gathered, de-tiled frame is the unsharded one
+        whole = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+        tracer.RenderDevice(whole.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(whole, final), "gathered frame differs from the unsharded render"
+        print("bench.py: gathered frame verified against the unsharded render", file=sys.stderr)
     rays = st0["rays_closest"] + st0["rays_shadow"]
     res = dict(rays=rays, seconds=dt, ms_intersect=ms_int, launches=launches, stats=st0, build_s=build_s, width=W, height=H,
                tris=sum(m[0].ntri for m in spec.meshes), instances=len(spec.objects), overlapped=False)

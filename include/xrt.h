@@ -256,9 +256,10 @@ int xrt_render_device_end(xrt_scene *scene, int32_t ticket, xrt_stats *stats_out
 int xrt_shard_layout(int32_t width, int32_t height, int32_t shard_count, int32_t *tiles_x_out,
                      int32_t *tiles_y_out, int32_t *tiles_per_rank_out);
 
-/* De-tile the gathered per-rank buffers (shard_count * tiles_per_rank * 512 pixels, rank-major) into
- * a W*H frame on the device (used on rank 0 after the RCCL gather). */
-int xrt_detile_device(int32_t width, int32_t height, int32_t shard_count, const void *d_gathered,
+/* De-tile the gathered per-rank buffers (rank-major: rank r's tiles_per_rank * 512 pixels start at pixel
+ * r * rank_stride; rank_stride 0 = tiles_per_rank * 512, i.e. contiguous) into a W*H frame on the device (used on
+ * rank 0 after the RCCL gather; a stride lets one gather carry the tiles of several frames). */
+int xrt_detile_device(int32_t width, int32_t height, int32_t shard_count, const void *d_gathered, int64_t rank_stride,
                       void *d_rgba_out, void *stream);
 
 /* RayTracer.Progress (RT:43-46): fraction of the frame's ray generations completed; callable from

@@ -33,9 +33,20 @@ def _worker(rank, world, port, width, height, q):
         frame = orc.OracleScene(spec).render(nthreads=1, want_float=False)[0]   # every rank holds the replicated scene
         local = torch.from_numpy(xrt.dist.pack_shard(frame, width, height, rank, world).view(np.int32).copy())
         gathered = xrt.dist.gather_frame(local, width, height)
+        ok = True
         if rank == 0:
             out = xrt.dist.detile_host(gathered.numpy().view(np.uint32), width, height, world)
-            q.put(bool(np.array_equal(out, frame)))
+            ok = bool(np.array_equal(out, frame))
+        # one gather carrying the tiles of M frames (bench.py, N > 1): frame m of rank r sits at r * M * n + m * n
+        M, n = 3, local.numel()
+        frames = [frame, frame[::-1].copy(), (frame ^ np.uint32(0x00ff00ff)).astype(np.uint32)]
+        group = torch.cat([torch.from_numpy(xrt.dist.pack_shard(f, width, height, rank, world).view(np.int32).copy()) for f in frames])
+        got = xrt.dist.gather_frame_async(group, recv=torch.empty(world * M * n, dtype=torch.int32) if rank == 0 else None)()
+        if rank == 0:
+            for m, f in enumerate(frames):
+                out = xrt.dist.detile_host(got.numpy().view(np.uint32), width, height, world, rank_stride=M * n, offset=m * n)
+                ok = ok and bool(np.array_equal(out, f))
+            q.put(ok)
         dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -375,7 +375,15 @@ def test_full_size_properties_c2(xrt):
         part = gathered[r * tpr.value * 512:(r + 1) * tpr.value * 512]
         tracer.RenderDevice(part.data_ptr(), shard_rank=r, shard_count=world)
     out = torch.zeros(1920 * 1080, dtype=torch.int32, device="cuda")
-    xrt.abi.check(xrt.abi.lib().xrt_detile_device(1920, 1080, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out.data_ptr()), None))
+    xrt.abi.check(xrt.abi.lib().xrt_detile_device(1920, 1080, world, C.c_void_p(gathered.data_ptr()), 0, C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), a)
+    # strided form (one gather carrying several frames): the same tiles as frame 1 of 3 per rank
+    n = tpr.value * 512
+    wide = torch.full((world * 3 * n,), -1, dtype=torch.int32, device="cuda")
+    wide.view(world, 3, n)[:, 1, :] = gathered.view(world, n)
+    out.zero_()
+    xrt.dist.detile_device(wide, 1920, 1080, world, out, rank_stride=3 * n, offset=n)
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint32), a)
 

@@ -100,7 +100,7 @@ SYMBOLS = {
     "xrt_render_device_begin": (C.c_int, [C.c_void_p, _P(xrt_camera), _P(xrt_light), C.c_int32, _P(xrt_render_opts), C.c_void_p, C.c_void_p, _P(C.c_int32)]),
     "xrt_render_device_end": (C.c_int, [C.c_void_p, C.c_int32, _P(xrt_stats)]),
     "xrt_shard_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
-    "xrt_detile_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "xrt_detile_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "xrt_progress": (C.c_float, [C.c_void_p]),
     "xrt_generate_primary_rays": (C.c_int, [C.c_void_p, _P(xrt_camera), _P(xrt_ray)]),
 }

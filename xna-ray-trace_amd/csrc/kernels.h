@@ -109,6 +109,7 @@ void launch_resolve(const RayGenParams &g, const uint32_t *sampleColor, const fl
 void launch_ms_decide(const RayGenParams &g, const uint32_t *quadColor, const int *nQuadsDev, int nQuadsHost, long long pixelBase, int *childBase,
                       int *childMask, float *nextCx, float *nextCy, int *nextCount, hipStream_t st);
 void launch_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *childBase, const int *childMask, int n, hipStream_t st);
-void launch_detile(int width, int height, int shardCount, int tilesPerRank, const uint32_t *gathered, uint32_t *out, hipStream_t st);
+void launch_detile(int width, int height, int shardCount, int tilesPerRank, const uint32_t *gathered, long long rankStride, uint32_t *out,
+                   hipStream_t st);
 
 }  // namespace xrt

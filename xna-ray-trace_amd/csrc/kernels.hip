@@ -1152,7 +1152,7 @@ void launch_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *
 
 // rank-major gathered tiles -> W*H frame (rank 0 after the RCCL gather)
 __global__ __launch_bounds__(256) void k_detile(int width, int height, int shardCount, int tilesPerRank, int tilesX, int tilesY,
-                                                const uint32_t *gathered, uint32_t *out) {
+                                                const uint32_t *gathered, long long rankStride, uint32_t *out) {
     const long long total = (long long)shardCount * tilesPerRank * 512;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         int rank;
@@ -1170,12 +1170,12 @@ __global__ __launch_bounds__(256) void k_detile(int width, int height, int shard
         if (t >= (long long)tilesX * tilesY) continue;
         const unsigned ti = (unsigned)t, tyq = ti / (unsigned)tilesX;
         int x = (int)(ti - tyq * (unsigned)tilesX) * XRT_TILE_W + (within & 63), y = (int)tyq * XRT_TILE_H + (within >> 6);
-        if (x < width && y < height) out[(size_t)y * width + x] = gathered[i];
+        if (x < width && y < height) out[(size_t)y * width + x] = gathered[(long long)rank * rankStride + rem];
     }
 }
-void launch_detile(int width, int height, int shardCount, int tilesPerRank, const uint32_t *gathered, uint32_t *out, hipStream_t st) {
+void launch_detile(int width, int height, int shardCount, int tilesPerRank, const uint32_t *gathered, long long rankStride, uint32_t *out, hipStream_t st) {
     int tilesX = (width + XRT_TILE_W - 1) / XRT_TILE_W, tilesY = (height + XRT_TILE_H - 1) / XRT_TILE_H;
-    hipLaunchKernelGGL(k_detile, dim3(2048), dim3(256), 0, st, width, height, shardCount, tilesPerRank, tilesX, tilesY, gathered, out);
+    hipLaunchKernelGGL(k_detile, dim3(2048), dim3(256), 0, st, width, height, shardCount, tilesPerRank, tilesX, tilesY, gathered, rankStride, out);
 }
 
 }  // namespace xrt

@@ -1077,13 +1077,16 @@ int xrt_shard_layout(int32_t width, int32_t height, int32_t shard_count, int32_t
     return XRT_OK;
 }
 
-int xrt_detile_device(int32_t width, int32_t height, int32_t shard_count, const void *d_gathered, void *d_rgba_out, void *stream) {
+int xrt_detile_device(int32_t width, int32_t height, int32_t shard_count, const void *d_gathered, int64_t rank_stride, void *d_rgba_out,
+                      void *stream) {
     if (width <= 0 || height <= 0 || shard_count <= 0 || !d_gathered || !d_rgba_out) return fail(XRT_E_INVALID_ARG, "xrt_detile_device: bad argument");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(XRT_E_NO_DEVICE, "no HIP device visible"); }
     int tpr = 0;
     xrt_shard_layout(width, height, shard_count, nullptr, nullptr, &tpr);
-    launch_detile(width, height, shard_count, tpr, (const uint32_t *)d_gathered, (uint32_t *)d_rgba_out, (hipStream_t)stream);
+    if (rank_stride < 0 || (rank_stride > 0 && rank_stride < (int64_t)tpr * 512)) return fail(XRT_E_INVALID_ARG, "xrt_detile_device: rank_stride smaller than a rank's tiles");
+    launch_detile(width, height, shard_count, tpr, (const uint32_t *)d_gathered, rank_stride > 0 ? rank_stride : (long long)tpr * 512,
+                  (uint32_t *)d_rgba_out, (hipStream_t)stream);
     HIPCHECK(hipGetLastError());
     return XRT_OK;
 }

@@ -41,10 +41,12 @@ def pack_shard(frame, width, height, rank, world):
     return out
 
 
-def detile_host(gathered, width, height, world):
+def detile_host(gathered, width, height, world, rank_stride=0, offset=0):
     """Host mirror of xrt_detile_device (k_detile): rank-major gathered buffers -> H*W frame."""
     tx, ty, tpr = shard_layout(width, height, world)
-    g = np.asarray(gathered, dtype=np.uint32).reshape(world, tpr, abi.TILE_H, abi.TILE_W)
+    flat = np.asarray(gathered, dtype=np.uint32).reshape(-1)
+    stride = rank_stride or tpr * 512
+    g = np.stack([flat[offset + r * stride: offset + r * stride + tpr * 512] for r in range(world)]).reshape(world, tpr, abi.TILE_H, abi.TILE_W)
     img = np.zeros((height, width), dtype=np.uint32)
     for rank in range(world):
         for slot in range(tpr):
@@ -83,8 +85,9 @@ def gather_frame_async(local, group=None, dst=0, recv=None):
     return wait
 
 
-def detile_device(gathered, width, height, world, out, stream=None):
-    """xrt_detile_device on HBM-resident tensors."""
-    abi.check(abi.lib().xrt_detile_device(width, height, world, C.c_void_p(gathered.data_ptr()), C.c_void_p(out.data_ptr()),
-                                          C.c_void_p(stream or 0)))
+def detile_device(gathered, width, height, world, out, stream=None, rank_stride=0, offset=0):
+    """xrt_detile_device on HBM-resident tensors.  rank_stride / offset (pixels): rank r's tiles start at
+    offset + r * rank_stride of `gathered` (0 = contiguous) -- one gather may carry the tiles of several frames."""
+    abi.check(abi.lib().xrt_detile_device(width, height, world, C.c_void_p(gathered.data_ptr() + 4 * int(offset)), int(rank_stride),
+                                          C.c_void_p(out.data_ptr()), C.c_void_p(stream or 0)))
     return out
