@@ -936,6 +936,7 @@ int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_thre
     scene->blocksPerCU = intersect_blocks_per_cu(scene->stackNeeded, scene->sceneMode);
     scene->blocksPerCUMesh = intersect_blocks_per_cu(scene->stackNeeded, MODE_MESH);
     scene->firstBatch = (A.meshDepth == 0) ? 256 : 64;   // every mesh is a single leaf: rays are cheap, avoid queue traffic
+    if (const char *e = getenv("XRT_FIRST_BATCH")) { int v = atoi(e); if (v >= 64 && v <= 4096 && v % 64 == 0) scene->firstBatch = v; }
     {   // "long ray first": worth it only where rays can be long, i.e. where some mesh has a real octree
         float frac = 0.25f;
         if (const char *e = getenv("XRT_HEAVY")) frac = (float)atof(e);
