@@ -595,3 +595,30 @@ def test_random_scenes_against_the_oracle(xrt, orc, seed):
             assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
         else:
             assert np.array_equal(rgba, o_rgba), (seed, mode)   # (no fp32 colour vector in the supersampled modes)
+
+
+@pytest.mark.parametrize("name,rows", [("C3", (500, 516)), ("C5_1spp", (600, 608))])
+def test_full_size_c3_c5_pipelined_frames_and_sampled_rows(xrt, name, rows):
+    """C3 and the C5 scene at their full 1080p size (too slow for a full oracle frame in a unit test): eight frames in
+    flight pairwise -- they run long enough to overlap on two streams, with the long-ray list and its cost feedback
+    building up history -- all equal the blocking render, whose sampled rows equal the oracle's."""
+    import torch
+    spec = xrt.configs.config(name)
+    scene, tracer = xrt.configs.build_product(spec)
+    want = tracer.Render().copy()
+    n = spec.width * spec.height
+    outs = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(2)]
+    frs = [tracer.PrepareDevice(o.data_ptr()) for o in outs]
+    open_t = None
+    for i in range(8):
+        t = frs[i % 2].begin()
+        if open_t is not None:
+            frs[(i - 1) % 2].end(open_t)
+            assert np.array_equal(outs[(i - 1) % 2].cpu().numpy().view(np.uint32), want), i
+        open_t = t
+    frs[7 % 2].end(open_t)
+    assert np.array_equal(outs[7 % 2].cpu().numpy().view(np.uint32), want)
+    from oracle import oracle_py as orc
+    o_rgba, _, _ = orc.OracleScene(spec).render(nthreads=8, rows=rows, want_float=False)
+    W = spec.width
+    assert np.array_equal(want.reshape(-1, W)[rows[0]:rows[1]], o_rgba.reshape(-1, W)[rows[0]:rows[1]])
