@@ -515,7 +515,10 @@ def test_scheduling_switches_never_change_results(xrt, monkeypatch, env):
         assert np.array_equal(tracer2.Render(), want)
 
 
-@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606])
+FUZZ_SEEDS = [101, 202, 303, 404, 505, 606] + list(range(1000, 1000 + int(os.environ.get("XRT_FUZZ_EXTRA", "0"))))   # XRT_FUZZ_EXTRA=n: n more scenes
+
+
+@pytest.mark.parametrize("seed", FUZZ_SEEDS)
 def test_random_scenes_against_the_oracle(xrt, orc, seed):
     """Fuzz: random bodies (1-7) of random triangle soups (one to three meshes each, 20-600 triangles, leaf thresholds
     2-40) under random rotations, non-uniform scales and translations; rays from outside, from inside the boxes, exactly
@@ -537,7 +540,13 @@ def test_random_scenes_against_the_oracle(xrt, orc, seed):
     s.lights = [xrt.configs.spot((3, 20, 12)), xrt.configs.directional((0.2, 0.9, 0.3), (0.5, 0.5, 0.4), 0.6)]
     s.max_reflections = 2
     s = s.with_size(96, 54)
-    scene, tracer = xrt.configs.build_product(s)
+    try:
+        scene, tracer = xrt.configs.build_product(s)
+    except xrt.abi.XrtError as e:
+        # bodies that overlap more than the scene threshold allows can never be separated: OSM:101-113 has no depth limit,
+        # the reference would recurse forever and the library refuses the scene
+        assert "would not terminate" in str(e)
+        pytest.skip("the reference's BuildTree would not terminate on this scene")
     o = orc.OracleScene(s)
     # mesh ids are handles: the host mirror numbers meshes by first use in the bodies (OctreeSpatialManager.Build), the
     # oracle wrapper by their position in the spec
