@@ -91,23 +91,47 @@ __device__ __forceinline__ bool long_ray(const SceneView &S, const HeavyArgs &H,
     return H.path > 0.0f && predict_heavy(S, o, d, H.path);
 }
 
+// wave64 inclusive scans on the DPP network (row shifts, then the two row broadcasts): no LDS round trip
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int wave_scan_max(int v) {   // values >= 0
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
 // Stream compaction with ONE global atomic per 1024-thread block and round (atomics on one word serialise at
-// ~11 ns each, MI355X_MICROARCH.md "dequeue"): waves post their ballot counts to LDS, thread 0 reserves the
-// block's range, every flagged lane gets base + (lanes of earlier waves) + (earlier lanes of its wave).
-// Must be called by all threads of the block.
+// ~11 ns each, MI355X_MICROARCH.md "dequeue"): waves post their ballot counts to LDS, the first wave scans them on the
+// DPP network and reserves the block's range, every flagged lane gets base + (lanes of earlier waves) + (earlier
+// lanes of its wave).  Must be called by all threads of the block.
 constexpr int APPEND_BLOCK = 1024;
 __device__ __forceinline__ int block_append(int *counter, bool flag, int *ldsCounts /* [17] */) {
     const unsigned long long m = __ballot(flag);
-    const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
-    if (lane_id() == 0) ldsCounts[wave] = (int)__popcll(m);
+    const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6), lane = lane_id();
+    if (lane == 0) ldsCounts[wave] = (int)__popcll(m);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int total = 0;
-        for (int w = 0; w < nw; w++) { int c = ldsCounts[w]; ldsCounts[w] = total; total += c; }
-        ldsCounts[16] = total ? atomicAdd(counter, total) : 0;
+    if (wave == 0) {
+        const int c = lane < nw ? ldsCounts[lane] : 0;
+        const int incl = wave_scan_add(c);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        int base = 0;
+        if (lane == 0 && total) base = atomicAdd(counter, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < nw) ldsCounts[lane] = base + incl - c;
     }
     __syncthreads();
-    const int slot = ldsCounts[16] + ldsCounts[wave] + lanes_below(m);
+    const int slot = ldsCounts[wave] + lanes_below(m);
     __syncthreads();   // ldsCounts is reused by the next round
     return slot;
 }
@@ -169,26 +193,6 @@ template <> struct SceneHome<MODE_SCENE> { using type = ParkedScene; };
 // ray.  A lane alone in a 40-triangle leaf is done in one step instead of twenty, and a step's arithmetic runs with
 // as many lanes as there are references left, not as there are lanes in a leaf.  Candidates go back to their owner in
 // slot order, which is list order per owner, so MO:293's strict '<' keeps the first of equal distances.
-// wave64 inclusive scans on the DPP network (row shifts, then the two row broadcasts): no LDS round trip
-__device__ __forceinline__ int wave_scan_add(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-__device__ __forceinline__ int wave_scan_max(int v) {   // values >= 0
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
-    return v;
-}
-
 constexpr int COOP_ROUNDS = 2;   // references per lane and cooperative step
 __device__ __forceinline__ void coop_leaf_step(Lane &L, const SceneView &S, unsigned char *own /* [64 * COOP_ROUNDS] of this wave */) {
     constexpr int CAP = 64 * COOP_ROUNDS;
