@@ -631,3 +631,53 @@ def test_full_size_c3_c5_pipelined_frames_and_sampled_rows(xrt, name, rows):
     o_rgba, _, _ = orc.OracleScene(spec).render(nthreads=8, rows=rows, want_float=False)
     W = spec.width
     assert np.array_equal(want.reshape(-1, W)[rows[0]:rows[1]], o_rgba.reshape(-1, W)[rows[0]:rows[1]])
+
+
+def test_changing_frame_parameters_between_pipelined_frames(xrt):
+    """One scene, frames in flight while the caller changes what a frame is: reflection depth, lights, target size, a
+    counting pass in between.  Per-context counters, the light cache, the cost map and the work buffers must follow."""
+    import torch
+    spec = xrt.configs.heightfield_scene(160, 90, m=96)
+    scene, tracer = xrt.configs.build_product(spec)
+
+    def setup(step):
+        tracer.MaxReflections = (2, 4, 1, 3)[step % 4]
+        tracer.CurrentTarget = xrt.api.RenderTarget(*((160, 90), (160, 90), (224, 126), (96, 54))[step % 4])
+        c = spec.camera
+        tracer.CurrentCamera = xrt.api.Camera(c["pos"], c["target"], c["up"], c["fov"],
+                                              xrt.xna.aspect_ratio(tracer.CurrentTarget.Width, tracer.CurrentTarget.Height), c["near"], c["far"])
+        lights = list(tracer.Lights)
+        if step % 4 == 1 and len(lights) < 2:
+            L = xrt.api.DirectionalLight()
+            L.Direction, L.Color, L.Intensity = (0.3, 0.8, 0.5), (0.4, 0.5, 0.6), 0.7
+            tracer.Lights = lights + [L]
+        if step % 4 == 3:
+            tracer.Lights = lights[:1]
+    want = {}
+    for step in range(4):
+        setup(step)
+        want[step] = tracer.Render().copy()
+    assert len({w.tobytes() for w in want.values()}) == 4
+    open_frames = []
+    for i in range(16):
+        step = (i // 2) % 4                      # two frames per parameter set, so consecutive frames in flight differ
+        setup(step)
+        if i == 9:                               # a counting pass (a blocking call: close the open ticket first) in the middle
+            f, t, o, s = open_frames.pop(0)
+            f.end(t)
+            assert np.array_equal(o.cpu().numpy().view(np.uint32), want[s]), (i, s)
+            tracer.collect_stats = True
+            assert np.array_equal(tracer.Render(), want[step])
+            assert tracer.last_stats["tri_tests"] > 0
+            tracer.collect_stats = False
+        out = torch.zeros(tracer.CurrentTarget.Width * tracer.CurrentTarget.Height, dtype=torch.int32, device="cuda")
+        fr = tracer.PrepareDevice(out.data_ptr())
+        open_frames.append((fr, fr.begin(), out, step))
+        while len(open_frames) >= 2:
+            f, t, o, s = open_frames.pop(0)
+            f.end(t)
+            assert np.array_equal(o.cpu().numpy().view(np.uint32), want[s]), (i, s)
+    while open_frames:
+        f, t, o, s = open_frames.pop(0)
+        f.end(t)
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), want[s]), s
