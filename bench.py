@@ -37,6 +37,7 @@ WORKLOADS = {
     "C5_1spp": "C5 scene, 1920x1080, depth=3, 1 spp",
     "H100k": "100k-triangle heightfield (100,352 triangles), 1920x1080, depth=3, 1 spp",
     "G1": "G1: the reference's default scene (Game1.cs): 2x2 Transparent spheres (Sphere.fbx, 960 triangles each), 512x512, MaxReflections 8",
+    "G2": "G2: the reference's content (monkey, torus, sphere, cube, textured ground with the content project's parameters), 1280x720, MaxReflections 4, two lights",
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 

@@ -23,6 +23,22 @@ def main():
     md = fbx.import_mesh(meshes[0], up, scale=2.0, diffuse_color=(255, 0, 0, 100))
     np.savez_compressed(os.path.join(HERE, "sphere_mesh.npz"), v=md.v, n=md.n, uv=md.uv, color=md.color)
     print("Sphere.fbx ->", md.ntri, "triangles")
+    # more of the reference's content, each with the processor parameters the content project gives it
+    # (RayTraceProjectContent.contentproj:124-165; rotation parameters are not reproduced, so prism2 is left out)
+    fixtures = importlib.import_module("xna-ray-trace_amd.fixtures")
+    out = {}
+    for name, asset, kw in (("plane", "plane.fbx", dict(scale=18.0, diffuse_color=(255, 255, 255, 255))),         # contentproj:124-135 "ground" (Scale 18 instead of 3:
+                            # object-space distances are compared across bodies (OSM:370-378), so the size goes into the geometry, not the body)
+                            ("monkey", "monkey.fbx", dict(scale=5.0, diffuse_color=(255, 255, 255, 64))),        # contentproj:137-146
+                            ("torus", "torus.fbx", dict(scale=2.0, diffuse_color=(0, 0, 255, 255))),             # contentproj:148-156
+                            ("cube", "cube.fbx", dict())):                                                        # contentproj:107-110
+        meshes, up = fbx.load_fbx(os.path.join(CONTENT, asset))
+        md = fbx.import_mesh(meshes[0], up, **kw)
+        for k in ("v", "n", "uv", "color"):
+            out[name + "_" + k] = getattr(md, k)
+        print(asset, "->", md.ntri, "triangles")
+    out["checkers_argb"] = fixtures.load_bmp_argb(os.path.join(CONTENT, "checkers.bmp"))   # the content project's texture asset
+    np.savez_compressed(os.path.join(HERE, "content_meshes.npz"), **out)
 
 
 if __name__ == "__main__":

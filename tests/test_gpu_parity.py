@@ -681,3 +681,28 @@ def test_changing_frame_parameters_between_pipelined_frames(xrt):
         f, t, o, s = open_frames.pop(0)
         f.end(t)
         assert np.array_equal(o.cpu().numpy().view(np.uint32), want[s]), s
+
+
+def test_reference_content_scene(xrt, orc):
+    """The reference's own assets (monkey, torus, plane, cube, Sphere from RayTraceProjectContent, imported by fbx.py and
+    committed as data) with the parameters of its content project: glass monkey and sphere (ray tree), textured ground,
+    two lights.  Hits and frames (plain, bilinear + mirror addressing, adaptive supersampling) against the oracle."""
+    spec = xrt.configs.content_scene(192, 108, max_reflections=4)
+    scene, tracer = xrt.configs.build_product(spec)
+    o = orc.OracleScene(spec)
+    prim = o.primary_rays()
+    o_hits = o.intersect(prim)
+    assert (o_hits["hit"] != 0).mean() > 0.3
+    assert hits_equal(o_hits, scene.IntersectBatch(prim)) == {}     # bodies list their meshes in spec order here
+    tracer.collect_stats = True
+    rgba, rgbf = tracer.Render(want_float=True)
+    o_rgba, o_rgbf, o_st = o.render(nthreads=8)
+    assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+    assert o_st["rays_closest"] > 192 * 108 * 1.5, "no ray tree"
+    for k in ("rays_closest", "rays_shadow", "shaded_hits", "tri_tests", "algorithmic_bytes"):
+        assert tracer.last_stats[k] == o_st[k], (k, tracer.last_stats[k], o_st[k])
+    spec2 = xrt.configs.content_scene(128, 72, max_reflections=2)
+    spec2.address_mode, spec2.filtering = xrt.abi.ADDRESS_MIRROR, xrt.abi.FILTER_BILINEAR
+    spec2.multisampling, spec2.multisample_quality = xrt.abi.MS_ADAPTIVE, 1
+    _, tracer2 = xrt.configs.build_product(spec2)
+    assert np.array_equal(tracer2.Render(), orc.OracleScene(spec2).render(nthreads=8, want_float=False)[0])

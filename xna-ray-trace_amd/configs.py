@@ -116,6 +116,36 @@ def default_game_scene(width=512, height=512, max_reflections=8):
     return s.with_size(width, height)
 
 
+def content_scene(width=320, height=180, max_reflections=4):
+    """A scene of the reference's own content with the processor parameters of its content project
+    (RayTraceProjectContent.contentproj): the textured ground plane (:124-135, checkers.bmp standing in for the absent
+    smiley.bmp), the glass monkey (:137-146, alpha 64/255, refraction index 1.32), the blue reflective torus (:148-156),
+    the Game1 glass sphere (:87-96) and the default cube (:107-110).  Geometry = tests/golden/content_meshes.npz,
+    imported from the FBX files by xna-ray-trace_amd/fbx.py."""
+    import os
+    s = SceneSpec("reference_content")
+    z = np.load(os.path.join(fixtures._GOLDEN, "content_meshes.npz"))
+    zs = np.load(os.path.join(fixtures._GOLDEN, "sphere_mesh.npz"))
+
+    def md(name):
+        return fixtures.MeshData(z[name + "_v"], z[name + "_n"], z[name + "_uv"], z[name + "_color"])
+    s.meshes.append((md("plane"), material(0.5, interpolate_normals=False, texture=np.ascontiguousarray(z["checkers_argb"]))))
+    s.meshes.append((md("monkey"), material(0.5, transparent=True, refraction_index=float(f32(1.32)), interpolate_normals=True)))
+    s.meshes.append((md("torus"), material(0.7, interpolate_normals=True)))
+    s.meshes.append((fixtures.MeshData(zs["v"], zs["n"], zs["uv"], zs["color"]),
+                     material(0.7, transparent=True, refraction_index=float(f32(1.32)), interpolate_normals=True)))
+    s.meshes.append((md("cube"), material(0.5, interpolate_normals=True)))
+    s.objects.append(([0], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))            # ground, 36 x 36 (sized by the processor's Scale)
+    s.objects.append(([1], (-2.0, 5.2, -4.0), (0.0, 0.4, 0.0), (1.0, 1.0, 1.0)))          # monkey
+    s.objects.append(([2], (8.0, 3.0, 2.0), (1.2, 0.0, 0.3), (1.0, 1.0, 1.0)))            # torus
+    s.objects.append(([3], (-8.0, 2.2, 5.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))           # sphere
+    s.objects.append(([4], (3.0, 1.0, 8.0), (0.0, 0.7, 0.0), (1.0, 1.0, 1.0)))            # cube
+    s.camera = camera((0, 14, 30), (0, 3, 0))
+    s.lights = [spot((6, 22, 18)), directional((0.3, 0.8, 0.5), (0.4, 0.4, 0.5), 0.5)]
+    s.max_reflections = max_reflections
+    return s.with_size(width, height)
+
+
 def config(name, scale=1.0):
     """BASELINE.json configs by id.  `scale` shrinks the image (parity tests at oracle-friendly sizes)."""
     def sz(w, h):
@@ -136,6 +166,8 @@ def config(name, scale=1.0):
         return heightfield_scene(*sz(1920, 1080), m=224)
     if name == "G1":
         return default_game_scene(*sz(512, 512))
+    if name == "G2":
+        return content_scene(*sz(1280, 720))
     raise KeyError(name)
 
 
