@@ -361,7 +361,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     long long maxPaths = s->maxChunkPaths;
     if (nL > 1 && maxPaths > (1LL << 30) / nL) maxPaths = ((1LL << 30) / nL) & ~8191LL;   // shadow rays of a generation are counted in an int
     if (heap) {
-        maxPaths = 262144;
+        maxPaths = 1 << 21;   // (a 1080p frame is one chunk when the level records fit 8 GB: MaxReflections <= 6)
         const long long byRecords = (long long)((8ull << 30) / (nodes * 36ull));
         if (byRecords < maxPaths) maxPaths = byRecords;
         maxPaths &= ~63LL;
