@@ -706,3 +706,24 @@ def test_reference_content_scene(xrt, orc):
     spec2.multisampling, spec2.multisample_quality = xrt.abi.MS_ADAPTIVE, 1
     _, tracer2 = xrt.configs.build_product(spec2)
     assert np.array_equal(tracer2.Render(), orc.OracleScene(spec2).render(nthreads=8, want_float=False)[0])
+
+
+def test_ray_tree_overflow_retries_with_fewer_paths(xrt, monkeypatch):
+    """A generation of the ray tree that does not fit the ray buffers (forced here by XRT_HEAP_RAY_CAP: one ray per path,
+    while a glass sphere filling the view doubles the rays of most paths) is discarded and its chunk retried with a
+    quarter of the paths: same frame, same accounting as with room to spare."""
+    spec = xrt.configs.default_game_scene(96, 96, max_reflections=4)
+    spec.objects = [([0], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (4.0, 4.0, 4.0))]
+    spec.camera = xrt.configs.camera((0, 0, 14), (0, 0, 0))
+    scene, tracer = xrt.configs.build_product(spec)
+    want = tracer.Render().copy()
+    st_want = dict(tracer.last_stats)
+    assert st_want["rays_closest"] > 3 * 96 * 96, "the sphere does not fill the view"
+    monkeypatch.setenv("XRT_HEAP_RAY_CAP", "1024")
+    scene2, tracer2 = xrt.configs.build_product(spec)
+    monkeypatch.delenv("XRT_HEAP_RAY_CAP")
+    got = tracer2.Render()
+    assert np.array_equal(got, want)
+    for k in ("rays_closest", "rays_shadow", "shaded_hits", "pixels"):
+        assert tracer2.last_stats[k] == st_want[k], (k, tracer2.last_stats[k], st_want[k])
+    assert tracer2.last_stats["intersect_launches"] > st_want["intersect_launches"], "no chunk was split"

@@ -153,6 +153,7 @@ struct xrt_scene {
     } frames[2];
     std::vector<hipEvent_t> events;   // xrt_scene_intersect timing
     int firstBatch = 64;
+    long long heapRayCap = HEAP_RAY_CAP;         // XRT_HEAP_RAY_CAP=<n> forces small ray buffers (tests of the overflow / retry path)
     long long maxChunkPaths = MAX_CHUNK_PATHS;   // XRT_CHUNK_PATHS=<n> (multiple of 8192) forces smaller chunks (tests of the multi-chunk path)
     float lastFrameMs = 0.0f;    // GPU time of the last finished frame
     float overlapMinMs = 0.5f;   // frames at least this long run on per-context streams
@@ -370,7 +371,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const long long chunkPaths = firstPaths < maxPaths ? firstPaths : maxPaths;
     const int P = (int)chunkPaths;
     size_t rayCap = (size_t)P;
-    if (heap) { rayCap = (R < 20 && ((size_t)P << R) < (size_t)HEAP_RAY_CAP) ? ((size_t)P << R) : (size_t)HEAP_RAY_CAP; if (rayCap < (size_t)P) rayCap = (size_t)P; }
+    if (heap) { rayCap = (R < 20 && ((size_t)P << R) < (size_t)s->heapRayCap) ? ((size_t)P << R) : (size_t)s->heapRayCap; if (rayCap < (size_t)P) rayCap = (size_t)P; }
     const size_t shadowCap = rayCap;   // hits of one generation (each emits nL shadow rays)
     const bool wantF32 = d_outF32 != nullptr && !adaptive && g.samples == 1;
     const bool fuseResolve = !adaptive && !heap && g.samples == 1;   // k_compose writes the framebuffer itself
@@ -858,6 +859,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     s->device = device;
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
     if (const char *e = getenv("XRT_OVERLAP_MS")) s->overlapMinMs = (float)atof(e);   // 0: every single-chunk frame gets its context's stream
+    if (const char *e = getenv("XRT_HEAP_RAY_CAP")) { long long v = atoll(e); if (v >= 1024 && v <= HEAP_RAY_CAP) s->heapRayCap = v; }
     if (const char *e = getenv("XRT_CHUNK_PATHS")) { long long v = atoll(e); if (v >= 8192 && v <= MAX_CHUNK_PATHS && v % 8192 == 0) s->maxChunkPaths = v; }
     if (const char *t = getenv("XRT_TUNE")) {   // "refill,nodeBurst,leafBurst[,coopMax]" — scheduling only, never results
         int v[4] = {0, 0, 0, s->tune[3]};
