@@ -39,6 +39,7 @@ def lib():
         l.emu_add_mesh.argtypes = [C.c_void_p, _F, _F, _F, _F, _F, C.c_int, C.POINTER(abi.xrt_material), _F]
         l.emu_add_object.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int, _F, _F, _F, _F]
         l.emu_build.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.emu_set_cull_safety.argtypes = [C.c_void_p, C.c_double]
         l.emu_get_tree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64)]
         l.emu_tree_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         l.emu_intersect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
@@ -52,10 +53,12 @@ def _fp(a):
 
 
 class EmulScene:
-    def __init__(self, spec):
+    def __init__(self, spec, cull_safety=None):
         from oracle import oracle_py as orc
         L = lib()
         self.h = C.c_void_p(L.emu_create())
+        if cull_safety is not None:
+            L.emu_set_cull_safety(self.h, float(cull_safety))
         for data, m in spec.meshes:
             a, keep = orc.material_abi(m)
             sn = np.ascontiguousarray(data.surface_normal, dtype=np.float32)

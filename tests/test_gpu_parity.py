@@ -515,7 +515,9 @@ def test_scheduling_switches_never_change_results(xrt, monkeypatch, env):
         assert np.array_equal(tracer2.Render(), want)
 
 
-FUZZ_SEEDS = [101, 202, 303, 404, 505, 606] + list(range(1000, 1000 + int(os.environ.get("XRT_FUZZ_EXTRA", "0"))))   # XRT_FUZZ_EXTRA=n: n more scenes
+# 32 committed seeds in the default run; XRT_FUZZ_EXTRA=n adds n more scenes
+FUZZ_SEEDS = [101, 202, 303, 404, 505, 606, 707, 808, 909, 1111, 1212, 1313, 1414, 1515, 1616, 1717, 1818, 1919, 2020, 2121, 2222, 2323, 2424, 2525,
+              2626, 2727, 2828, 2929, 3030, 3131, 3232, 3333] + list(range(5000, 5000 + int(os.environ.get("XRT_FUZZ_EXTRA", "0"))))
 
 
 @pytest.mark.parametrize("seed", FUZZ_SEEDS)
@@ -604,6 +606,29 @@ def test_random_scenes_against_the_oracle(xrt, orc, seed):
             assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
         else:
             assert np.array_equal(rgba, o_rgba), (seed, mode)   # (no fp32 colour vector in the supersampled modes)
+
+
+def test_object_precull_far_origins_and_grazing_rays(xrt, orc):
+    """The world-space object pre-cull (traverse.h advance_scene, margin m(|o|) of DESIGN.md §3) on the GPU: rays from 1e3,
+    1e4 and 1e5 units away aimed around the corners of two small bodies near the origin (the regime where the reference's
+    own ray transform, OSM:358-364, loses precision like eps * |o|^2), and rays grazing the un-enlarged world hull of
+    bodies scaled 1e-3 .. 1e3 with condition numbers up to ~350 within 1e-7 .. 1e-3 of its size."""
+    from util import far_origin_scene, far_origin_rays, precull_adversarial_scene, grazing_rays
+    s = far_origin_scene(xrt)
+    scene, _ = xrt.configs.build_product(s)
+    o = orc.OracleScene(s)
+    for radius, seed in ((1e3, 1), (1e4, 2), (1e5, 3)):
+        rays = far_origin_rays(xrt, s, radius, 2000, seed)
+        ho = o.intersect(rays)
+        assert hits_equal(ho, scene.IntersectBatch(rays)) == {}, radius
+    s = precull_adversarial_scene(xrt)
+    scene, _ = xrt.configs.build_product(s)
+    o = orc.OracleScene(s)
+    for seed in (11, 12):
+        rays = grazing_rays(xrt, s, 6000, seed)
+        ho = o.intersect(rays)
+        assert 0.02 < (ho["hit"] != 0).mean() < 0.98
+        assert hits_equal(ho, scene.IntersectBatch(rays)) == {}, seed
 
 
 @pytest.mark.parametrize("name,rows", [("C3", (500, 516)), ("C5_1spp", (600, 608))])

@@ -249,6 +249,36 @@ def test_conservative_skips_under_grazing_rays(xrt, orc, emul):
         assert hits_equal(o.intersect(sec), e.intersect(sec)) == {}
 
 
+def test_object_precull_far_origins(xrt, orc, emul):
+    """with the world-space pre-cull margin independent of the ray, rays from 1e4 units away lost hits the
+    reference finds (and found the wrong body).  The margin is now m(|o|) (scene_host.cpp): 96k rays from
+    radius 1e3, 1e4 and 1e5 answer exactly like the oracle -- and with the margin cut to a thousandth of the proven bound
+    the same rays DO show mismatches, i.e. the test reaches the regime the bound is for."""
+    from util import far_origin_scene, far_origin_rays
+    s = far_origin_scene(xrt)
+    o, e = orc.OracleScene(s), emul.EmulScene(s)
+    weak = emul.EmulScene(s, cull_safety=1e-3)
+    bitten = 0
+    for radius, seed in ((1e3, 1), (1e4, 2), (1e5, 3)):
+        rays = far_origin_rays(xrt, s, radius, 2000, seed)
+        ho = o.intersect(rays)
+        assert hits_equal(ho, e.intersect(rays)) == {}, radius
+        bitten += len(hits_equal(ho, weak.intersect(rays)))
+    assert bitten > 0
+
+
+def test_object_precull_adversarial_transforms(xrt, orc, emul):
+    """Rays grazing the un-enlarged world hull of every body within 1e-7 .. 1e-3 of its size, bodies scaled by 1e-3 .. 1e3
+    with condition numbers up to ~350, origins from one to 1e5 hull sizes away (tests/util.py)."""
+    from util import precull_adversarial_scene, grazing_rays
+    s = precull_adversarial_scene(xrt)
+    o, e = orc.OracleScene(s), emul.EmulScene(s)
+    rays = grazing_rays(xrt, s, 6000, 11)
+    ho = o.intersect(rays)
+    assert 0.02 < (ho["hit"] != 0).mean() < 0.98
+    assert hits_equal(ho, e.intersect(rays)) == {}
+
+
 REF_CONTENT = "/root/reference/RayTraceProject/RayTraceProjectContent"
 
 

@@ -50,3 +50,89 @@ def random_rays(xrt, n, seed, radius=3.0):
     d = t - o
     d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
     return xrt.rays_array(o, d.astype(np.float32))
+
+
+def precull_adversarial_scene(xrt, seed=7):
+    """Bodies whose transforms stress the world-space object pre-cull: scales from 1e-3 to 1e3, condition
+    numbers up to ~350 (a 300:1 non-uniform scale under a rotation), far from and near the world origin.  Fewer bodies
+    than the scene threshold: one scene leaf, every ray visits every body."""
+    rng = np.random.default_rng(seed)
+    s = xrt.configs.SceneSpec("precull")
+    s.meshes.append((xrt.fixtures.crate(2), xrt.configs.material(0.5)))
+    s.meshes.append((triangle_soup(120, seed, 0.5), xrt.configs.material(0.3)))
+    scales = [(1e-3, 1e-3, 1e-3), (1e3, 1e3, 1e3), (1.0, 300.0, 1.0), (250.0, 1.0, 1.0), (0.01, 3.5, 0.01), (1.0, 1.0, 1.0), (30.0, 0.1, 5.0),
+              (2.0, 2.0, 700.0), (0.5, 0.5, 0.5), (1.0, 1.0, 1.0), (5.0, 1e-2, 1e-2), (1e2, 1e2, 1e-1)]
+    for k, sc in enumerate(scales):
+        far = 1.0 if k % 3 else 40.0
+        p = tuple(float(x) for x in rng.uniform(-300, 300, size=3) * far)
+        rot = tuple(float(x) for x in rng.uniform(-3.1, 3.1, size=3))
+        s.objects.append(([k % 2], p, rot, sc))
+    s.camera = xrt.configs.camera((0, 2000, 4000), (0, 0, 0), far=100000.0)
+    s.lights = [xrt.configs.spot((0, 3000, 3000))]
+    return s.with_size(64, 36)
+
+
+def grazing_rays(xrt, spec, per_body, seed, radii=(1.0, 30.0, 1e3, 1e4, 1e5)):
+    """Rays that graze the exact world-space hull of every body's mesh AABBs (the box the pre-cull tests before it is
+    enlarged): targets on the hull's faces, edges and corners, pushed in or out by 1e-7 .. 1e-3 of its size, origins at
+    `radii` times the hull size away in random directions."""
+    rng = np.random.default_rng(seed)
+    origins, dirs = [], []
+    for ids, p, rot, sc in spec.objects:
+        bb = np.zeros(6)
+        for i in ids:
+            bb[:3] = np.minimum(bb[:3], spec.meshes[i][0].bbox[:3])
+            bb[3:] = np.maximum(bb[3:], spec.meshes[i][0].bbox[3:])
+        world, inv, wbb = xrt.xna.build_world(sc, rot, p, bb.astype(np.float32))
+        W = xrt.xna.as_array(world).reshape(4, 4).astype(np.float64)
+        corners = np.array([[bb[3 if c & 1 else 0], bb[4 if c & 2 else 1], bb[5 if c & 4 else 2], 1.0] for c in range(8)]) @ W
+        lo, hi = corners[:, :3].min(axis=0), corners[:, :3].max(axis=0)
+        size = float(np.linalg.norm(hi - lo))
+        n = per_body
+        t = rng.uniform(0, 1, size=(n, 3))
+        snap = rng.integers(0, 4, size=(n, 3))            # per axis: 0/1 free, 2 -> lo face, 3 -> hi face
+        t = np.where(snap == 2, 0.0, np.where(snap == 3, 1.0, t))
+        none = (snap < 2).all(axis=1)
+        t[none, 0] = rng.integers(0, 2, size=int(none.sum()))   # at least one coordinate on the surface
+        tgt = lo + t * (hi - lo)
+        tgt += rng.normal(size=(n, 3)) * size * (10.0 ** rng.uniform(-7, -3, size=(n, 1)))
+        org = rng.normal(size=(n, 3))
+        org = org / np.linalg.norm(org, axis=1, keepdims=True) * size * rng.choice(radii, size=(n, 1))
+        org += tgt
+        d = tgt - org
+        origins.append(org)
+        dirs.append(d / np.linalg.norm(d, axis=1, keepdims=True))
+    return xrt.rays_array(np.concatenate(origins).astype(np.float32), np.concatenate(dirs).astype(np.float32))
+
+
+def far_origin_scene(xrt):
+    """Two small bodies near the world origin (one rotated and non-uniformly scaled): a single-body scene would hide a
+    wrong pre-cull behind the scene root box."""
+    s = xrt.configs.SceneSpec("far")
+    s.meshes.append((xrt.fixtures.crate(2), xrt.configs.material(0.5)))
+    s.objects.append(([0], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    s.objects.append(([0], (30.0, 5.0, -20.0), (0.3, 1.1, -0.4), (1.0, 1.3, 0.8)))
+    s.camera = xrt.configs.camera((0, 200, 400), (0, 0, 0))
+    s.lights = [xrt.configs.spot((0, 300, 300))]
+    return s.with_size(64, 36)
+
+
+def far_origin_rays(xrt, spec, radius, per_corner, seed):
+    """Rays from a sphere of `radius` around the world origin towards points scattered (1e-4 .. 3 units) around the
+    corners of every body's world-space box: the reference's object-space ray (OSM:358-364) is bent by the cancellation
+    in Transform(o + d) - Transform(o), an error that grows like eps * |o|^2."""
+    rng = np.random.default_rng(seed)
+    origins, dirs = [], []
+    for ids, p, rot, sc in spec.objects:
+        bb = spec.meshes[ids[0]][0].bbox
+        world, inv, wbb = xrt.xna.build_world(sc, rot, p, bb)
+        W = xrt.xna.as_array(world).reshape(4, 4).astype(np.float64)
+        for c in range(8):
+            wc = np.array([bb[3 if c & 1 else 0], bb[4 if c & 2 else 1], bb[5 if c & 4 else 2], 1.0]) @ W
+            tgt = wc[:3] + rng.normal(size=(per_corner, 3)) * (10.0 ** rng.uniform(-4, 0.5, size=(per_corner, 1)))
+            org = rng.normal(size=(per_corner, 3))
+            org = org / np.linalg.norm(org, axis=1, keepdims=True) * radius
+            d = tgt - org
+            origins.append(org)
+            dirs.append(d / np.linalg.norm(d, axis=1, keepdims=True))
+    return xrt.rays_array(np.concatenate(origins).astype(np.float32), np.concatenate(dirs).astype(np.float32))

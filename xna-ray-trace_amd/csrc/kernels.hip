@@ -170,6 +170,9 @@ struct LdsRay {
         return *this;
     }
 };
+__device__ __forceinline__ void ray_axis(const LdsRay &w, int k, float &o, float &d, float &inv) {
+    o = i2f((int)w.p[64 * k]); d = i2f((int)w.p[64 * (3 + k)]); inv = i2f((int)w.p[64 * (6 + k)]);
+}
 constexpr int PARK_WORDS = 27;
 struct ParkedScene {
     LdsRay w;

@@ -54,14 +54,53 @@ int HostScene::add_object(const int *meshIds, int n, const float *world, const f
     return (int)objects.size() - 1;
 }
 
-// World-space pre-cull box of one SceneObject.  The reference transforms the ray into object space with
-// InverseWorld and tests each mesh AABB there (OSM:349-368).  The affine image of a mesh AABB under
-// (InverseWorld)^-1 lies inside the axis-aligned box of its eight transformed corners, so a world ray that misses
-// that box misses the AABB in object space in exact arithmetic; enlarging the box by 1e-3 of its size leaves
-// three to four orders of magnitude over the binary32 rounding of the reference's own transform and slab test as
-// long as the transform is well conditioned (checked; otherwise the object is never pre-culled).
-static void object_cull_box(const HostObject &o, const std::vector<HostMesh> &meshes, ObjRec &r) {
+// Largest eigenvalue of the symmetric 3x3 matrix M (closed form, double): the square of a 2-norm.
+static double sym3_max_eig(const double M[3][3]) {
+    const double p1 = M[0][1] * M[0][1] + M[0][2] * M[0][2] + M[1][2] * M[1][2];
+    if (p1 == 0.0) return std::fmax(M[0][0], std::fmax(M[1][1], M[2][2]));
+    const double q = (M[0][0] + M[1][1] + M[2][2]) / 3.0;
+    const double p2 = (M[0][0] - q) * (M[0][0] - q) + (M[1][1] - q) * (M[1][1] - q) + (M[2][2] - q) * (M[2][2] - q) + 2.0 * p1;
+    const double p = std::sqrt(p2 / 6.0);
+    double Bm[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Bm[i][j] = (M[i][j] - (i == j ? q : 0.0)) / p;
+    double r = (Bm[0][0] * (Bm[1][1] * Bm[2][2] - Bm[1][2] * Bm[2][1]) - Bm[0][1] * (Bm[1][0] * Bm[2][2] - Bm[1][2] * Bm[2][0]) +
+                Bm[0][2] * (Bm[1][0] * Bm[2][1] - Bm[1][1] * Bm[2][0])) / 2.0;
+    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    return q + 2.0 * p * std::cos(std::acos(r) / 3.0);
+}
+static double norm2_3x3(const double A[3][3]) {   // ||A||_2 = sqrt(lambda_max(A^T A)), rounded up
+    double M[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = A[0][i] * A[0][j] + A[1][i] * A[1][j] + A[2][i] * A[2][j];
+    const double l = sym3_max_eig(M);
+    return std::sqrt(l > 0.0 ? l : 0.0) * (1.0 + 1e-9);
+}
+
+// World-space pre-cull record of one SceneObject (ObjRec::cullMin/cullMax/cullK2; DESIGN.md §3 has the derivation).
+//
+// The reference transforms the world ray (o, d) into object space in binary32 (OSM:358-364):
+//     q = fl(o + d);  v1 = fl(o*A + t);  v2 = fl(q*A + t);  w = fl(v2 - v1);  dir = fl(normalize(w))
+// (A, t = linear part and translation row of InverseWorld) and tests every mesh AABB with BoundingBox.Intersects
+// (MESH:34-39).  With u = 2^-24, r = |o|, a = ||A||_2, alpha = ||A||_F, beta = ||A^-1||_2, tau = |t|, B = the largest
+// corner norm of the object's mesh AABBs and V = a r + tau + B (>= |v1| + B, the reach of the object-space ray up to
+// the box):
+//   * |v1 - (oA + t)|        <= 4u (alpha r + tau)                                   (three products, three sums per component)
+//   * |w' - dA|              <= 10u (alpha (r + 2) + tau), w' = the direction actually used (normalisation is a common
+//                               factor; its last multiplication perturbs each component by u)
+//   * a hit of the binary32 slab test means the point of the ray (v1, dir) at parameter tmin >= 0 lies inside the AABB
+//     enlarged by 3.1u (|v1_k| + |b_k|) per axis, or, on an axis taken as parallel (|dir_k| < 1e-6), by 1e-6 * tmin:
+//     together <= 29.1u V
+//   so the exact image of the world ray, oA + t + s dA (s >= 0), passes within
+//       D = 4u (alpha r + tau) + beta V 10u (alpha (r + 2) + tau) + 29.1u V
+//   of the AABB, and the world ray itself within beta * D of the AABB's exact world image, which lies inside the
+//   axis-aligned hull of its eight mapped corners (cullMin/cullMax, evaluated in double).
+//   * the world-space test is binary32 too: 3.1u (|o_k| + |c_k|) per axis, 1e-6 * reach on a parallel axis: <= 23u (r + 2C),
+//     C = the hull's largest coordinate.
+// m(r) = S * [beta * D + 23u (r + 2C)] is a quadratic in r; S = 2 pays for rounding m's own evaluation, the 1-norm the
+// kernel uses for r and the float conversion of the coefficients.  A ray that misses the hull enlarged by m(r) cannot be
+// accepted by MESH:34-39 for any mesh of the object.
+static void object_cull_box(const HostObject &o, const std::vector<HostMesh> &meshes, ObjRec &r, double safety) {
     r.cullOk = 0;
+    r.cullK2 = 0;
     for (int a = 0; a < 4; a++) { r.cullMin[a] = 0; r.cullMax[a] = 0; }
     double A[3][3], t[3];
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) A[i][j] = (double)o.invWorld[4 * i + j]; t[i] = (double)o.invWorld[12 + i]; }
@@ -74,15 +113,19 @@ static void object_cull_box(const HostObject &o, const std::vector<HostMesh> &me
     B[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) / det; B[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det; B[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det;
     B[1][0] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) / det; B[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det; B[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
     B[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det; B[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det; B[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
-    double na = 0, nb = 0;
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { na += A[i][j] * A[i][j]; nb += B[i][j] * B[i][j]; }
-    if (!(std::sqrt(na) * std::sqrt(nb) <= 300.0)) return;   // Frobenius condition estimate (3 for a rotation)
-    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    double fro = 0;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) fro += A[i][j] * A[i][j];
+    const double alpha = std::sqrt(fro) * (1.0 + 1e-9), a2 = norm2_3x3(A), beta = norm2_3x3(B);
+    const double tau = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+    if (!(alpha <= 1e15 && beta <= 1e15 && tau <= 1e15)) return;
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300}, Bn = 0;
     if (o.meshes.empty()) return;
     for (int mi : o.meshes) {
         const float *bb = meshes[(size_t)mi].bbox;
         for (int c = 0; c < 8; c++) {
-            double p[3] = {(double)bb[(c & 1) ? 3 : 0] - t[0], (double)bb[(c & 2) ? 4 : 1] - t[1], (double)bb[(c & 4) ? 5 : 2] - t[2]};
+            const double q[3] = {(double)bb[(c & 1) ? 3 : 0], (double)bb[(c & 2) ? 4 : 1], (double)bb[(c & 4) ? 5 : 2]};
+            Bn = std::fmax(Bn, std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]));
+            const double p[3] = {q[0] - t[0], q[1] - t[1], q[2] - t[2]};
             for (int j = 0; j < 3; j++) {
                 double w = p[0] * B[0][j] + p[1] * B[1][j] + p[2] * B[2][j];
                 if (!(std::fabs(w) <= 1e30)) return;
@@ -91,11 +134,16 @@ static void object_cull_box(const HostObject &o, const std::vector<HostMesh> &me
             }
         }
     }
-    double diag = 0, big = 0;
-    for (int j = 0; j < 3; j++) { diag += (mx[j] - mn[j]) * (mx[j] - mn[j]); big = std::fmax(big, std::fmax(std::fabs(mn[j]), std::fabs(mx[j]))); }
-    const double delta = 1e-3 * (std::sqrt(diag) + big) + 1e-30;
-    for (int j = 0; j < 3; j++) { r.cullMin[j] = (float)(mn[j] - delta); r.cullMax[j] = (float)(mx[j] + delta); }
-    // float conversion may round inwards by half an ulp: far inside the margin
+    double Cmax = 0;
+    for (int j = 0; j < 3; j++) Cmax = std::fmax(Cmax, std::fmax(std::fabs(mn[j]), std::fabs(mx[j])));
+    const double u = std::ldexp(1.0, -24), S = safety;
+    const double k2 = S * u * 10.0 * beta * beta * a2 * alpha;
+    const double k1 = S * u * (4.0 * beta * alpha + 10.0 * beta * beta * (a2 * (2.0 * alpha + tau) + alpha * (tau + Bn)) + 29.1 * beta * a2 + 23.0);
+    const double k0 = S * u * (4.0 * beta * tau + 10.0 * beta * beta * (tau + Bn) * (2.0 * alpha + tau) + 29.1 * beta * (tau + Bn) + 46.0 * Cmax);
+    if (!(k0 <= 1e30 && k1 <= 1e30 && k2 <= 1e30)) return;
+    const double up = 1.0 + 1e-6;   // the float conversions below may round down by half an ulp
+    for (int j = 0; j < 3; j++) { r.cullMin[j] = (float)(mn[j] - 1e-6 * std::fabs(mn[j])); r.cullMax[j] = (float)(mx[j] + 1e-6 * std::fabs(mx[j])); }
+    r.cullMin[3] = (float)(k0 * up) + 1e-30f; r.cullMax[3] = (float)(k1 * up); r.cullK2 = (float)(k2 * up);
     r.cullOk = 1;
 }
 
@@ -193,7 +241,7 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
         std::memset(&r, 0, sizeof(r));
         std::memcpy(r.invWorld, o.invWorld, 64); std::memcpy(r.world, o.world, 64);
         r.meshStart = (int)A.objMesh.size(); r.meshCount = (int)o.meshes.size();
-        object_cull_box(o, meshes, r);
+        object_cull_box(o, meshes, r, cullSafety);
         A.objMesh.insert(A.objMesh.end(), o.meshes.begin(), o.meshes.end());
         A.objects.push_back(r);
     }

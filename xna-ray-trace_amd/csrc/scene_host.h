@@ -35,6 +35,7 @@ struct HostScene {
     FlatTree sceneTree;
     SceneArrays arrays;
     bool built = false;
+    double cullSafety = 2.0;   // factor S of the object pre-cull margin (scene_host.cpp); tests lower it to see the bound bite
 
     int add_mesh(const float *v, const float *n, const float *uv, const float *sn, const float *color, int ntri,
                  const xrt_material *m, const float bbox[6], std::string &err);

@@ -252,6 +252,37 @@ XRT_HD void merge_mesh_result(Lane &L, SC &C) {
     }
 }
 
+// World-space object pre-cull (ObjRec).  BoundingBox.Intersects of the world ray against the object's world
+// hull enlarged by m(|o|), one axis at a time so that few registers are live: the margin grows with the square of the
+// origin's distance from the world origin, which is how the cancellation in OSM:358-364 (Transform(o + d) - Transform(o))
+// bends the reference's object-space ray.  Same decisions as `slab` for a ray without NaNs (the early-outs collapse into
+// the final comparison: tmin only grows, tmax only shrinks).  W = RayPre or its LDS proxy (component access by axis).
+XRT_HD void ray_axis(const RayPre &w, int k, float &o, float &d, float &inv) {
+    o = k == 0 ? w.o.x : (k == 1 ? w.o.y : w.o.z); d = k == 0 ? w.d.x : (k == 1 ? w.d.y : w.d.z); inv = k == 0 ? w.inv.x : (k == 1 ? w.inv.y : w.inv.z);
+}
+template <class W>
+XRT_HD bool precull_hit(const W &w, const ObjRec &ob) {
+    float ox, oy, oz, dd, ii;
+    ray_axis(w, 0, ox, dd, ii); ray_axis(w, 1, oy, dd, ii); ray_axis(w, 2, oz, dd, ii);
+    const float r = (fabsf(ox) + fabsf(oy)) + fabsf(oz);   // >= |o|
+    const float m = cull_margin(ob, r);
+    if (!(m <= 1.0e30f)) return true;   // an overflowing or NaN margin: no cull
+    float tmin = 0.0f, tmax = FLT_MAX;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float o, d, inv;
+        ray_axis(w, k, o, d, inv);
+        const float lo = ob.cullMin[k] - m, hi = ob.cullMax[k] + m;
+        if (fabsf(d) < 1e-06f) ok = ok && !(o < lo || o > hi);
+        else {
+            const float t1 = ((d < 0.0f ? hi : lo) - o) * inv, t2 = ((d < 0.0f ? lo : hi) - o) * inv;
+            tmin = fmaxf(tmin, t1); tmax = fminf(tmax, t2);
+        }
+    }
+    return ok && !(tmin > tmax);
+}
+
 template <class Stack, class SC>
 XRT_HD void advance_scene(Lane &L, SC &C, const SceneView &S, Stack &stk) {
     if (L.mfound) {   // a mesh query ended with a hit since the last scene step (finish_mesh_query defers the merge to here)
@@ -275,13 +306,8 @@ XRT_HD void advance_scene(Lane &L, SC &C, const SceneView &S, Stack &stk) {
         while (C.sRef < C.sRefEnd) {   // OSM:341-364: next body of the current leaf, world -> object space
             const int o = S.srefs[C.sRef++];
             const ObjRec &ob = S.objects[o];
+            if (ob.cullOk && !L.weird && !precull_hit(C.w, ob)) continue;   // conservative world-space reject: the visit would end at MESH:34-39 for every mesh
             const RayPre w = C.w;
-            if (ob.cullOk && !L.weird) {   // conservative world-space reject (xrt_core.h ObjRec): the visit would end at MESH:34-39 for every mesh
-                float kc;
-                const v3 cmn = mk(ob.cullMin[0], ob.cullMin[1], ob.cullMin[2]), cmx = mk(ob.cullMax[0], ob.cullMax[1], ob.cullMax[2]);
-                const bool hitBox = (w.par == 0) ? slab_fast(w, dir_mask(w.d), cmn, cmx, kc) : slab(w, cmn.x, cmn.y, cmn.z, cmx.x, cmx.y, cmx.z, kc);
-                if (!hitBox) continue;
-            }
             C.obj = o;
             v3 rayDirPosition = add(w.o, w.d);                      // OSM:358
             v3 v1 = transform(w.o, ob.invWorld);                    // OSM:360

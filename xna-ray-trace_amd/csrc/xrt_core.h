@@ -79,11 +79,17 @@ struct ObjRec {         // 176 B
     float world[16];    // SO:193
     int   meshStart;    // into objMesh[]
     int   meshCount;
-    int   cullOk;       // cullMin/cullMax are valid (well-conditioned, finite transform)
-    int   pad0;
-    float cullMin[4];   // world-space box that contains the image of every mesh AABB of the object, enlarged by 1e-3 of
-    float cullMax[4];   // its size: a world ray that misses it cannot pass MESH:34-39 for any mesh
+    int   cullOk;       // the pre-cull record below is valid (finite, invertible transform)
+    float cullK2;
+    // World-space pre-cull (DESIGN.md §3 "Object pre-cull": the bound and its proof).  cullMin/cullMax[0..2] = the
+    // axis-aligned hull of the object's mesh AABBs mapped to world space (exact image, evaluated in double).  A world ray
+    // with |origin| = r that misses this box enlarged by  m(r) = cullMin[3] + cullMax[3] * r + cullK2 * r * r  cannot pass
+    // MESH:34-39 for any mesh of the object in the reference's binary32 arithmetic (OSM:358-364 transform + slab test).
+    float cullMin[4];
+    float cullMax[4];
 };
+// m(r) of ObjRec; r = Euclidean norm of the world-space ray origin (any upper bound of it is as good).
+XRT_HD float cull_margin(const ObjRec &ob, float r) { return ob.cullMin[3] + (ob.cullMax[3] + ob.cullK2 * r) * r; }
 
 struct MaterialRec {    // 32 B (MAT:234-268)
     float reflectiveness;
