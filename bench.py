@@ -4,8 +4,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5|C5_1spp|H100k] [--scale S]
 
 One step = one frame of the workload: every pixel's CastRay tree (closest-hit, shadow and reflection
-queries).  Default workload is BASELINE.json configs[1] (C2: Free_crate mesh, 1920x1080, depth 3, 1 spp);
-the other configs are reported as short side measurements in "other_configs" at N=1.
+queries).  Default workload is the configuration BASELINE.json quotes its target on and which fits one GPU:
+C5 = the 1M-triangle mesh at 1920x1080, depth 3, 16 sub-rays per pixel; C2 / C3 / C4 are reported as short side
+measurements in "other_configs" at N=1.  The `roofline` block carries three fractions of the dominant kernel
+(k_intersect) -- reference-algorithm bytes, measured HBM traffic and VALU issue (the latter two from the
+committed rocprofv3 PMC passes of THIS build, profiles/pmc_k_intersect.json, divided by launch durations measured live
+with HIP events) -- and names as `bound` whichever physical limit is closest.
 For N > 1 the driver starts one process per GPU (torch.distributed.run); the frame is sharded by 64x8 image
 tiles (total work fixed -> "strong" scaling), each rank renders its tiles from its own scene replica, and the
 per-frame exchange step is one RCCL gather of the tile buffers onto rank 0 followed by a de-tile kernel.
@@ -40,6 +44,32 @@ WORKLOADS = {
     "G2": "G2: the reference's content (monkey, torus, sphere, cube, textured ground with the content project's parameters), 1280x720, MaxReflections 4, two lights",
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# VALU issue peak: 256 CUs x 4 SIMD-32 x 32 lanes per cycle x 2.4 GHz (MI355X_MICROARCH.md: a wave64 VALU instruction issues over
+# 2 cycles on a SIMD-32 with >= 2 waves resident, chip table "Max clock 2400 MHz") = 78.6 T lane-operations per second
+# (= the 157.3 TFLOP/s vector peak, which counts a fused multiply-add as two; this path is built with contraction off)
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+KERNEL_SOURCES = ("kernels.hip", "kernels.h", "traverse.h", "xrt_core.h")
+
+
+def build_id():
+    """Hash of the sources the traversal kernel is compiled from: PMC figures are only quoted for the build they were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "xna-ray-trace_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(config):
+    """Per-launch PMC averages of k_intersect for `config` (tools/pmc_collect.py, separate rocprofv3 --pmc passes), or None
+    when the committed file was taken on another build of the kernel."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_intersect.json")))
+    except Exception:
+        return None
+    if pmc.get("build_id") != build_id():
+        return None
+    return pmc.get("configs", {}).get(config)
 
 
 def intersect_bytes(st):
@@ -199,6 +229,44 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
     return res, spec
 
 
+def time_host_output(tracer, spec, steps, warmup):
+    """The seam the north star names ends in the host's Color[] (CurrentTarget.SetData, RT:122-123): the same frames through
+    xrt_render_begin / _end into two page-locked host buffers, the device-to-host copy of frame i under the rendering of
+    frame i+1.  PCIe-inclusive; reported beside `value`, never as `value`."""
+    n = spec.width * spec.height
+    lib = xrt.abi.lib()
+    bufs = [np.zeros(n, dtype=np.uint32) for _ in range(2)]
+    for b in bufs:
+        xrt.abi.check(lib.xrt_host_register(C.c_void_p(b.ctypes.data), b.nbytes))
+    try:
+        fr = [tracer.PrepareHost(b) for b in bufs]
+        open_frames = []
+
+        def frame(i):
+            open_frames.append((fr[i % 2].begin(), i))
+            while len(open_frames) >= 2:
+                t, j = open_frames.pop(0)
+                fr[j % 2].end(t)
+
+        def drain():
+            while open_frames:
+                t, j = open_frames.pop(0)
+                fr[j % 2].end(t)
+        for i in range(warmup):
+            frame(i)
+        drain()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            frame(i)
+        drain()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / max(steps, 1)
+    finally:
+        for b in bufs:
+            lib.xrt_host_unregister(C.c_void_p(b.ctypes.data))
+
+
 def cpu_baseline(spec, budget_s=12.0):
     """The CPU oracle (C++ restatement of the reference's C# path, kind "port") on the host cores, rank 0 at
     N=1 only, on a bounded sample of the same workload (about `budget_s` seconds of single-thread work): centre
@@ -207,9 +275,9 @@ def cpu_baseline(spec, budget_s=12.0):
     o = orc.OracleScene(spec)
     H = spec.height
     t0 = time.perf_counter()
-    o.render(nthreads=1, rows=(H // 2 - 4, H // 2 + 4), want_float=False)   # probe: 8 centre rows
+    o.render(nthreads=1, rows=(H // 2 - 2, H // 2 + 2), want_float=False)   # probe: 4 centre rows
     probe = max(time.perf_counter() - t0, 1e-4)
-    rows = int(min(H, max(8, 8 * budget_s / probe)))
+    rows = int(min(H, max(4, 4 * budget_s / probe)))
     r0 = max(0, H // 2 - rows // 2)
     reps, rays, dt = 0, 0, 0.0
     t0 = time.perf_counter()
@@ -228,9 +296,51 @@ def cpu_baseline(spec, budget_s=12.0):
         rays_m += stm["rays_closest"] + stm["rays_shadow"]
     dtm = time.perf_counter() - t0
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": "rows %d..%d of the %dx%d frame x%d (%d rays, %.1f s): oracle/ (C++ restatement of the C# path), single thread as the shipped reference (RayTracer.cs:99)"
-                      % (r0, r0 + rows, spec.width, H, reps, rays, dt),
+            "sample": "rows %d..%d of the %dx%d frame x%d (%d rays, %.1f s) of %s: oracle/ (C++ restatement of the C# path), single thread as the shipped reference (RayTracer.cs:99)"
+                      % (r0, r0 + rows, spec.width, H, reps, rays, dt, spec.name),
             "value_all_cores": round(rays_m / dtm / 1e6, 4), "cores_all": nt}
+
+
+def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_frame, serial=None):
+    """Three fractions for the dominant kernel over the same live launch time:
+      algorithmic  the REFERENCE algorithm's bytes (un-pruned node / reference / triangle counts) / time / 8 TB/s -- what the
+                   north star's target is quoted in; the GPU prunes and caches, so this is an equivalent rate, not a physical one (may exceed 1);
+      hbm          HBM bytes the launch really moved (rocprofv3 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) / time / 8 TB/s;
+      valu         VALU lane-operations the launch really executed (SQ_THREAD_CYCLES_VALU) / time / 78.6 T lane-op/s, and the
+                   instruction-issue slots they occupied (SQ_INSTS_VALU x 64 lanes).
+    `bound` names the physical limit the kernel is closest to; achieved / peak / unit / frac are that limit's."""
+    t = ms_per_launch * 1e-3
+    alg = alg_bytes_per_launch / t / 1e9 if t > 0 else 0.0
+    pmc = load_pmc(config)
+    fr = {"algorithmic": {"achieved": round(alg, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / HBM_PEAK_GBS, 4),
+                          "bytes_per_launch": int(alg_bytes_per_launch), "what": "reference-algorithm bytes (SURVEY 8d), an equivalent rate: may exceed 1"}}
+    traffic = None
+    bound, top = "unmeasured (no PMC pass of this kernel build in profiles/pmc_k_intersect.json)", None
+    if pmc and t > 0:
+        traffic = int((2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024)
+        hbm = traffic / t / 1e9
+        useful = pmc["SQ_THREAD_CYCLES_VALU"] / t / 1e12
+        issue = pmc["SQ_INSTS_VALU"] * 64.0 / t / 1e12
+        fr["hbm"] = {"achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4), "bytes_per_launch": traffic}
+        fr["valu"] = {"achieved": round(useful, 2), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlane-op/s", "frac": round(useful / VALU_PEAK_TLANEOPS, 4),
+                      "issue_frac": round(issue / VALU_PEAK_TLANEOPS, 4), "lane_utilisation": round(pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_INSTS_VALU"] * 64.0), 3),
+                      "valu_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]),
+                      "waves_waiting_frac": round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 3) if pmc.get("SQ_WAVE_CYCLES") else None}
+        bound = "valu" if fr["valu"]["issue_frac"] >= fr["hbm"]["frac"] else "hbm"
+        top = fr[bound]
+    out = {"bound": bound, "kernel": "k_intersect",
+           "achieved": top["achieved"] if top else None, "peak": top["peak"] if top else None, "unit": top["unit"] if top else None,
+           "frac": (top["issue_frac"] if bound == "valu" else top["frac"]) if top else None,
+           "traffic": traffic, "ms_per_launch": round(ms_per_launch, 5), "launches_per_frame": launches_per_frame, "fractions": fr,
+           "pmc_build_id": build_id() if pmc else None,
+           "note": "branchy scalar fp32 traversal, scene resident in the 256 MiB Infinity Cache: not HBM-bound. `frac` is the named bound's "
+                   "(valu: VALU instruction-issue slots used, of which fractions.valu.frac did useful lane work); durations = HIP events on "
+                   "the launches of the timed region; PMC = rocprofv3 passes of this build (profiles/), per launch"}
+    if pmc:
+        out["pmc_ms_per_launch"] = pmc.get("ms_per_launch")
+    if serial:
+        out["serialised"] = serial
+    return out
 
 
 def main():
@@ -238,10 +348,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C2", choices=list(WORKLOADS))
+    ap.add_argument("--config", default="C5", choices=list(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the image (debug only; invalid as a benchmark)")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements of the other configs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-output (PCIe-inclusive) timing")
     args = ap.parse_args()
 
     rank, local_rank, world = xrt.dist.env_rank_world()
@@ -280,61 +391,69 @@ def main():
 
     if rank == 0:
         st = res["stats"]
-        # roofline of the dominant kernel (k_intersect), this rank: algorithmic bytes per launch / mean launch time
+        metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        # roofline of the dominant kernel (k_intersect), this rank: per launch over the timed region
         launches = max(res["launches"], 1)
         bytes_per_launch = intersect_bytes(st) * args.steps / launches
         ms_per_launch = res["ms_intersect"] / launches
-        achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
-        traffic = None   # HBM bytes per k_intersect launch from the committed PMC run of this command (profiles/)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final", "pmc_hbm_traffic.json")))
-            traffic = pmc.get(args.config, {}).get("traffic_bytes_per_launch") if world == 1 else None
-        except Exception:
-            traffic = None
-        line = {
-            "metric": ("Mrays/sec (primary+shadow+reflection queries), %dx%d" % (res["width"], res["height"])) if args.scale == 1.0 else "Mrays/sec (scaled image, not a benchmark)",
-            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(seconds / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.config], "width": res["width"], "height": res["height"], "triangles": res["tris"],
-                       "instances": res["instances"], "rays_per_frame": int(rays_frame), "parallelism": "image tiles 64x8 round-robin x%d" % world,
-                       "scene_build_s": round(res["build_s"], 3)},
-            "roofline": {"bound": "hbm", "kernel": "k_intersect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(bytes_per_launch), "ms_per_launch": round(ms_per_launch, 5),
-                         "launches_per_frame": launches // max(args.steps, 1),
-                         "note": "achieved = the REFERENCE algorithm's bytes (SURVEY 8d) / measured launch time; traffic = measured HBM bytes per launch (rocprofv3 2*FETCH_SIZE+WRITE_SIZE, profiles/r01_final/pmc_hbm_traffic.json): the scene fits the 256 MiB Infinity Cache and the GPU prunes, so traffic << achieved bytes"},
-        }
+        serial = None
         if res.get("overlapped"):
             l_s = max(res["serial_launches"], 1)
             ms_l = res["serial_ms_intersect"] / l_s
             ach_s = intersect_bytes(st) * res["serial_steps"] / l_s / (ms_l * 1e-3) / 1e9 if ms_l > 0 else 0.0
-            line["roofline"]["note"] += "; the timed frames overlapped pairwise on two streams, so ms_per_launch above includes time shared with the other frame: `serialised` is the same launch with the GPU to itself"
-            line["roofline"]["serialised"] = {"ms_per_launch": round(ms_l, 5), "achieved": round(ach_s, 2), "frac": round(ach_s / HBM_PEAK_GBS, 4),
-                                              "ms_per_step": round(res["serial_seconds"] / res["serial_steps"] * 1e3, 4)}
+            serial = {"what": "the timed frames overlapped pairwise on two streams, so ms_per_launch includes time shared with the other frame; this is the same launch with the GPU to itself",
+                      "ms_per_launch": round(ms_l, 5), "algorithmic_achieved": round(ach_s, 2), "ms_per_step": round(res["serial_seconds"] / res["serial_steps"] * 1e3, 4)}
+        line = {
+            "metric": metric if args.scale == 1.0 else "Mrays/sec (scaled image, not a benchmark)",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(seconds / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.config], "width": res["width"], "height": res["height"], "triangles": res["tris"],
+                       "instances": res["instances"], "rays_per_frame": int(rays_frame),
+                       "rays_closest_per_frame": int(st["rays_closest"]), "rays_shadow_per_frame": int(st["rays_shadow"]),
+                       "parallelism": "image tiles 64x8 round-robin x%d" % world, "scene_build_s": round(res["build_s"], 3)},
+            "roofline": roofline_block(args.config if world == 1 else "(N > 1: no PMC pass)", bytes_per_launch, ms_per_launch, launches // max(args.steps, 1), serial),
+        }
+        if world == 1 and not args.no_host and args.scale == 1.0:
+            try:
+                _, tracer_h = xrt.configs.build_product(spec, device=local_rank)
+                hs = time_host_output(tracer_h, spec, max(2, min(args.steps, 10)), 2)
+                line["ms_per_step_host_output"] = round(hs * 1e3, 4)
+                line["host_output"] = {"what": "xrt_render_begin/_end into two page-locked host Color[] buffers (RT:122-123), D2H of frame i under frame i+1; PCIe-inclusive, never `value`",
+                                       "Mrays_per_s": round(rays_frame / hs / 1e6, 2)}
+                del tracer_h
+            except Exception as e:   # a side measurement must not take the headline down
+                line["host_output"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(spec)
         if world == 1 and not args.no_extra and args.scale == 1.0:
             other = {}
-            for name, k in (("C3", 5), ("C5_1spp", 3)):
+            for name, k in (("C2", 20), ("C3", 5), ("C4", 3)):
                 if name == args.config:
                     continue
                 try:
                     r2, _ = run_config(name, 1.0, k, 2, 0, local_rank, 1)
                     # per-launch figures from the serialised pass when the timed frames overlapped
                     ms_i, l2, kk = (r2["serial_ms_intersect"], max(r2["serial_launches"], 1), r2["serial_steps"]) if r2["overlapped"] else (r2["ms_intersect"], max(r2["launches"], 1), k)
-                    ach = intersect_bytes(r2["stats"]) * kk / l2 / (ms_i / l2 * 1e-3) / 1e9
+                    rb = roofline_block(name, intersect_bytes(r2["stats"]) * kk / l2, ms_i / l2, l2 // max(kk, 1))
                     other[name] = {"workload": WORKLOADS[name], "Mrays_per_s": round(r2["rays"] * k / r2["seconds"] / 1e6, 2),
                                    "ms_per_step": round(r2["seconds"] / k * 1e3, 3), "rays_per_frame": int(r2["rays"]),
-                                   "frames_overlap": bool(r2["overlapped"]),
-                                   "ms_per_launch": round(ms_i / l2, 4), "intersect_GBps_algorithmic": round(ach, 1), "roofline_frac": round(ach / HBM_PEAK_GBS, 4),
-                                   "scene_build_s": round(r2["build_s"], 2)}
+                                   "frames_overlap": bool(r2["overlapped"]), "ms_per_launch": round(ms_i / l2, 4),
+                                   "bound": rb["bound"], "frac": rb["frac"], "fractions": rb["fractions"], "scene_build_s": round(r2["build_s"], 2)}
                     if r2["overlapped"]:
                         other[name]["ms_per_step_serialised"] = round(r2["serial_seconds"] / kk * 1e3, 3)
                 except Exception as e:   # a side measurement must not take the headline down
                     other[name] = {"error": str(e)[:200]}
             line["other_configs"] = other
         print(json.dumps(line))
+        try:   # per-run metrics file: the line plus the frame's accounting
+            mdir = os.environ.get("XRT_METRICS_DIR", os.path.join(ROOT, "gpurun_out"))
+            os.makedirs(mdir, exist_ok=True)
+            with open(os.path.join(mdir, "bench_metrics_%s_n%d.json" % (args.config, world)), "w") as f:
+                json.dump({"line": line, "frame_stats": {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in st.items()},
+                           "argv": sys.argv[1:], "kernel_build_id": build_id(), "time": time.strftime("%Y-%m-%dT%H:%M:%S")}, f, indent=1)
+        except Exception:
+            pass
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -39,6 +39,8 @@ namespace RayTraceProject.Native
     public struct XrtRenderOpts
     {
         public int maxReflections, useMultisampling, multisampleQuality, addressMode, filtering, shardRank, shardCount, collectStats;
+        public int nGpus;                          // > 1: the library spreads the frame's tiles over that many devices and gathers them with RCCL
+        public int reserved0, reserved1, reserved2;   // zero
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -71,6 +73,13 @@ namespace RayTraceProject.Native
         [DllImport(Lib)] public static extern int xrt_render_device_begin(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,
                                                                             ref XrtRenderOpts opts, IntPtr dRgbaOut, IntPtr stream, out int ticket);
         [DllImport(Lib)] public static extern int xrt_render_device_end(IntPtr scene, int ticket, IntPtr statsOut);
+        // pipelined form with the frame ending in the host's Color[] (RenderAsync + CurrentTarget.SetData, RayTracer.cs:59-79,122-123):
+        // pin renderTargetData (GCHandle.Alloc(.., GCHandleType.Pinned)) and xrt_host_register it once; up to two tickets open
+        [DllImport(Lib)] public static extern int xrt_render_begin(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,
+                                                                     ref XrtRenderOpts opts, IntPtr rgbaOut, out int ticket);
+        [DllImport(Lib)] public static extern int xrt_render_end(IntPtr scene, int ticket, IntPtr statsOut);
+        [DllImport(Lib)] public static extern int xrt_host_register(IntPtr hostPtr, ulong bytes);
+        [DllImport(Lib)] public static extern int xrt_host_unregister(IntPtr hostPtr);
         [DllImport(Lib)] public static extern float xrt_progress(IntPtr scene);
 
         // error convention of the reference: InvalidOperationException when busy (RayTracer.cs:26-27,62-63),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define XRT_VERSION 100
+#define XRT_VERSION 200
 
 /* error codes (C# shim: BUSY -> InvalidOperationException (RT:26-27,62-63),
  * INVALID_ARG -> ArgumentException (SO:123-124, MAT:85,97)) */
@@ -49,6 +49,8 @@ extern "C" {
 #define XRT_ADDRESS_CLAMP    0
 #define XRT_ADDRESS_WRAP     1
 #define XRT_ADDRESS_MIRROR   2
+
+#define XRT_MAX_LIGHTS        32   /* more lights per frame: XRT_E_INVALID_ARG */
 
 #define XRT_LIGHT_SPOT         0   /* SPOT: IsPositionable == true  */
 #define XRT_LIGHT_DIRECTIONAL  1   /* DIR:  IsPositionable == false */
@@ -121,16 +123,24 @@ typedef struct xrt_light {
     float   decay_exponent;   /* SPOT:33, default 1.3f */
 } xrt_light;
 
-/* The RayTracer properties a frame reads (RT:19-41) + the image-tile shard of this process. */
+/* The RayTracer properties a frame reads (RT:19-41) + how the frame is spread over GPUs. */
 typedef struct xrt_render_opts {
     int32_t max_reflections;      /* RT:33  */
     int32_t use_multisampling;    /* RT:40, XRT_MS_* */
     int32_t multisample_quality;  /* RT:41  */
     int32_t address_mode;         /* RT:37, XRT_ADDRESS_* */
     int32_t filtering;            /* RT:36, XRT_FILTER_*  */
-    int32_t shard_rank;           /* image-tile shard: this process renders tiles t with t % shard_count == shard_rank */
+    int32_t shard_rank;           /* one process per GPU: this process renders tiles t with t % shard_count == shard_rank */
     int32_t shard_count;          /* 0 or 1 = whole frame */
     int32_t collect_stats;        /* 1: also run the (untimed) reference-work counting pass */
+    /* One process, several GPUs -- the drop-in for the C# host, whose RenderInternal is ONE call on ONE thread
+     * (RT:103-126).  0 or 1: the scene's device only.  N > 1: the frame's 64x8 tiles are dealt round-robin to devices
+     * d, d+1, .. d+N-1 (d = the scene's device; the scene is replicated on first use), every device renders its
+     * tiles, one grouped RCCL send/recv over xGMI gathers the tile buffers on device d, a de-tile kernel writes the
+     * W*H frame there.  Needs N visible devices (XRT_E_NO_DEVICE) and shard_count <= 1 (XRT_E_INVALID_ARG); an RCCL
+     * failure is XRT_E_RCCL. */
+    int32_t n_gpus;
+    int32_t reserved[3];          /* zero */
 } xrt_render_opts;
 
 /* Exact work counters of the REFERENCE algorithm for the rays of one call and the
@@ -204,7 +214,11 @@ int xrt_scene_get_tree(const xrt_scene *scene, int32_t mesh_id, xrt_node_info *n
 
 /* ---- seam 1: ISpatialManager.GetRayIntersection (ISM:15 = OSM:312-455), batched --------------
  * ignore_object (nullable, n entries) is the dead `Mesh ignoreObject` parameter (OSM:343 compares a
- * Mesh with an ISpatialBody and can never be equal); it is accepted and ignored. Host buffers. */
+ * Mesh with an ISpatialBody and can never be equal); it is accepted and ignored. Host buffers.
+ * Re-entrant like the reference's (its N render threads call it concurrently, RT:105-113): concurrent
+ * seam-1 calls on one scene are serialised inside the library and every caller gets its own answers.
+ * They may also run while a begin/end ticket is open, except with stats_out (the counters are shared
+ * with the frames' counting pass): XRT_E_BUSY.  The scene must not be rebuilt or destroyed meanwhile. */
 int xrt_scene_intersect(xrt_scene *scene, const xrt_ray *rays, const int32_t *ignore_object,
                         int64_t n, xrt_hit *hits_out, xrt_stats *stats_out /* nullable */);
 
@@ -221,11 +235,26 @@ int xrt_mesh_intersect(xrt_scene *scene, int32_t mesh_id, const xrt_ray *rays, i
 /* ---- seam 2: RayTracer.RenderInternal (RT:103-126) / RenderInternalWithMultisampling
  *      (RT:128-168) -------------------------------------------------------------------------------
  * Fills rgba_out[y*W + x] with the packed XNA Color (R in the low byte, RT:425). Blocking.
- * rgb_f32_out (nullable, W*H*3) receives the iteration-0 colorVector before packing (RT:705/726).
+ * rgb_f32_out (nullable, W*H*3) receives the iteration-0 colorVector before packing (RT:705/726); it exists only
+ * with XRT_MS_OFF (the supersampled modes average PACKED colours, RT:309): otherwise XRT_E_UNSUPPORTED.
  * A second concurrent call on the same scene returns XRT_E_BUSY (RT:62-63). */
 int xrt_render(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights, int32_t n_lights,
                const xrt_render_opts *opts, uint32_t *rgba_out, float *rgb_f32_out,
                xrt_stats *stats_out /* nullable */);
+
+/* Pipelined form of xrt_render -- RenderAsync / RenderCompleted (RT:59-79, 431-437) with the frame still ending in the
+ * host's Color[] (CurrentTarget.SetData, RT:122-123).  _begin enqueues the frame and its device-to-host copy and returns
+ * a ticket; _end waits for both and fills stats_out (may be NULL).  Up to two frames may be open (tickets are shared with
+ * xrt_render_device_begin), so the copy of frame i runs under the rendering of frame i+1.  rgba_out must stay valid
+ * until _end; the copy overlaps only if the buffer is page-locked: xrt_host_register it once (the C# host pins its
+ * renderTargetData with GCHandle first), otherwise the runtime stages it. */
+int xrt_render_begin(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights, int32_t n_lights,
+                     const xrt_render_opts *opts, uint32_t *rgba_out, int32_t *ticket_out);
+int xrt_render_end(xrt_scene *scene, int32_t ticket, xrt_stats *stats_out);
+
+/* Page-lock / release a caller-owned host buffer for DMA (hipHostRegister): the host Color[] of xrt_render[_begin]. */
+int xrt_host_register(void *host_ptr, uint64_t bytes);
+int xrt_host_unregister(void *host_ptr);
 
 /* Same, writing to device memory. With opts->shard_count > 1 only this rank's tiles are rendered and
  * d_rgba_out receives them contiguously, tile after tile (see xrt_shard_layout); otherwise the full

@@ -388,6 +388,69 @@ def test_full_size_properties_c2(xrt):
     assert np.array_equal(out.cpu().numpy().view(np.uint32), a)
 
 
+def test_seam1_is_reentrant_across_host_threads(xrt, orc):
+    """ISpatialManager.GetRayIntersection is called from N render threads at once (RT:105-113): four host threads query one
+    scene with different ray sets, many times each, and every thread must get the hits of ITS rays (the staging buffers
+    and the queue word are shared inside the scene).  Also while a begin/end ticket is open -- where only a call
+    that wants stats answers BUSY."""
+    import torch
+    spec = xrt.configs.crate_grid_scene(160, 90)
+    scene, tracer = xrt.configs.build_product(spec)
+    o = orc.OracleScene(spec)
+    prim = o.primary_rays()
+    sets = [np.ascontiguousarray(prim[i::4][: 3000 + 257 * i]) for i in range(4)]
+    want = [o.intersect(r) for r in sets]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(12):
+                got = scene.IntersectBatch(sets[i])
+                bad = hits_equal(want[i], got)
+                if bad:
+                    errors.append((i, bad))
+                    return
+        except Exception as e:   # noqa: BLE001
+            errors.append((i, repr(e)))
+    out = torch.zeros(spec.width * spec.height, dtype=torch.int32, device="cuda")
+    fr = tracer.PrepareDevice(out.data_ptr())
+    ticket = fr.begin()
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    with pytest.raises(RuntimeError):
+        scene.IntersectBatch(sets[0], stats=True)        # shared counters: BUSY while the ticket is open
+    for t in threads:
+        t.join()
+    fr.end(ticket)
+    assert errors == []
+    hits, st = scene.IntersectBatch(sets[0], stats=True)   # and works again afterwards
+    assert hits_equal(want[0], hits) == {} and st["rays_closest"] == len(sets[0])
+
+
+def test_render_argument_limits(xrt):
+    """rgb_f32_out exists only without multisampling (RT:309 averages packed colours): UNSUPPORTED instead of stale memory;
+    more than XRT_MAX_LIGHTS lights: INVALID_ARG."""
+    spec = xrt.configs.config("C1", 0.25)
+    scene, tracer = xrt.configs.build_product(spec)
+    lib, abi = xrt.abi.lib(), xrt.abi
+    W, H = spec.width, spec.height
+    rgba = np.zeros(W * H, dtype=np.uint32)
+    f32 = np.zeros(W * H * 3, dtype=np.float32)
+    cam, lights, n, opts = tracer._camera_abi(), tracer._lights_abi(), len(tracer.Lights), tracer._opts_abi()
+    opts.use_multisampling = abi.MS_FIXED16
+    rc = lib.xrt_render(scene.handle, C.byref(cam), lights, n, C.byref(opts), rgba.ctypes.data_as(C.POINTER(C.c_uint32)),
+                        f32.ctypes.data_as(C.POINTER(C.c_float)), None)
+    assert rc == abi.XRT_E_UNSUPPORTED and b"rgb_f32_out" in lib.xrt_last_error()
+    opts.use_multisampling = abi.MS_OFF
+    many = (abi.xrt_light * 33)(*([lights[0]] * 33))
+    rc = lib.xrt_render(scene.handle, C.byref(cam), many, 33, C.byref(opts), rgba.ctypes.data_as(C.POINTER(C.c_uint32)), None, None)
+    assert rc == abi.XRT_E_INVALID_ARG and b"XRT_MAX_LIGHTS" in lib.xrt_last_error()
+    rc = lib.xrt_render(scene.handle, C.byref(cam), lights, n, C.byref(opts), rgba.ctypes.data_as(C.POINTER(C.c_uint32)),
+                        f32.ctypes.data_as(C.POINTER(C.c_float)), None)
+    assert rc == 0 and rgba.any()
+
+
 def test_device_pointer_intersect(xrt, orc):
     import torch
     spec = xrt.configs.heightfield_scene(160, 90, m=64)
@@ -656,6 +719,147 @@ def test_full_size_c3_c5_pipelined_frames_and_sampled_rows(xrt, name, rows):
     o_rgba, _, _ = orc.OracleScene(spec).render(nthreads=8, rows=rows, want_float=False)
     W = spec.width
     assert np.array_equal(want.reshape(-1, W)[rows[0]:rows[1]], o_rgba.reshape(-1, W)[rows[0]:rows[1]])
+
+
+@pytest.mark.parametrize("name,rows", [("C4", (1076, 1084)), ("C5", (598, 602))])
+def test_full_size_c4_c5_as_specified(xrt, name, rows):
+    """BASELINE configs[3] and [4] at their full sizes: C4 = the 64-instance grid at 3840x2160, C5 = the 999,698-triangle
+    heightfield at 1920x1080 with 16 sub-rays per pixel (XRT_MS_FIXED16), depth 3.  Too slow for a full oracle frame, so:
+    sampled rows bit-equal to the oracle's, idempotence, ray accounting (shards add up to the whole frame), and the 4- and
+    8-way image-tile shards rendered in turn, gathered and de-tiled == the unsharded frame."""
+    import torch
+    spec = xrt.configs.config(name)
+    assert (spec.width, spec.height) == ((3840, 2160) if name == "C4" else (1920, 1080))
+    assert name != "C5" or (spec.multisampling == xrt.abi.MS_FIXED16 and sum(m[0].ntri for m in spec.meshes) == 999698)
+    scene, tracer = xrt.configs.build_product(spec)
+    W, H = spec.width, spec.height
+    whole = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    st = dict(tracer.RenderDevice(whole.data_ptr()))
+    want = whole.cpu().numpy().view(np.uint32).copy()
+    samples = 16 if name == "C5" else 1
+    assert st["pixels"] == W * H and st["rays_closest"] >= W * H * samples and st["rays_shadow"] == st["shaded_hits"]
+    from oracle import oracle_py as orc
+    o_rgba, _, o_st = orc.OracleScene(spec).render(nthreads=16, rows=rows, want_float=False)
+    assert np.array_equal(want.reshape(H, W)[rows[0]:rows[1]], o_rgba.reshape(H, W)[rows[0]:rows[1]])
+    assert (want.reshape(H, W)[rows[0]:rows[1]] & 0xffffff).any() and o_st["rays_closest"] >= (rows[1] - rows[0]) * W * samples
+    again = torch.zeros_like(whole)
+    tracer.RenderDevice(again.data_ptr())
+    assert torch.equal(again, whole)
+    for world in (4, 8):
+        tx, ty, tpr = C.c_int32(), C.c_int32(), C.c_int32()
+        xrt.abi.lib().xrt_shard_layout(W, H, world, C.byref(tx), C.byref(ty), C.byref(tpr))
+        n = tpr.value * 512
+        gathered = torch.zeros(world * n, dtype=torch.int32, device="cuda")
+        acc = dict(rays_closest=0, rays_shadow=0, shaded_hits=0, pixels=0)
+        for r in range(world):
+            s_r = tracer.RenderDevice(gathered[r * n:(r + 1) * n].data_ptr(), shard_rank=r, shard_count=world)
+            for k in acc:
+                acc[k] += s_r[k]
+        for k in acc:
+            assert acc[k] == st[k], (world, k, acc[k], st[k])
+        out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+        xrt.abi.check(xrt.abi.lib().xrt_detile_device(W, H, world, C.c_void_p(gathered.data_ptr()), 0, C.c_void_p(out.data_ptr()), None))
+        torch.cuda.synchronize()
+        assert torch.equal(out, whole), world
+
+
+def test_in_library_multi_gpu(xrt, monkeypatch):
+    """xrt_render_opts.n_gpus: ONE call from ONE host thread (RT:103-126) spreads the frame's tiles over N devices, one grouped
+    RCCL send/recv gathers them on the scene's device, k_detile writes the frame.  On this one-GPU box: n_gpus = 1 is today's
+    path; asking for more devices than are visible is XRT_E_NO_DEVICE; with XRT_FAKE_GPUS=1 the N scene replicas live on
+    the one device and the exchange is RCCL send-to-self, which runs replica upload, the per-device host threads, the
+    shard parameters, the RCCL calls, the de-tile and the statistics for N = 2, 3, 8 -- for plain, 16-sub-ray, adaptive and
+    ray-tree frames, to host and to device memory, blocking and pipelined."""
+    import torch
+    spec = xrt.configs.crate_grid_scene(200, 120)
+    scene, tracer = xrt.configs.build_product(spec)
+    want = tracer.Render().copy()
+    st_want = dict(tracer.last_stats)
+    tracer.NumGpus = 1
+    assert np.array_equal(tracer.Render(), want)
+    ndev = torch.cuda.device_count()
+    tracer.NumGpus = ndev + 1
+    with pytest.raises(xrt.abi.XrtError) as e:
+        tracer.Render()
+    assert e.value.code == xrt.abi.XRT_E_NO_DEVICE
+    tracer.NumGpus = 2
+    with pytest.raises(ValueError):
+        xrt.abi.check(_render_with(xrt, scene, tracer, n_gpus=2, shard_count=2))   # the library shards the frame itself
+    tracer.NumGpus = 1
+    monkeypatch.setenv("XRT_FAKE_GPUS", "1")
+    keys = ("rays_closest", "rays_shadow", "hits_closest", "shaded_hits", "pixels")
+    for mode in ("plain", "ms16", "adaptive", "glass"):
+        s2 = xrt.configs.crate_grid_scene(200, 120) if mode != "glass" else glass_scene(xrt, 96, 64, 3)
+        if mode == "ms16":
+            s2.multisampling = xrt.abi.MS_FIXED16
+        if mode == "adaptive":
+            s2.multisampling, s2.multisample_quality = xrt.abi.MS_ADAPTIVE, 2
+        scene2, tracer2 = xrt.configs.build_product(s2)
+        ref = tracer2.Render().copy()
+        st_ref = dict(tracer2.last_stats)
+        for n in (2, 3, 8):
+            tracer2.NumGpus = n
+            got = tracer2.Render().copy()                                   # xrt_render: host Color[]
+            assert np.array_equal(got, ref), (mode, n)
+            for k in keys:
+                assert tracer2.last_stats[k] == st_ref[k], (mode, n, k)
+            d = torch.zeros(s2.width * s2.height, dtype=torch.int32, device="cuda")
+            tracer2.RenderDevice(d.data_ptr())                              # xrt_render_device
+            assert np.array_equal(d.cpu().numpy().view(np.uint32), ref), (mode, n)
+        # pipelined, two tickets open, to device and to host memory
+        tracer2.NumGpus = 2
+        outs = [torch.zeros(s2.width * s2.height, dtype=torch.int32, device="cuda") for _ in range(2)]
+        frs = [tracer2.PrepareDevice(o.data_ptr()) for o in outs]
+        t0, t1 = frs[0].begin(), frs[1].begin()
+        frs[0].end(t0); frs[1].end(t1)
+        for o in outs:
+            assert np.array_equal(o.cpu().numpy().view(np.uint32), ref), mode
+        hosts = [np.zeros(s2.width * s2.height, dtype=np.uint32) for _ in range(2)]
+        hfr = [tracer2.PrepareHost(h) for h in hosts]
+        t0, t1 = hfr[0].begin(), hfr[1].begin()
+        hfr[0].end(t0); hfr[1].end(t1)
+        for h in hosts:
+            assert np.array_equal(h, ref), mode
+        tracer2.NumGpus = 1
+    assert st_want["pixels"] == 200 * 120
+
+
+def _render_with(xrt, scene, tracer, n_gpus, shard_count):
+    cam, lights, n, opts = tracer._camera_abi(), tracer._lights_abi(), len(tracer.Lights), tracer._opts_abi()
+    opts.n_gpus, opts.shard_count = n_gpus, shard_count
+    out = np.zeros(tracer._target.Width * tracer._target.Height, dtype=np.uint32)
+    return xrt.abi.lib().xrt_render(scene.handle, C.byref(cam), lights, n, C.byref(opts), out.ctypes.data_as(C.POINTER(C.c_uint32)), None, None)
+
+
+def test_pipelined_host_output_frames(xrt):
+    """xrt_render_begin / xrt_render_end: RenderAsync with the frame ending in the host's Color[] (RT:122-123).  Two tickets
+    open, page-locked (xrt_host_register) and pageable buffers, equal to the blocking xrt_render; a third begin is BUSY."""
+    spec = xrt.configs.config("C3", 0.25)
+    scene, tracer = xrt.configs.build_product(spec)
+    want = tracer.Render().copy()
+    n = spec.width * spec.height
+    lib = xrt.abi.lib()
+    pinned = [np.zeros(n, dtype=np.uint32) for _ in range(2)]
+    for b in pinned:
+        xrt.abi.check(lib.xrt_host_register(C.c_void_p(b.ctypes.data), b.nbytes))
+    try:
+        for bufs in (pinned, [np.zeros(n, dtype=np.uint32) for _ in range(2)]):
+            fr = [tracer.PrepareHost(b) for b in bufs]
+            for rep in range(3):
+                t0 = fr[0].begin()
+                t1 = fr[1].begin()
+                with pytest.raises(RuntimeError):
+                    fr[0].begin()
+                st0 = fr[0].end(t0)
+                st1 = fr[1].end(t1)
+                assert np.array_equal(bufs[0], want) and np.array_equal(bufs[1], want)
+                assert st0["rays_closest"] == st1["rays_closest"] == tracer.last_stats["rays_closest"] > 0
+                bufs[0][:] = 0
+                bufs[1][:] = 0
+    finally:
+        for b in pinned:
+            xrt.abi.check(lib.xrt_host_unregister(C.c_void_p(b.ctypes.data)))
+    assert np.array_equal(tracer.Render(), want)
 
 
 def test_changing_frame_parameters_between_pipelined_frames(xrt):

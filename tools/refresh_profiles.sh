@@ -1,19 +1,30 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): refreshes the profile evidence under gpurun_out/final for the current build.
-#   1. rocprofv3 --kernel-trace --stats of the default `python3 bench.py` command (the bench line is kept next to it)
-#   2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of the bench of C2, C3 and C5_1spp -> HBM bytes per k_intersect launch
-# tools/pmc_traffic.py turns the counter CSVs into profiles/<round>/pmc_hbm_traffic.json.
+#   1. separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ set) of the bench of every config -> tools/pmc_collect.py ->
+#      profiles/pmc_k_intersect.json (stamped with the kernel sources' hash; bench.py's roofline block reads it)
+#   2. rocprofv3 --kernel-trace --stats of the default `python3 bench.py` command (the bench line is kept next to it)
+# Usage: tools/refresh_profiles.sh [configs...]   (default: C5 C3 C2 C4)
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/final
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py > $OUT/bench_under_rocprof.log 2>&1
-grep '^{"metric"' $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_line_under_rocprof.json
-for c in C2 C3 C5_1spp; do
-  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$c -- python3 $R/bench.py --config $c --no-extra --no-cpu --steps 10 --warmup 2 > $OUT/pmc_fetch_$c.log 2>&1
-  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$c -- python3 $R/bench.py --config $c --no-extra --no-cpu --steps 10 --warmup 2 > $OUT/pmc_write_$c.log 2>&1
+CFGS=${@:-C5 C3 C2 C4}
+SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU"
+for c in $CFGS; do
+  for pass in fetch write sq; do
+    case $pass in fetch) CTR="FETCH_SIZE";; write) CTR="WRITE_SIZE";; sq) CTR="$SQ";; esac
+    echo "== pmc $pass $c"
+    timeout -k 10 400 rocprofv3 --pmc $CTR --output-format csv -d $OUT/pmc_${pass}_$c -- python3 $R/bench.py --config $c --no-extra --no-cpu --no-host --steps 4 --warmup 1 > $OUT/pmc_${pass}_$c.log 2>&1
+  done
 done
-python3 $R/tools/pmc_traffic.py $OUT > $OUT/pmc_hbm_traffic.json
-cat $OUT/pmc_hbm_traffic.json
+python3 $R/tools/pmc_collect.py $OUT --out $OUT/pmc_k_intersect.json > /dev/null
+cp $OUT/pmc_k_intersect.json $R/profiles/pmc_k_intersect.json   # so that the bench below quotes it (same build)
+echo "== kernel trace of the default bench"
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py > $OUT/bench_under_rocprof.log 2>&1
+grep '^{"metric"' $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_line_under_rocprof.json
+# keep only the small summaries (gpurun merges at most 64 MiB back)
+find $OUT -name "*counter_collection.csv" -size +20M -delete
+find $OUT -name "*kernel_trace.csv" -size +20M -delete
+du -sh $OUT

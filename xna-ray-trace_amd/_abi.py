@@ -58,7 +58,7 @@ class xrt_light(C.Structure):
 class xrt_render_opts(C.Structure):
     _fields_ = [("max_reflections", C.c_int32), ("use_multisampling", C.c_int32), ("multisample_quality", C.c_int32),
                 ("address_mode", C.c_int32), ("filtering", C.c_int32), ("shard_rank", C.c_int32),
-                ("shard_count", C.c_int32), ("collect_stats", C.c_int32)]
+                ("shard_count", C.c_int32), ("collect_stats", C.c_int32), ("n_gpus", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class xrt_stats(C.Structure):
@@ -77,7 +77,8 @@ class xrt_node_info(C.Structure):
                 ("dfs_index", C.c_int32), ("depth", C.c_int32), ("first_ref", C.c_int32), ("reserved", C.c_int32)]
 
 
-assert C.sizeof(xrt_ray) == 32 and C.sizeof(xrt_hit) == 48
+assert C.sizeof(xrt_ray) == 32 and C.sizeof(xrt_hit) == 48 and C.sizeof(xrt_render_opts) == 48
+XRT_VERSION = 200
 
 # every symbol include/xrt.h declares: name -> (restype, argtypes)
 _P = C.POINTER
@@ -96,6 +97,10 @@ SYMBOLS = {
     "xrt_scene_intersect_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "xrt_mesh_intersect": (C.c_int, [C.c_void_p, C.c_int32, _P(xrt_ray), C.c_int64, _P(xrt_hit)]),
     "xrt_render": (C.c_int, [C.c_void_p, _P(xrt_camera), _P(xrt_light), C.c_int32, _P(xrt_render_opts), _P(C.c_uint32), _F, _P(xrt_stats)]),
+    "xrt_render_begin": (C.c_int, [C.c_void_p, _P(xrt_camera), _P(xrt_light), C.c_int32, _P(xrt_render_opts), _P(C.c_uint32), _P(C.c_int32)]),
+    "xrt_render_end": (C.c_int, [C.c_void_p, C.c_int32, _P(xrt_stats)]),
+    "xrt_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "xrt_host_unregister": (C.c_int, [C.c_void_p]),
     "xrt_render_device": (C.c_int, [C.c_void_p, _P(xrt_camera), _P(xrt_light), C.c_int32, _P(xrt_render_opts), C.c_void_p, C.c_void_p, _P(xrt_stats)]),
     "xrt_render_device_begin": (C.c_int, [C.c_void_p, _P(xrt_camera), _P(xrt_light), C.c_int32, _P(xrt_render_opts), C.c_void_p, C.c_void_p, _P(C.c_int32)]),
     "xrt_render_device_end": (C.c_int, [C.c_void_p, C.c_int32, _P(xrt_stats)]),

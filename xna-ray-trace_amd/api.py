@@ -356,6 +356,7 @@ class RayTracer:
         self.renderTargetData = None
         self.last_stats = None
         self.collect_stats = False
+        self.NumGpus = 1                # xrt_render_opts.n_gpus: one process, the frame's tiles dealt to this many devices
 
     @property
     def CurrentTarget(self):
@@ -391,6 +392,7 @@ class RayTracer:
         o.address_mode, o.filtering = int(self.AddressMode), int(self.TextureFiltering)
         o.shard_rank, o.shard_count = shard_rank, shard_count
         o.collect_stats = int(self.collect_stats)
+        o.n_gpus = int(self.NumGpus) if shard_count <= 1 else 0
         return o
 
     def _lights_abi(self):
@@ -461,6 +463,27 @@ class RayTracer:
             return self.last_stats
         frame.begin, frame.end = begin, end
         return frame
+
+    def PrepareHost(self, host_array):
+        """Pipelined host-output frames (xrt_render_begin / xrt_render_end): RenderAsync with the frame ending in the host's
+        Color[] (RT:122-123).  `host_array`: a uint32 numpy array of W*H elements, ideally registered with
+        xrt_host_register so that the device-to-host copy of frame i runs under the rendering of frame i+1."""
+        cam, opts, lights = self._camera_abi(), self._opts_abi(), self._lights_abi()
+        st, ticket, lib = abi.xrt_stats(), C.c_int32(0), abi.lib()
+        handle, n = self.CurrentScene.handle, len(self.Lights)
+        ptr = host_array.ctypes.data_as(C.POINTER(C.c_uint32))
+
+        def begin():
+            abi.check(lib.xrt_render_begin(handle, C.byref(cam), lights, n, C.byref(opts), ptr, C.byref(ticket)))
+            return ticket.value
+
+        def end(t):
+            abi.check(lib.xrt_render_end(handle, t, C.byref(st)))
+            self.last_stats = st.as_dict()
+            return self.last_stats
+        begin.keepalive = (cam, opts, lights, st, host_array)
+        begin.begin, begin.end = begin, end
+        return begin
 
     def GeneratePrimaryRays(self):
         """The rays of RT:410-421 for the whole target."""

@@ -10,11 +10,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/xrt.h"
 #include "kernels.h"
+#include "rccl_gather.h"
 #include "scene_host.h"
 
 using namespace xrt;
@@ -73,6 +78,7 @@ int upload(DevBuf<T> &b, const std::vector<T> &v) {
 struct xrt_scene {
     int device = -1;   // -1: host-only scene (inspection of the built trees; every compute call fails)
     HostScene hs;
+    const HostScene *host = &hs;   // what the frame code reads; a replica on another device points at its primary's
     // HBM-resident scene
     DevBuf<f4> blocks, refN, snodes, shade, leafNB;
     DevBuf<g3> refG;
@@ -160,10 +166,32 @@ struct xrt_scene {
     int tune[4] = {24, 16, 48, 32};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
     std::atomic<bool> busy{false};
     std::atomic<float> progress{0.0f};
+    // Seam 1 (xrt_scene_intersect / xrt_mesh_intersect / xrt_generate_primary_rays) is re-entrant like the reference's
+    // ISpatialManager.GetRayIntersection (ISM:15, called from N render threads, RT:105-113): the host-buffer calls share
+    // one staging area and are serialised by this mutex; every stream has its own work-queue word.
+    // In-library multi-GPU (xrt_render_opts.n_gpus): copies of the scene on devices device+1 .. (owned), the RCCL
+    // communicators, and per ticket the buffer the tile shards are gathered into.  XRT_FAKE_GPUS=1 (test boxes with one
+    // GPU): the replicas live on the scene's own device and the exchange is RCCL send-to-self.
+    std::vector<xrt_scene *> replicas;
+    RcclGather rccl;
+    bool fakeGpus = false;
+    DevBuf<uint32_t> gathered[2];    // primary: n * tiles_per_rank * 512 pixels, rank-major
+    DevBuf<uint32_t> tileOut[2];     // replica: its tiles of the frame in slot 0 / 1
+    DevBuf<uint32_t> frameOut[2];    // W*H frame of a host-output ticket
+    hipEvent_t tilesReady[2] = {nullptr, nullptr};   // replica (fake mode): its tiles are rendered
+    hipEvent_t tailDone[2] = {nullptr, nullptr};     // primary: gather + de-tile + host copy of the ticket are done
+    struct OpenFrame { int nGpus = 0; bool tail = false; } open[2];
+    std::mutex apiMutex;
+    std::unordered_map<hipStream_t, int> queueOfStream;
+    // development switches, read once at xrt_scene_create (never per frame)
+    bool noRectCull = false, oneStream = false, noFeedback = false;
 
     ~xrt_scene() {
+        for (xrt_scene *r : replicas) delete r;
+        replicas.clear();
         if (device >= 0) {
             (void)hipSetDevice(device);
+            for (int i = 0; i < 2; i++) { if (tilesReady[i]) (void)hipEventDestroy(tilesReady[i]); if (tailDone[i]) (void)hipEventDestroy(tailDone[i]); gathered[i].release(); tileOut[i].release(); frameOut[i].release(); }
             for (auto e : events) (void)hipEventDestroy(e);
             for (auto &f : frames) {
                 for (auto e : f.events) (void)hipEventDestroy(e);
@@ -199,7 +227,7 @@ bool in_flight(const xrt_scene *s) { return s->busy.load() || s->frames[0].pendi
 int need_device(xrt_scene *s, const char *fn) {
     if (!s) return fail(XRT_E_INVALID_ARG, "%s: null scene", fn);
     if (s->device < 0) return fail(XRT_E_NO_DEVICE, "%s: host-only scene (created with device -1); libxrt has no CPU execution path", fn);
-    if (!s->hs.built || !s->resident) return fail(XRT_E_NOT_BUILT, "%s: call xrt_scene_build first", fn);
+    if (!s->host->built || !s->resident) return fail(XRT_E_NOT_BUILT, "%s: call xrt_scene_build first", fn);
     HIPCHECK(hipSetDevice(s->device));
     return XRT_OK;
 }
@@ -259,7 +287,7 @@ LightRec make_light(const xrt_light &l) {
     return r;
 }
 
-int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g, const float *rootBox = nullptr /* min xyz, max xyz */) {
+int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g, const float *rootBox = nullptr /* min xyz, max xyz; null: no screen-rectangle cull */) {
     if (cam->vp_width <= 0 || cam->vp_height <= 0) return fail(XRT_E_INVALID_ARG, "viewport must be positive");
     float wv[16], wvp[16], ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     mat_multiply(ident, cam->view, wv);     // Matrix.Multiply(world = Identity, view)   (Viewport.Unproject, RT:415)
@@ -276,7 +304,7 @@ int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g
     g.cullX0 = 0; g.cullY0 = 0; g.cullX1 = g.width - 1; g.cullY1 = g.height - 1;
     g.cullSkipsRecord = 0;
     if (g.shardRank < 0 || g.shardRank >= g.shardCount) return fail(XRT_E_INVALID_ARG, "shard_rank out of range");
-    if (rootBox && !getenv("XRT_NO_RECT_CULL")) {
+    if (rootBox) {
         // Screen rectangle of the scene's root box.  A ray through pixel (x, y) that reaches the box at a point P has P
         // projecting onto (x, y); the box is convex, so with all eight corners in front of the eye every such pixel lies
         // inside the corners' bounding rectangle.  Evaluated in double from the same float matrices; used only when
@@ -324,12 +352,13 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const bool stats = true;   // the read-back is two small pinned copies; always taken
     xrt_scene::WorkBufs &W = F.w;
     if (!cam || !opts || (!lights && nLights > 0) || nLights < 0) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
+    if (nLights > XRT_MAX_LIGHTS) return fail(XRT_E_INVALID_ARG, "xrt_render: more than XRT_MAX_LIGHTS (%d) lights", XRT_MAX_LIGHTS);
     if (opts->max_reflections < 0 || opts->max_reflections > 64) return fail(XRT_E_INVALID_ARG, "max_reflections out of range");
     if (opts->address_mode < XRT_ADDRESS_CLAMP || opts->address_mode > XRT_ADDRESS_MIRROR)
         return fail(XRT_E_INVALID_ARG, "Value does not fall within the expected range: addressMode (MAT:85)");
     if (opts->filtering != XRT_FILTER_POINT && opts->filtering != XRT_FILTER_BILINEAR)
         return fail(XRT_E_INVALID_ARG, "Value does not fall within the expected range: filtering (MAT:97)");
-    const bool heap = s->hs.arrays.anyTransparent && opts->max_reflections > 0;   // RT:586-702: binary ray tree
+    const bool heap = s->host->arrays.anyTransparent && opts->max_reflections > 0;   // RT:586-702: binary ray tree
     if (heap && opts->max_reflections > 12)
         return fail(XRT_E_UNSUPPORTED, "Transparent materials with MaxReflections > 12 (a ray tree of more than 8191 nodes per pixel)");
     const int msMode = opts->use_multisampling;
@@ -339,12 +368,12 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     if (adaptive && (quality < 0 || quality > 6)) return fail(XRT_E_UNSUPPORTED, "MultisampleQuality above 6 (4^7 sub-quadrants per pixel)");
     RayGenParams g;
     float rootBox[6] = {0, 0, 0, 0, 0, 0};
-    const bool haveRoot = s->hs.arrays.snodes.size() >= 2;
+    const bool haveRoot = s->host->arrays.snodes.size() >= 2;
     if (haveRoot) {
-        const f4 lo = s->hs.arrays.snodes[0], hi = s->hs.arrays.snodes[1];
+        const f4 lo = s->host->arrays.snodes[0], hi = s->host->arrays.snodes[1];
         rootBox[0] = lo.x; rootBox[1] = lo.y; rootBox[2] = lo.z; rootBox[3] = hi.x; rootBox[4] = hi.y; rootBox[5] = hi.z;
     }
-    int rc = make_raygen(cam, opts, g, haveRoot ? rootBox : nullptr);
+    int rc = make_raygen(cam, opts, g, (haveRoot && !s->noRectCull) ? rootBox : nullptr);
     if (rc != XRT_OK) return rc;
     if (adaptive) g.samples = 4;
     g.cullSkipsRecord = heap ? 0 : 1;   // (k_compose_tree reads every root record)
@@ -372,6 +401,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const int P = (int)chunkPaths;
     size_t rayCap = (size_t)P;
     if (heap) { rayCap = (R < 20 && ((size_t)P << R) < (size_t)s->heapRayCap) ? ((size_t)P << R) : (size_t)s->heapRayCap; if (rayCap < (size_t)P) rayCap = (size_t)P; }
+    // shadow rays of one generation are counted in an int (rayCap <= 2^25, nL <= XRT_MAX_LIGHTS = 32: at most 2^30)
+    if ((unsigned long long)rayCap * (unsigned long long)(nL > 0 ? nL : 1) > (1ull << 30)) return fail(XRT_E_UNSUPPORTED, "frame too large: %zu rays x %d lights per generation", rayCap, nL);
     const size_t shadowCap = rayCap;   // hits of one generation (each emits nL shadow rays)
     const bool wantF32 = d_outF32 != nullptr && !adaptive && g.samples == 1;
     const bool fuseResolve = !adaptive && !heap && g.samples == 1;   // k_compose writes the framebuffer itself
@@ -402,7 +433,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         // frames in flight overlap on the GPU; everything else stays on the scene's one stream (measured on MI355X /
         // ROCm 7.2: enqueueing on a stream that has gone idle costs ~15 us a launch, on one that still has work ~4 us --
         // alternating two streams with 60-200 us frames makes the host the bottleneck).
-        if (fast && s->lastFrameMs >= s->overlapMinMs && !getenv("XRT_ONE_STREAM")) {
+        if (fast && s->lastFrameMs >= s->overlapMinMs && !s->oneStream) {
             if (!W.stream) HIPCHECK(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
             st = W.stream;
         } else st = s->stream;
@@ -415,7 +446,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         if (O.pending && O.w.lastStream != st && (!fast || !O.fast || remap)) HIPCHECK(hipEventSynchronize(O.fast ? O.events[1] : O.done));
         W.lastStream = st;
     }
-    if (fast && s->deepMeshes && !getenv("XRT_NO_FEEDBACK")) {
+    if (fast && s->deepMeshes && !s->noFeedback) {
         const size_t need = (size_t)(R + 1) * (size_t)P;
         if (s->costMapPaths != (size_t)P || s->costMap.cap < need) {   // new frame geometry: forget
             if ((rc = s->costMap.ensure(need))) return rc;
@@ -500,7 +531,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             C.nCap = (int)rayCap;
             { const HeavyArgs H = heavy_for(k); C.heavyIdx = H.list; C.nHeavy = H.count; }
             B.rays = W.shadowRays.p; B.hits = W.shadowHits.p; B.index = nullptr; B.nDev = hasShadow ? scnt + (k - 1) : nullptr; B.nMul = nL; B.n = 0;
-            B.nCap = (int)shadowCap * nL;
+            B.nCap = (int)((long long)shadowCap * nL);
             for (IntersectArgs *a : {&C, &B}) {
                 a->queue = q + k; a->mode = s->sceneMode; a->meshId = 0;
                 a->refillMin = s->tune[0]; a->nodeBurst = s->tune[1]; a->leafBurst = s->tune[2]; a->coopMax = s->tune[3]; a->firstBatch = s->firstBatch;
@@ -789,21 +820,223 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
     return XRT_OK;
 }
 
-int render_impl(xrt_scene *s, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts, uint32_t *d_out,
-                float *d_outF32, hipStream_t st, xrt_stats *stats) {
-    int rc = frame_begin(s, s->frames[0], cam, lights, nLights, opts, d_out, d_outF32, st);
-    if (rc != XRT_OK) return rc;
-    return frame_finish(s, s->frames[0], stats);
+// ---- in-library multi-GPU (xrt_render_opts.n_gpus) -----------------------------------------------------------------
+constexpr int XRT_MAX_GPUS = 64;
+
+int scene_upload(xrt_scene *scene);
+
+// Copies of the scene on devices device+1 .. device+n-1 (the scene's own device in the single-GPU test mode).
+int ensure_replicas(xrt_scene *s, int n) {
+    while ((int)s->replicas.size() < n - 1) {
+        const int i = (int)s->replicas.size() + 1;
+        std::unique_ptr<xrt_scene> r(new xrt_scene());
+        r->device = s->fakeGpus ? s->device : s->device + i;
+        r->host = s->host;
+        r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths;
+        for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
+        HIPCHECK(hipSetDevice(r->device));
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) r->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        HIPCHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+        int rc = scene_upload(r.get());
+        if (rc != XRT_OK) return rc;
+        s->replicas.push_back(r.release());
+    }
+    return hipSetDevice(s->device) == hipSuccess ? XRT_OK : fail(XRT_E_HIP, "hipSetDevice failed");
 }
 
+xrt_scene *rank_scene(xrt_scene *s, int i) { return i == 0 ? s : s->replicas[(size_t)i - 1]; }
+
+// Frame `slot` on n devices: rank i renders the tiles t with t % n == i (its own frame context `slot`, its own stream, one
+// host thread per device so that frames which need host decisions between passes still run side by side), then ONE
+// grouped RCCL exchange moves the tile buffers to rank 0 -- the path's only exchange step -- and k_detile writes the
+// W*H frame into d_out on the scene's device.  Everything after the enqueue is stream-ordered on rank 0's stream.
+int multi_begin(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts, uint32_t *d_out,
+                hipStream_t *stream0_out) {
+    const int n = opts->n_gpus;
+    if (opts->shard_count > 1) return fail(XRT_E_INVALID_ARG, "n_gpus > 1 shards the frame inside the library: shard_count must be 0 or 1");
+    if (n > XRT_MAX_GPUS) return fail(XRT_E_INVALID_ARG, "n_gpus %d exceeds %d", n, XRT_MAX_GPUS);
+    if (!cam || cam->vp_width <= 0 || cam->vp_height <= 0) return fail(XRT_E_INVALID_ARG, "viewport must be positive");
+    if (!s->fakeGpus) {
+        int nd = 0;
+        if (hipGetDeviceCount(&nd) != hipSuccess) { (void)hipGetLastError(); nd = 0; }
+        if (s->device + n > nd) return fail(XRT_E_NO_DEVICE, "n_gpus %d from device %d needs %d visible devices, %d present", n, s->device, s->device + n, nd);
+    }
+    int rc;
+    if ((rc = ensure_replicas(s, n))) return rc;
+    {
+        std::vector<int> devs;
+        if (s->fakeGpus) devs.push_back(s->device);
+        else for (int i = 0; i < n; i++) devs.push_back(s->device + i);
+        std::string err;
+        if (!s->rccl.init(devs, err)) return fail(XRT_E_RCCL, "%s", err.c_str());
+        HIPCHECK(hipSetDevice(s->device));
+    }
+    int tpr = 0;
+    xrt_shard_layout(cam->vp_width, cam->vp_height, n, nullptr, nullptr, &tpr);
+    const size_t count = (size_t)tpr * 512;
+    if ((rc = s->gathered[slot].ensure(count * (size_t)n))) return rc;
+    for (int i = 1; i < n; i++) {
+        xrt_scene *r = rank_scene(s, i);
+        HIPCHECK(hipSetDevice(r->device));
+        if ((rc = r->tileOut[slot].ensure(count))) return rc;
+        if (s->fakeGpus && !r->tilesReady[slot]) HIPCHECK(hipEventCreateWithFlags(&r->tilesReady[slot], hipEventDisableTiming));
+    }
+    HIPCHECK(hipSetDevice(s->device));
+    // one host thread per device
+    std::vector<int> rcs((size_t)n, XRT_OK);
+    std::vector<std::string> errs((size_t)n);
+    auto work = [&](int i) {
+        xrt_scene *r = rank_scene(s, i);
+        if (hipSetDevice(r->device) != hipSuccess) { rcs[(size_t)i] = XRT_E_HIP; errs[(size_t)i] = "hipSetDevice failed"; return; }
+        xrt_render_opts o = *opts;
+        o.n_gpus = 0; o.shard_rank = i; o.shard_count = n;
+        uint32_t *dst = i == 0 ? s->gathered[slot].p : r->tileOut[slot].p;
+        rcs[(size_t)i] = frame_begin(r, r->frames[slot], cam, lights, nLights, &o, dst, nullptr, nullptr);
+        if (rcs[(size_t)i] != XRT_OK) errs[(size_t)i] = g_err;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < n; i++) th.emplace_back(work, i);
+        work(0);
+        for (auto &t : th) t.join();
+    }
+    HIPCHECK(hipSetDevice(s->device));
+    for (int i = 0; i < n; i++)
+        if (rcs[(size_t)i] != XRT_OK) {   // wait for the ranks that did start, then report the first failure
+            for (int j = 0; j < n; j++) {
+                xrt_scene *r = rank_scene(s, j);
+                if (r->frames[slot].pending) { (void)hipSetDevice(r->device); (void)frame_finish(r, r->frames[slot], nullptr); }
+            }
+            (void)hipSetDevice(s->device);
+            return fail(rcs[(size_t)i], "rank %d: %s", i, errs[(size_t)i].c_str());
+        }
+    hipStream_t st0 = s->frames[slot].w.lastStream;
+    std::vector<const void *> src;
+    std::vector<int> srcRank;
+    std::vector<hipStream_t> srcStream;
+    std::vector<void *> dst;
+    for (int i = 1; i < n; i++) {
+        xrt_scene *r = rank_scene(s, i);
+        hipStream_t sti = r->frames[slot].w.lastStream;
+        if (s->fakeGpus) {   // same device, one communicator: rank 0's stream waits for the tiles, then sends to itself
+            HIPCHECK(hipEventRecord(r->tilesReady[slot], sti));
+            HIPCHECK(hipStreamWaitEvent(st0, r->tilesReady[slot], 0));
+            sti = st0;
+        }
+        src.push_back(r->tileOut[slot].p); srcRank.push_back(s->fakeGpus ? 0 : i); srcStream.push_back(sti);
+        dst.push_back(s->gathered[slot].p + (size_t)i * count);
+    }
+    {
+        std::string err;
+        if (!s->rccl.gather(src, srcRank, srcStream, dst, count, st0, err)) {
+            for (int j = 0; j < n; j++) { xrt_scene *r = rank_scene(s, j); (void)hipSetDevice(r->device); (void)frame_finish(r, r->frames[slot], nullptr); }
+            (void)hipSetDevice(s->device);
+            return fail(XRT_E_RCCL, "%s", err.c_str());
+        }
+    }
+    HIPCHECK(hipSetDevice(s->device));
+    launch_detile(cam->vp_width, cam->vp_height, n, tpr, s->gathered[slot].p, (long long)count, d_out, st0);
+    HIPCHECK(hipGetLastError());
+    *stream0_out = st0;
+    return XRT_OK;
+}
+
+// Counters add up over the ranks; times are the slowest rank's (the frame's critical path).
+int multi_end(xrt_scene *s, int slot, int n, xrt_stats *stats) {
+    int rc = XRT_OK;
+    xrt_stats acc;
+    std::memset(&acc, 0, sizeof(acc));
+    for (int i = 0; i < n; i++) {
+        xrt_scene *r = rank_scene(s, i);
+        if (hipSetDevice(r->device) != hipSuccess) { rc = fail(XRT_E_HIP, "hipSetDevice failed"); continue; }
+        xrt_stats st;
+        std::memset(&st, 0, sizeof(st));
+        const int rci = frame_finish(r, r->frames[slot], &st);
+        if (rci != XRT_OK) { rc = rci; continue; }
+        uint64_t *a = reinterpret_cast<uint64_t *>(&acc);
+        const uint64_t *b = reinterpret_cast<const uint64_t *>(&st);
+        for (size_t k = 0; k < offsetof(xrt_stats, ms_total) / sizeof(uint64_t); k++) a[k] += b[k];
+        if (st.ms_total > acc.ms_total) acc.ms_total = st.ms_total;
+        if (st.ms_intersect > acc.ms_intersect) acc.ms_intersect = st.ms_intersect;
+        if (i == 0) acc.intersect_launches = st.intersect_launches;
+    }
+    (void)hipSetDevice(s->device);
+    if (rc == XRT_OK && stats) *stats = acc;
+    return rc;
+}
+
+// ---- one ticket: frame (on one or n GPUs) -> optional copy into the host's Color[] (RT:122-123) -------------------------
+// d_out: the W*H frame in HBM (or this process's tile shard), or null when the frame is only wanted on the host (the
+// library then keeps it in a buffer of the ticket).  host_out: page-locked or pageable host memory, or null.
+int open_frame(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts, uint32_t *d_out,
+               float *d_outF32, uint32_t *host_out, hipStream_t st) {
+    if (!cam || !opts) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
+    if (opts->n_gpus < 0) return fail(XRT_E_INVALID_ARG, "n_gpus must not be negative");
+    const int n = opts->n_gpus > 1 ? opts->n_gpus : 1;
+    if (n > 1 && d_outF32) return fail(XRT_E_UNSUPPORTED, "rgb_f32_out with n_gpus > 1");
+    const size_t px = (size_t)(cam->vp_width > 0 ? cam->vp_width : 0) * (size_t)(cam->vp_height > 0 ? cam->vp_height : 0);
+    int rc;
+    if (!d_out) {
+        if (opts->shard_count > 1) return fail(XRT_E_INVALID_ARG, "a host frame is a whole frame; use xrt_render_device for shards");
+        if ((rc = s->frameOut[slot].ensure(px ? px : 1))) return rc;
+        d_out = s->frameOut[slot].p;
+    }
+    hipStream_t st0 = nullptr;
+    if (n == 1) {
+        if ((rc = frame_begin(s, s->frames[slot], cam, lights, nLights, opts, d_out, d_outF32, st))) return rc;
+        st0 = s->frames[slot].w.lastStream;
+    } else if ((rc = multi_begin(s, slot, cam, lights, nLights, opts, d_out, &st0))) return rc;
+    xrt_scene::OpenFrame &O = s->open[slot];
+    O.nGpus = n;
+    O.tail = n > 1 || host_out != nullptr;
+    if (O.tail) {   // work enqueued behind the frame's own kernels: its end is an event of its own
+        if (host_out && px) HIPCHECK(hipMemcpyAsync(host_out, d_out, px * sizeof(uint32_t), hipMemcpyDeviceToHost, st0));   // CurrentTarget.SetData (RT:123)
+        if (!s->tailDone[slot]) HIPCHECK(hipEventCreateWithFlags(&s->tailDone[slot], hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(s->tailDone[slot], st0));
+    }
+    return XRT_OK;
+}
+
+int close_frame(xrt_scene *s, int slot, xrt_stats *stats) {
+    xrt_scene::OpenFrame &O = s->open[slot];
+    int rc = O.nGpus > 1 ? multi_end(s, slot, O.nGpus, stats) : frame_finish(s, s->frames[slot], stats);
+    if (O.tail) {
+        const hipError_t e = hipEventSynchronize(s->tailDone[slot]);
+        if (e != hipSuccess && rc == XRT_OK) rc = fail(XRT_E_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+    }
+    O = xrt_scene::OpenFrame();
+    return rc;
+}
+
+// The work-queue word of launches on `st` (launches of one stream are ordered, so they can share a word; launches on
+// different streams may overlap and must not).  Caller holds apiMutex.
+int queue_word_for(xrt_scene *s, hipStream_t st, unsigned **word) {
+    constexpr size_t MAX_STREAMS = 1024;
+    int rc;
+    if ((rc = s->queues.ensure(MAX_STREAMS))) return rc;
+    auto it = s->queueOfStream.find(st);
+    if (it == s->queueOfStream.end()) {
+        if (s->queueOfStream.size() >= MAX_STREAMS) return fail(XRT_E_UNSUPPORTED, "xrt_scene_intersect_device: more than %zu distinct streams on one scene", MAX_STREAMS);
+        it = s->queueOfStream.emplace(st, (int)s->queueOfStream.size()).first;
+    }
+    *word = s->queues.p + it->second;
+    return XRT_OK;
+}
+
+// Caller holds apiMutex.
 int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hits, int mode, int meshId, hipStream_t st, xrt_stats *stats,
                   bool sync) {
     if (n > 0x7fffffff / 2) return fail(XRT_E_INVALID_ARG, "too many rays in one call");
     int rc;
-    if ((rc = s->queues.ensure(8)) || (rc = s->counters.ensure(2 * C_COUNT))) return rc;
-    HIPCHECK(hipMemsetAsync(s->queues.p, 0, sizeof(unsigned), st));
+    unsigned *queue = nullptr;
+    if ((rc = queue_word_for(s, st, &queue)) || (rc = s->counters.ensure(2 * C_COUNT + 8))) return rc;
+    // the reference-work counters are shared with the frames' counting pass: exact counts need the scene to itself
+    if (stats && in_flight(s)) return fail(XRT_E_BUSY, "xrt_scene_intersect with stats while a render is in flight");
+    HIPCHECK(hipMemsetAsync(queue, 0, sizeof(unsigned), st));
     IntersectArgs A;
-    A.rays = d_rays; A.hits = d_hits; A.index = nullptr; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.nCap = 0; A.queue = s->queues.p; A.mode = mode; A.meshId = meshId;
+    A.rays = d_rays; A.hits = d_hits; A.index = nullptr; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.nCap = 0; A.queue = queue; A.mode = mode; A.meshId = meshId;
     A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.coopMax = s->tune[3]; A.firstBatch = s->firstBatch;
     hipEvent_t a0 = nullptr, a1 = nullptr;
     if (stats) {
@@ -826,6 +1059,55 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
         if (n > 0) HIPCHECK(hipEventElapsedTime(&ms, a0, a1));
         stats->ms_total = ms; stats->ms_intersect = ms; stats->intersect_launches = n > 0 ? 1 : 0;
     }
+    return XRT_OK;
+}
+
+// Host arrays of scene->host -> HBM of scene->device, launch geometry and scheduling defaults (second half of
+// xrt_scene_build; also what puts a replica of the scene on another device).
+int scene_upload(xrt_scene *scene) {
+    const SceneArrays &A = scene->host->arrays;
+    scene->stackNeeded = (A.sceneDepth + 1) + (A.meshDepth + 1);
+    if (intersect_stack_capacity(scene->stackNeeded) < 0) return fail(XRT_E_UNSUPPORTED, "octree too deep for the LDS stack (%d levels)", scene->stackNeeded);
+    if (scene->device < 0) return XRT_OK;   // host-only scene: trees can be inspected, nothing can be traced
+    HIPCHECK(hipSetDevice(scene->device));
+    int rc;
+    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->leafNB, A.leafNB)) || (rc = upload(scene->refN, A.refN)) || (rc = upload(scene->refG, A.refG)) ||
+        (rc = upload(scene->snodes, A.snodes)) || (rc = upload(scene->shade, A.shade)) || (rc = upload(scene->childDfs, A.childDfs)) ||
+        (rc = upload(scene->srefs, A.srefs)) || (rc = upload(scene->objMesh, A.objMesh)) ||
+        (rc = upload(scene->meshes, A.meshes)) || (rc = upload(scene->objects, A.objects)) || (rc = upload(scene->materials, A.materials)) ||
+        (rc = upload(scene->texels, A.texels)))
+        return rc;
+    SceneView &S = scene->view;
+    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.leafNB = scene->leafNB.p; S.refN = scene->refN.p; S.refG = scene->refG.p;
+    S.meshes = scene->meshes.p; S.snodes = scene->snodes.p; S.srefs = scene->srefs.p;
+    S.objects = scene->objects.p; S.objMesh = scene->objMesh.p;
+    S.nMeshes = (int)scene->host->meshes.size(); S.nObjects = (int)scene->host->objects.size();
+    S.sceneDepth = A.sceneDepth + 1; S.meshDepth = A.meshDepth + 1;
+    scene->sceneMode = (scene->host->objects.size() == 1 && scene->host->objects[0].meshes.size() == 1 && scene->host->meshes.size() == 1 &&
+                        scene->host->sceneTree.nodeCount == 1) ? MODE_SINGLE : MODE_SCENE;
+    if (getenv("XRT_NO_SINGLE")) scene->sceneMode = MODE_SCENE;
+    scene->blocksPerCU = intersect_blocks_per_cu(scene->stackNeeded, scene->sceneMode);
+    scene->blocksPerCUMesh = intersect_blocks_per_cu(scene->stackNeeded, MODE_MESH);
+    scene->firstBatch = (A.meshDepth == 0) ? 256 : 64;   // every mesh is a single leaf: rays are cheap, avoid queue traffic
+    if (const char *e = getenv("XRT_FIRST_BATCH")) { int v = atoi(e); if (v >= 64 && v <= 4096 && v % 64 == 0) scene->firstBatch = v; }
+    {   // "long ray first": worth it only where rays can be long, i.e. where some mesh has a real octree
+        float frac = 0.25f;
+        if (const char *e = getenv("XRT_HEAVY")) frac = (float)atof(e);
+        scene->heavyPath = 0.0f;
+        scene->deepMeshes = A.meshDepth > 0;
+        for (int &t : scene->costT) t = 24;
+        if (const char *e = getenv("XRT_LONG_FRAC")) { int lo = 0, hi = 0; if (sscanf(e, "%d,%d", &lo, &hi) == 2 && lo >= 0 && hi > lo && hi <= 100) { scene->longFracLo = lo; scene->longFracHi = hi; } }
+        // (measured: +24 % on the 1M-triangle heightfield, whose stragglers are rays skimming the terrain; nothing on the
+        //  instanced grid, whose rays are all about as long as the box -- XRT_HEAVY forces it on for any scene)
+        const bool wanted = getenv("XRT_HEAVY") != nullptr || scene->sceneMode == MODE_SINGLE;
+        if (wanted && frac > 0.0f && A.meshDepth > 0 && A.snodes.size() >= 2) {
+            const f4 lo = A.snodes[0], hi = A.snodes[1];
+            const double dx = (double)hi.x - lo.x, dy = (double)hi.y - lo.y, dz = (double)hi.z - lo.z;
+            const double diag = std::sqrt(dx * dx + dy * dy + dz * dz);
+            if (diag > 0.0 && diag < 1e30) scene->heavyPath = (float)(frac * diag);
+        }
+    }
+    scene->resident = true;
     return XRT_OK;
 }
 
@@ -858,6 +1140,8 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     xrt_scene *s = new xrt_scene();
     s->device = device;
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
+    s->fakeGpus = getenv("XRT_FAKE_GPUS") != nullptr;
+    s->noRectCull = getenv("XRT_NO_RECT_CULL") != nullptr; s->oneStream = getenv("XRT_ONE_STREAM") != nullptr; s->noFeedback = getenv("XRT_NO_FEEDBACK") != nullptr;
     if (const char *e = getenv("XRT_OVERLAP_MS")) s->overlapMinMs = (float)atof(e);   // 0: every single-chunk frame gets its context's stream
     if (const char *e = getenv("XRT_HEAP_RAY_CAP")) { long long v = atoll(e); if (v >= 1024 && v <= HEAP_RAY_CAP) s->heapRayCap = v; }
     if (const char *e = getenv("XRT_CHUNK_PATHS")) { long long v = atoll(e); if (v >= 8192 && v <= MAX_CHUNK_PATHS && v % 8192 == 0) s->maxChunkPaths = v; }
@@ -914,50 +1198,9 @@ int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_thre
     std::string err;
     scene->resident = false;
     if (!scene->hs.build(mesh_threshold, scene_threshold, err)) return fail(XRT_E_UNSUPPORTED, "%s", err.c_str());
-    const SceneArrays &A = scene->hs.arrays;
-    scene->stackNeeded = (A.sceneDepth + 1) + (A.meshDepth + 1);
-    if (intersect_stack_capacity(scene->stackNeeded) < 0) return fail(XRT_E_UNSUPPORTED, "octree too deep for the LDS stack (%d levels)", scene->stackNeeded);
-    if (scene->device < 0) return XRT_OK;   // host-only scene: trees can be inspected, nothing can be traced
-    HIPCHECK(hipSetDevice(scene->device));
-    int rc;
-    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->leafNB, A.leafNB)) || (rc = upload(scene->refN, A.refN)) || (rc = upload(scene->refG, A.refG)) ||
-        (rc = upload(scene->snodes, A.snodes)) || (rc = upload(scene->shade, A.shade)) || (rc = upload(scene->childDfs, A.childDfs)) ||
-        (rc = upload(scene->srefs, A.srefs)) || (rc = upload(scene->objMesh, A.objMesh)) ||
-        (rc = upload(scene->meshes, A.meshes)) || (rc = upload(scene->objects, A.objects)) || (rc = upload(scene->materials, A.materials)) ||
-        (rc = upload(scene->texels, A.texels)))
-        return rc;
-    SceneView &S = scene->view;
-    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.leafNB = scene->leafNB.p; S.refN = scene->refN.p; S.refG = scene->refG.p;
-    S.meshes = scene->meshes.p; S.snodes = scene->snodes.p; S.srefs = scene->srefs.p;
-    S.objects = scene->objects.p; S.objMesh = scene->objMesh.p;
-    S.nMeshes = (int)scene->hs.meshes.size(); S.nObjects = (int)scene->hs.objects.size();
-    S.sceneDepth = A.sceneDepth + 1; S.meshDepth = A.meshDepth + 1;
-    scene->sceneMode = (scene->hs.objects.size() == 1 && scene->hs.objects[0].meshes.size() == 1 && scene->hs.meshes.size() == 1 &&
-                        scene->hs.sceneTree.nodeCount == 1) ? MODE_SINGLE : MODE_SCENE;
-    if (getenv("XRT_NO_SINGLE")) scene->sceneMode = MODE_SCENE;
-    scene->blocksPerCU = intersect_blocks_per_cu(scene->stackNeeded, scene->sceneMode);
-    scene->blocksPerCUMesh = intersect_blocks_per_cu(scene->stackNeeded, MODE_MESH);
-    scene->firstBatch = (A.meshDepth == 0) ? 256 : 64;   // every mesh is a single leaf: rays are cheap, avoid queue traffic
-    if (const char *e = getenv("XRT_FIRST_BATCH")) { int v = atoi(e); if (v >= 64 && v <= 4096 && v % 64 == 0) scene->firstBatch = v; }
-    {   // "long ray first": worth it only where rays can be long, i.e. where some mesh has a real octree
-        float frac = 0.25f;
-        if (const char *e = getenv("XRT_HEAVY")) frac = (float)atof(e);
-        scene->heavyPath = 0.0f;
-        scene->deepMeshes = A.meshDepth > 0;
-        for (int &t : scene->costT) t = 24;
-        if (const char *e = getenv("XRT_LONG_FRAC")) { int lo = 0, hi = 0; if (sscanf(e, "%d,%d", &lo, &hi) == 2 && lo >= 0 && hi > lo && hi <= 100) { scene->longFracLo = lo; scene->longFracHi = hi; } }
-        // (measured: +24 % on the 1M-triangle heightfield, whose stragglers are rays skimming the terrain; nothing on the
-        //  instanced grid, whose rays are all about as long as the box -- XRT_HEAVY forces it on for any scene)
-        const bool wanted = getenv("XRT_HEAVY") != nullptr || scene->sceneMode == MODE_SINGLE;
-        if (wanted && frac > 0.0f && A.meshDepth > 0 && A.snodes.size() >= 2) {
-            const f4 lo = A.snodes[0], hi = A.snodes[1];
-            const double dx = (double)hi.x - lo.x, dy = (double)hi.y - lo.y, dz = (double)hi.z - lo.z;
-            const double diag = std::sqrt(dx * dx + dy * dy + dz * dz);
-            if (diag > 0.0 && diag < 1e30) scene->heavyPath = (float)(frac * diag);
-        }
-    }
-    scene->resident = true;
-    return XRT_OK;
+    for (xrt_scene *r : scene->replicas) delete r;   // copies of the previous build on other devices
+    scene->replicas.clear();
+    return scene_upload(scene);
 }
 
 int xrt_scene_get_tree(const xrt_scene *scene, int32_t mesh_id, xrt_node_info *nodes, int64_t *n_nodes_inout, int32_t *refs,
@@ -984,6 +1227,7 @@ int xrt_scene_intersect(xrt_scene *scene, const xrt_ray *rays, const int32_t *ig
     int rc = need_device(scene, "xrt_scene_intersect");
     if (rc != XRT_OK) return rc;
     if (n < 0 || (n > 0 && (!rays || !hits_out))) return fail(XRT_E_INVALID_ARG, "xrt_scene_intersect: null argument");
+    std::lock_guard<std::mutex> lock(scene->apiMutex);   // concurrent callers (RT:105-113) take turns on the staging buffers
     if ((rc = scene->apiRays.ensure((size_t)n)) || (rc = scene->apiHits.ensure((size_t)n))) return rc;
     hipStream_t st = scene->stream;
     if (n > 0) HIPCHECK(hipMemcpyAsync(scene->apiRays.p, rays, (size_t)n * sizeof(xrt_ray), hipMemcpyHostToDevice, st));
@@ -998,6 +1242,7 @@ int xrt_scene_intersect_device(xrt_scene *scene, const void *d_rays, int64_t n, 
     if (rc != XRT_OK) return rc;
     if (n < 0 || (n > 0 && (!d_rays || !d_hits_out))) return fail(XRT_E_INVALID_ARG, "xrt_scene_intersect_device: null argument");
     if (((uintptr_t)d_rays & 15) || ((uintptr_t)d_hits_out & 15)) return fail(XRT_E_INVALID_ARG, "device buffers must be 16-byte aligned");
+    std::lock_guard<std::mutex> lock(scene->apiMutex);   // (held for the enqueue only: the call is asynchronous)
     return run_intersect(scene, (const xrt_ray *)d_rays, n, (xrt_hit *)d_hits_out, scene->sceneMode, 0, (hipStream_t)stream, nullptr, false);
 }
 
@@ -1006,6 +1251,7 @@ int xrt_mesh_intersect(xrt_scene *scene, int32_t mesh_id, const xrt_ray *rays, i
     if (rc != XRT_OK) return rc;
     if (mesh_id < 0 || mesh_id >= (int)scene->hs.meshes.size()) return fail(XRT_E_INVALID_ARG, "xrt_mesh_intersect: unknown mesh id");
     if (n < 0 || (n > 0 && (!rays || !hits_out))) return fail(XRT_E_INVALID_ARG, "xrt_mesh_intersect: null argument");
+    std::lock_guard<std::mutex> lock(scene->apiMutex);
     if ((rc = scene->apiRays.ensure((size_t)n)) || (rc = scene->apiHits.ensure((size_t)n))) return rc;
     hipStream_t st = scene->stream;
     if (n > 0) HIPCHECK(hipMemcpyAsync(scene->apiRays.p, rays, (size_t)n * sizeof(xrt_ray), hipMemcpyHostToDevice, st));
@@ -1021,18 +1267,47 @@ int xrt_render(xrt_scene *scene, const xrt_camera *camera, const xrt_light *ligh
     if (rc != XRT_OK) return rc;
     if (!camera || !opts || !rgba_out) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
     if (opts->shard_count > 1) return fail(XRT_E_INVALID_ARG, "xrt_render writes a whole frame; use xrt_render_device for shards");
+    if (rgb_f32_out && opts->use_multisampling != XRT_MS_OFF)
+        return fail(XRT_E_UNSUPPORTED, "xrt_render: rgb_f32_out is the colorVector of RT:705/726 and exists only without multisampling (RT:309 averages packed colours)");
     BusyGuard guard(scene);
     if (!guard.owned || scene->frames[0].pending || scene->frames[1].pending)
         return fail(XRT_E_BUSY, "Current render operation not finished.");   // RT:62-63
-    const size_t px = (size_t)camera->vp_width * (size_t)camera->vp_height;
     if (camera->vp_width <= 0 || camera->vp_height <= 0) return fail(XRT_E_INVALID_ARG, "viewport must be positive");
-    if ((rc = scene->outRGBA.ensure(px))) return rc;
+    const size_t px = (size_t)camera->vp_width * (size_t)camera->vp_height;
     if (rgb_f32_out && (rc = scene->outF32.ensure(px * 3))) return rc;
-    hipStream_t st = scene->stream;
-    rc = render_impl(scene, camera, lights, n_lights, opts, scene->outRGBA.p, rgb_f32_out ? scene->outF32.p : nullptr, st, stats_out);
-    if (rc != XRT_OK) return rc;
-    HIPCHECK(hipMemcpy(rgba_out, scene->outRGBA.p, px * sizeof(uint32_t), hipMemcpyDeviceToHost));   // CurrentTarget.SetData (RT:123)
+    if ((rc = open_frame(scene, 0, camera, lights, n_lights, opts, nullptr, rgb_f32_out ? scene->outF32.p : nullptr, rgba_out, scene->stream))) return rc;
+    if ((rc = close_frame(scene, 0, stats_out))) return rc;
     if (rgb_f32_out) HIPCHECK(hipMemcpy(rgb_f32_out, scene->outF32.p, px * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return XRT_OK;
+}
+
+int xrt_render_begin(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights, int32_t n_lights, const xrt_render_opts *opts,
+                     uint32_t *rgba_out, int32_t *ticket_out) {
+    int rc = need_device(scene, "xrt_render_begin");
+    if (rc != XRT_OK) return rc;
+    if (!camera || !opts || !rgba_out || !ticket_out) return fail(XRT_E_INVALID_ARG, "xrt_render_begin: null argument");
+    BusyGuard guard(scene);
+    if (!guard.owned) return fail(XRT_E_BUSY, "Current render operation not finished.");
+    const int slot = !scene->frames[0].pending ? 0 : (!scene->frames[1].pending ? 1 : -1);
+    if (slot < 0) return fail(XRT_E_BUSY, "two frames are already in flight; call xrt_render_end first");
+    if ((rc = open_frame(scene, slot, camera, lights, n_lights, opts, nullptr, nullptr, rgba_out, nullptr))) return rc;
+    *ticket_out = slot;
+    return XRT_OK;
+}
+
+int xrt_render_end(xrt_scene *scene, int32_t ticket, xrt_stats *stats_out) { return xrt_render_device_end(scene, ticket, stats_out); }
+
+int xrt_host_register(void *host_ptr, uint64_t bytes) {
+    if (!host_ptr || bytes == 0) return fail(XRT_E_INVALID_ARG, "xrt_host_register: null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(XRT_E_NO_DEVICE, "no HIP device visible"); }
+    HIPCHECK(hipHostRegister(host_ptr, (size_t)bytes, hipHostRegisterDefault));
+    return XRT_OK;
+}
+
+int xrt_host_unregister(void *host_ptr) {
+    if (!host_ptr) return fail(XRT_E_INVALID_ARG, "xrt_host_unregister: null argument");
+    HIPCHECK(hipHostUnregister(host_ptr));
     return XRT_OK;
 }
 
@@ -1044,7 +1319,8 @@ int xrt_render_device(xrt_scene *scene, const xrt_camera *camera, const xrt_ligh
     BusyGuard guard(scene);
     if (!guard.owned || scene->frames[0].pending || scene->frames[1].pending) return fail(XRT_E_BUSY, "Current render operation not finished.");
     hipStream_t st = stream ? (hipStream_t)stream : scene->stream;
-    return render_impl(scene, camera, lights, n_lights, opts, (uint32_t *)d_rgba_out, nullptr, st, stats_out);
+    if ((rc = open_frame(scene, 0, camera, lights, n_lights, opts, (uint32_t *)d_rgba_out, nullptr, nullptr, st))) return rc;
+    return close_frame(scene, 0, stats_out);
 }
 
 int xrt_render_device_begin(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights, int32_t n_lights, const xrt_render_opts *opts,
@@ -1057,7 +1333,7 @@ int xrt_render_device_begin(xrt_scene *scene, const xrt_camera *camera, const xr
     const int slot = !scene->frames[0].pending ? 0 : (!scene->frames[1].pending ? 1 : -1);
     if (slot < 0) return fail(XRT_E_BUSY, "two frames are already in flight; call xrt_render_device_end first");
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = frame_begin(scene, scene->frames[slot], camera, lights, n_lights, opts, (uint32_t *)d_rgba_out, nullptr, st))) return rc;
+    if ((rc = open_frame(scene, slot, camera, lights, n_lights, opts, (uint32_t *)d_rgba_out, nullptr, nullptr, st))) return rc;
     *ticket_out = slot;
     return XRT_OK;
 }
@@ -1068,7 +1344,8 @@ int xrt_render_device_end(xrt_scene *scene, int32_t ticket, xrt_stats *stats_out
     if (ticket < 0 || ticket > 1) return fail(XRT_E_INVALID_ARG, "xrt_render_device_end: unknown ticket");
     BusyGuard guard(scene);
     if (!guard.owned) return fail(XRT_E_BUSY, "Current render operation not finished.");
-    return frame_finish(scene, scene->frames[ticket], stats_out);
+    if (!scene->frames[ticket].pending) return fail(XRT_E_INVALID_ARG, "no frame in flight for this ticket");
+    return close_frame(scene, ticket, stats_out);
 }
 
 int xrt_shard_layout(int32_t width, int32_t height, int32_t shard_count, int32_t *tiles_x_out, int32_t *tiles_y_out, int32_t *tiles_per_rank_out) {
@@ -1106,6 +1383,7 @@ int xrt_generate_primary_rays(xrt_scene *scene, const xrt_camera *camera, xrt_ra
     if ((rc = make_raygen(camera, &o, g))) return rc;
     const long long slots = (long long)g.tilesX * g.tilesY * 512;
     if (slots > (1LL << 25)) return fail(XRT_E_INVALID_ARG, "frame too large");
+    std::lock_guard<std::mutex> lock(scene->apiMutex);
     if ((rc = scene->apiRays.ensure((size_t)slots))) return rc;
     hipStream_t st = scene->stream;
     launch_raygen(g, scene->view, scene->apiRays.p, nullptr, nullptr, nullptr, (int)slots, 0, HeavyArgs(), st);
