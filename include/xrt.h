@@ -235,8 +235,9 @@ int xrt_mesh_intersect(xrt_scene *scene, int32_t mesh_id, const xrt_ray *rays, i
 /* ---- seam 2: RayTracer.RenderInternal (RT:103-126) / RenderInternalWithMultisampling
  *      (RT:128-168) -------------------------------------------------------------------------------
  * Fills rgba_out[y*W + x] with the packed XNA Color (R in the low byte, RT:425). Blocking.
- * rgb_f32_out (nullable, W*H*3) receives the iteration-0 colorVector before packing (RT:705/726); it exists only
- * with XRT_MS_OFF (the supersampled modes average PACKED colours, RT:309): otherwise XRT_E_UNSUPPORTED.
+ * rgb_f32_out (nullable, W*H*3) receives the iteration-0 colorVector before packing (RT:705/726); in the supersampled
+ * modes, which average PACKED colours (RT:309), it receives Color.ToVector3() of the pixel's final colour (written by
+ * the resolve kernel).  Not available with n_gpus > 1 (XRT_E_UNSUPPORTED).
  * A second concurrent call on the same scene returns XRT_E_BUSY (RT:62-63). */
 int xrt_render(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights, int32_t n_lights,
                const xrt_render_opts *opts, uint32_t *rgba_out, float *rgb_f32_out,

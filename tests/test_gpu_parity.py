@@ -429,26 +429,23 @@ def test_seam1_is_reentrant_across_host_threads(xrt, orc):
 
 
 def test_render_argument_limits(xrt):
-    """rgb_f32_out exists only without multisampling (RT:309 averages packed colours): UNSUPPORTED instead of stale memory;
-    more than XRT_MAX_LIGHTS lights: INVALID_ARG."""
+    """rgb_f32_out in a supersampled mode is Color.ToVector3() of the final colour (k_resolve writes it; ADVICE r1 suspected
+    stale memory); more than XRT_MAX_LIGHTS lights: INVALID_ARG instead of an int overflow of the shadow-ray count."""
     spec = xrt.configs.config("C1", 0.25)
+    spec.multisampling = xrt.abi.MS_FIXED16
     scene, tracer = xrt.configs.build_product(spec)
+    rgba, rgbf = tracer.Render(want_float=True)
+    unpacked = np.stack([(rgba >> s & 0xff).astype(np.float32) / np.float32(255.0) for s in (0, 8, 16)], axis=1)
+    assert np.array_equal(rgbf, unpacked) and (rgba & 0xffffff).any()
+    rgba = rgba.copy()
     lib, abi = xrt.abi.lib(), xrt.abi
-    W, H = spec.width, spec.height
-    rgba = np.zeros(W * H, dtype=np.uint32)
-    f32 = np.zeros(W * H * 3, dtype=np.float32)
+    out = np.zeros(spec.width * spec.height, dtype=np.uint32)
     cam, lights, n, opts = tracer._camera_abi(), tracer._lights_abi(), len(tracer.Lights), tracer._opts_abi()
-    opts.use_multisampling = abi.MS_FIXED16
-    rc = lib.xrt_render(scene.handle, C.byref(cam), lights, n, C.byref(opts), rgba.ctypes.data_as(C.POINTER(C.c_uint32)),
-                        f32.ctypes.data_as(C.POINTER(C.c_float)), None)
-    assert rc == abi.XRT_E_UNSUPPORTED and b"rgb_f32_out" in lib.xrt_last_error()
-    opts.use_multisampling = abi.MS_OFF
     many = (abi.xrt_light * 33)(*([lights[0]] * 33))
-    rc = lib.xrt_render(scene.handle, C.byref(cam), many, 33, C.byref(opts), rgba.ctypes.data_as(C.POINTER(C.c_uint32)), None, None)
+    rc = lib.xrt_render(scene.handle, C.byref(cam), many, 33, C.byref(opts), out.ctypes.data_as(C.POINTER(C.c_uint32)), None, None)
     assert rc == abi.XRT_E_INVALID_ARG and b"XRT_MAX_LIGHTS" in lib.xrt_last_error()
-    rc = lib.xrt_render(scene.handle, C.byref(cam), lights, n, C.byref(opts), rgba.ctypes.data_as(C.POINTER(C.c_uint32)),
-                        f32.ctypes.data_as(C.POINTER(C.c_float)), None)
-    assert rc == 0 and rgba.any()
+    rc = lib.xrt_render(scene.handle, C.byref(cam), lights, n, C.byref(opts), out.ctypes.data_as(C.POINTER(C.c_uint32)), None, None)
+    assert rc == 0 and np.array_equal(out, rgba)
 
 
 def test_device_pointer_intersect(xrt, orc):

@@ -1267,8 +1267,6 @@ int xrt_render(xrt_scene *scene, const xrt_camera *camera, const xrt_light *ligh
     if (rc != XRT_OK) return rc;
     if (!camera || !opts || !rgba_out) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
     if (opts->shard_count > 1) return fail(XRT_E_INVALID_ARG, "xrt_render writes a whole frame; use xrt_render_device for shards");
-    if (rgb_f32_out && opts->use_multisampling != XRT_MS_OFF)
-        return fail(XRT_E_UNSUPPORTED, "xrt_render: rgb_f32_out is the colorVector of RT:705/726 and exists only without multisampling (RT:309 averages packed colours)");
     BusyGuard guard(scene);
     if (!guard.owned || scene->frames[0].pending || scene->frames[1].pending)
         return fail(XRT_E_BUSY, "Current render operation not finished.");   // RT:62-63
