@@ -306,8 +306,8 @@ XRT_HD void advance_scene(Lane &L, SC &C, const SceneView &S, Stack &stk) {
         while (C.sRef < C.sRefEnd) {   // OSM:341-364: next body of the current leaf, world -> object space
             const int o = S.srefs[C.sRef++];
             const ObjRec &ob = S.objects[o];
-            if (ob.cullOk && !L.weird && !precull_hit(C.w, ob)) continue;   // conservative world-space reject: the visit would end at MESH:34-39 for every mesh
             const RayPre w = C.w;
+            if (ob.cullOk && !L.weird && !precull_hit(w, ob)) continue;   // conservative world-space reject: the visit would end at MESH:34-39 for every mesh
             C.obj = o;
             v3 rayDirPosition = add(w.o, w.d);                      // OSM:358
             v3 v1 = transform(w.o, ob.invWorld);                    // OSM:360

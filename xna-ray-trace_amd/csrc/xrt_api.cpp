@@ -1141,6 +1141,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     s->device = device;
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
     s->fakeGpus = getenv("XRT_FAKE_GPUS") != nullptr;
+    if (const char *e = getenv("XRT_CULL_SAFETY")) { const double v = atof(e); if (v >= 0.0 && v <= 1e6) s->hs.cullSafety = v; }   // development: factor S of the object pre-cull margin (below 2 the bound is no longer proven)
     s->noRectCull = getenv("XRT_NO_RECT_CULL") != nullptr; s->oneStream = getenv("XRT_ONE_STREAM") != nullptr; s->noFeedback = getenv("XRT_NO_FEEDBACK") != nullptr;
     if (const char *e = getenv("XRT_OVERLAP_MS")) s->overlapMinMs = (float)atof(e);   // 0: every single-chunk frame gets its context's stream
     if (const char *e = getenv("XRT_HEAP_RAY_CAP")) { long long v = atoll(e); if (v >= 1024 && v <= HEAP_RAY_CAP) s->heapRayCap = v; }
