@@ -424,6 +424,24 @@ def main():
                 del tracer_h
             except Exception as e:   # a side measurement must not take the headline down
                 line["host_output"] = {"error": str(e)[:200]}
+        if world == 1 and args.scale == 1.0:
+            try:   # what the C# host's blocking RenderInternal sees: one frame at a time (libxrt splits it over two streams)
+                _, tracer_b = xrt.configs.build_product(spec, device=local_rank)
+                outb = torch.zeros(spec.width * spec.height, dtype=torch.int32, device="cuda")
+                frb = tracer_b.PrepareDevice(outb.data_ptr())
+                for _ in range(3):
+                    frb()
+                torch.cuda.synchronize()
+                kb = max(2, min(args.steps, 10))
+                t0 = time.perf_counter()
+                for _ in range(kb):
+                    stb = frb()
+                torch.cuda.synchronize()
+                line["ms_per_step_blocking"] = round((time.perf_counter() - t0) / kb * 1e3, 4)
+                line["blocking_pieces"] = int(stb["pieces"])
+                del tracer_b, outb
+            except Exception as e:
+                line["ms_per_step_blocking"] = None
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(spec)
         if world == 1 and not args.no_extra and args.scale == 1.0:

@@ -48,7 +48,7 @@ namespace RayTraceProject.Native
     {
         public ulong raysClosest, raysShadow, hitsClosest, hitsShadow, sceneNodeTests, instanceVisits, meshAabbTests, meshQueries,
                      nodeTests, leafRefs, triTests, shadedHits, pixels, algorithmicBytes;
-        public double msTotal, msIntersect; public uint intersectLaunches, reserved;
+        public double msTotal, msIntersect; public uint intersectLaunches, pieces;
     }
 
     public static class Xrt

@@ -163,7 +163,7 @@ typedef struct xrt_stats {
     double   ms_total;            /* device time of the whole call */
     double   ms_intersect;        /* summed durations of the traversal kernel launches (HIP events) */
     uint32_t intersect_launches;
-    uint32_t reserved;
+    uint32_t pieces;              /* the frame was rendered in this many concurrent pieces (halves on two streams, GPUs); 1 otherwise */
 } xrt_stats;
 
 /* Flattened octree node for inspection by tests (mirrors the private CubeNode, MO:32-40 / OSM:37-48). */

@@ -800,6 +800,7 @@ def test_in_library_multi_gpu(xrt, monkeypatch):
             assert np.array_equal(got, ref), (mode, n)
             for k in keys:
                 assert tracer2.last_stats[k] == st_ref[k], (mode, n, k)
+            assert tracer2.last_stats["pieces"] == n
             d = torch.zeros(s2.width * s2.height, dtype=torch.int32, device="cuda")
             tracer2.RenderDevice(d.data_ptr())                              # xrt_render_device
             assert np.array_equal(d.cpu().numpy().view(np.uint32), ref), (mode, n)
@@ -857,6 +858,48 @@ def test_pipelined_host_output_frames(xrt):
         for b in pinned:
             xrt.abi.check(lib.xrt_host_unregister(C.c_void_p(b.ctypes.data)))
     assert np.array_equal(tracer.Render(), want)
+
+
+@pytest.mark.parametrize("split", ["1", "2"])
+def test_frames_split_in_two_halves_on_two_streams(xrt, monkeypatch, split):
+    """A blocking frame has no other frame to fill the drain of its launches, so libxrt renders it as two halves of its tiles
+    in two frame contexts on two streams (XRT_SPLIT, default 1; thresholds forced to zero here so that test-sized frames take
+    the path).  Same frame, same fp32 colour vector, same accounting as the unsplit render -- for 1 and 16 sub-rays, odd sizes,
+    host and device output, and (XRT_SPLIT=2) also for pipelined frames with four contexts busy."""
+    import torch
+    for spec in (xrt.configs.crate_grid_scene(333, 190), xrt.configs.heightfield_scene(320, 180, m=96),
+                 xrt.configs.heightfield_scene(200, 120, m=64, multisampling=xrt.abi.MS_FIXED16)):
+        monkeypatch.setenv("XRT_SPLIT", "0")
+        _, ref_tracer = xrt.configs.build_product(spec)
+        ms = spec.multisampling != xrt.abi.MS_OFF
+        want, want_f = ref_tracer.Render(want_float=True)
+        want, want_f, st_want = want.copy(), want_f.copy(), dict(ref_tracer.last_stats)
+        monkeypatch.setenv("XRT_SPLIT", split)
+        monkeypatch.setenv("XRT_SPLIT_MS", "0")
+        monkeypatch.setenv("XRT_OVERLAP_MS", "0")
+        scene, tracer = xrt.configs.build_product(spec)
+        for _ in range(3):   # the first frame of a scene is never split (no frame time known yet)
+            got, got_f = tracer.Render(want_float=True)
+            assert np.array_equal(got, want) and np.array_equal(got_f.view(np.uint32), want_f.view(np.uint32))
+            for k in ("rays_closest", "rays_shadow", "hits_closest", "shaded_hits", "pixels"):
+                assert tracer.last_stats[k] == st_want[k], (k, tracer.last_stats[k], st_want[k])
+        assert tracer.last_stats["intersect_launches"] == st_want["intersect_launches"]
+        assert tracer.last_stats["pieces"] == 2 and st_want["pieces"] == 1
+        n = spec.width * spec.height
+        outs = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(2)]
+        frs = [tracer.PrepareDevice(o.data_ptr()) for o in outs]
+        for rep in range(3):
+            t0 = frs[0].begin()
+            t1 = frs[1].begin()
+            frs[0].end(t0)
+            frs[1].end(t1)
+            for o in outs:
+                assert np.array_equal(o.cpu().numpy().view(np.uint32), want), rep
+                o.zero_()
+        frs[0]()   # blocking device render
+        assert np.array_equal(outs[0].cpu().numpy().view(np.uint32), want)
+        for k in ("XRT_SPLIT", "XRT_SPLIT_MS", "XRT_OVERLAP_MS"):
+            monkeypatch.delenv(k)
 
 
 def test_changing_frame_parameters_between_pipelined_frames(xrt):

@@ -66,10 +66,10 @@ class xrt_stats(C.Structure):
         "rays_closest", "rays_shadow", "hits_closest", "hits_shadow", "scene_node_tests", "instance_visits",
         "mesh_aabb_tests", "mesh_queries", "node_tests", "leaf_refs", "tri_tests", "shaded_hits", "pixels",
         "algorithmic_bytes")] + [("ms_total", C.c_double), ("ms_intersect", C.c_double),
-                                 ("intersect_launches", C.c_uint32), ("reserved", C.c_uint32)]
+                                 ("intersect_launches", C.c_uint32), ("pieces", C.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class xrt_node_info(C.Structure):

@@ -156,13 +156,18 @@ struct xrt_scene {
         unsigned long long shaded = 0, closestDeep = 0, livePaths = 0, live0 = 0, validPixels = 0;
         unsigned long long hcnt[2 * C_COUNT] = {0};
         WorkBufs w;
-    } frames[2];
+    } frames[8];   // context of ticket `slot`, part j of its frame: frames[slot + 2 * j] (a frame may be split into up to four bands on as many streams)
     std::vector<hipEvent_t> events;   // xrt_scene_intersect timing
     int firstBatch = 64;
     long long heapRayCap = HEAP_RAY_CAP;         // XRT_HEAP_RAY_CAP=<n> forces small ray buffers (tests of the overflow / retry path)
     long long maxChunkPaths = MAX_CHUNK_PATHS;   // XRT_CHUNK_PATHS=<n> (multiple of 8192) forces smaller chunks (tests of the multi-chunk path)
     float lastFrameMs = 0.0f;    // GPU time of the last finished frame
     float overlapMinMs = 0.5f;   // frames at least this long run on per-context streams
+    // A launch of persistent waves leaves the machine half empty while its last rays finish; a blocking single frame (what the
+    // C# host's RenderInternal asks for) has no other frame to fill the gaps, so it is rendered as two halves of its tiles on
+    // two streams.  XRT_SPLIT=0 never, 1 (default) frames nobody else overlaps, 2 also pipelined frames.
+    int splitMode = 1, splitParts = 2;
+    float splitMinMs = 1.0f;
     int tune[4] = {24, 16, 48, 32};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
     std::atomic<bool> busy{false};
     std::atomic<float> progress{0.0f};
@@ -180,7 +185,7 @@ struct xrt_scene {
     DevBuf<uint32_t> frameOut[2];    // W*H frame of a host-output ticket
     hipEvent_t tilesReady[2] = {nullptr, nullptr};   // replica (fake mode): its tiles are rendered
     hipEvent_t tailDone[2] = {nullptr, nullptr};     // primary: gather + de-tile + host copy of the ticket are done
-    struct OpenFrame { int nGpus = 0; bool tail = false; } open[2];
+    struct OpenFrame { int nGpus = 0, nParts = 1; bool tail = false; } open[2];
     std::mutex apiMutex;
     std::unordered_map<hipStream_t, int> queueOfStream;
     // development switches, read once at xrt_scene_create (never per frame)
@@ -222,7 +227,11 @@ struct BusyGuard {
     ~BusyGuard() { if (owned) s->busy.store(false); }
 };
 
-bool in_flight(const xrt_scene *s) { return s->busy.load() || s->frames[0].pending || s->frames[1].pending; }
+bool in_flight(const xrt_scene *s) {
+    if (s->busy.load()) return true;
+    for (const auto &f : s->frames) if (f.pending) return true;
+    return false;
+}
 
 int need_device(xrt_scene *s, const char *fn) {
     if (!s) return fail(XRT_E_INVALID_ARG, "%s: null scene", fn);
@@ -348,7 +357,7 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats);
 // frame_finish waits for them.  Adaptive supersampling and ray-tree frames need host decisions between their passes and
 // are complete when this returns.
 int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts,
-                uint32_t *d_out, float *d_outF32, hipStream_t st) {
+                uint32_t *d_out, float *d_outF32, hipStream_t st, int part = 0, int nParts = 1) {
     const bool stats = true;   // the read-back is two small pinned copies; always taken
     xrt_scene::WorkBufs &W = F.w;
     if (!cam || !opts || (!lights && nLights > 0) || nLights < 0) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
@@ -383,7 +392,12 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const long long myTiles = (totalTiles + g.shardCount - 1) / g.shardCount;   // tiles_per_rank (slots, some may be past the end)
     const long long totalPixels = myTiles * 512;
     if (adaptive && totalPixels * 4 > 0x7fffffffLL) return fail(XRT_E_UNSUPPORTED, "frame too large for adaptive supersampling");
-    const long long firstPaths = totalPixels * g.samples;
+    const long long framePaths = totalPixels * g.samples;   // the whole frame (this shard)
+    // part `part` of `nParts`: a contiguous range of the frame's paths (whole tiles), rendered by its own frame context
+    const long long partStride = nParts > 1 ? ((framePaths / nParts + 8191) / 8192) * 8192 : framePaths;
+    const long long partStart = (long long)part * partStride;
+    const long long firstPaths = nParts > 1 ? std::max(0LL, std::min(partStride, framePaths - partStart)) : framePaths;
+    if (nParts > 1 && (adaptive || firstPaths <= 0)) return fail(XRT_E_INTERNAL, "frame parts need a plain frame");
     // Chunking.  Without refraction a path owns one ray per generation.  With Transparent materials it may own up to
     // 2^k in generation k, but few paths do: chunks are sized optimistically (ray buffers of HEAP_RAY_CAP rays,
     // level records bounded by 8 GB) and a chunk whose generation overflows is retried with a quarter of the paths.
@@ -441,19 +455,19 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     {   // The other context's frame may still be running on another stream.  Two single-chunk frames share nothing they
         // write except scheduling hints; anything else (counting pass, supersampling levels, ray tree, a cost map
         // about to be reallocated) runs alone.
-        xrt_scene::FrameCtx &O = s->frames[&F == &s->frames[0] ? 1 : 0];
-        const bool remap = fast && s->deepMeshes && (s->costMapPaths != (size_t)P || s->costMap.cap < (size_t)(R + 1) * (size_t)P);
-        if (O.pending && O.w.lastStream != st && (!fast || !O.fast || remap)) HIPCHECK(hipEventSynchronize(O.fast ? O.events[1] : O.done));
+        const bool remap = fast && s->deepMeshes && (s->costMapPaths != (size_t)framePaths || s->costMap.cap < (size_t)(R + 1) * (size_t)framePaths);
+        for (xrt_scene::FrameCtx &O : s->frames)
+            if (&O != &F && O.pending && O.w.lastStream != st && (!fast || !O.fast || remap)) HIPCHECK(hipEventSynchronize(O.fast ? O.events[1] : O.done));
         W.lastStream = st;
     }
     if (fast && s->deepMeshes && !s->noFeedback) {
-        const size_t need = (size_t)(R + 1) * (size_t)P;
-        if (s->costMapPaths != (size_t)P || s->costMap.cap < need) {   // new frame geometry: forget
+        const size_t need = (size_t)(R + 1) * (size_t)framePaths;
+        if (s->costMapPaths != (size_t)framePaths || s->costMap.cap < need) {   // new frame geometry: forget
             if ((rc = s->costMap.ensure(need))) return rc;
             HIPCHECK(hipMemsetAsync(s->costMap.p, 0, s->costMap.cap * sizeof(unsigned), st));
-            s->costMapPaths = (size_t)P;
+            s->costMapPaths = (size_t)framePaths;
         }
-        s->epoch++;
+        if (part == 0) s->epoch++;
     } else if (s->costMap.p) {
         s->costMap.release(); s->costMapPaths = 0;
     }
@@ -513,7 +527,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             HeavyArgs H;
             if (listLong && (k == 0 || !heap)) {
                 H.list = W.heavyList.p; H.count = hcnt + k; H.path = s->heavyPath;
-                if (feedback) { H.costMap = s->costMap.p + (size_t)k * P; H.epoch = s->epoch & 0xffffu; H.costThreshold = s->costT[k]; }
+                if (feedback) { H.costMap = s->costMap.p + (size_t)k * (size_t)framePaths + (size_t)partStart; H.epoch = s->epoch & 0xffffu; H.costThreshold = s->costT[k]; }
             }
             return H;
         };
@@ -562,7 +576,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             X.hitsPrev = hitsOf[prv]; X.slotPrev = slotOf[prv]; X.scntPrev = k >= 1 ? scnt + (k - 1) : nullptr; X.shadowHits = W.shadowHits.p;
             X.lvlA = W.lvlA.p; X.lvlB = W.lvlB.p; X.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
             if (k < R) X.heavy = heavy_for(k + 1);
-            if (feedback && hasClosest) { X.costOut = s->costMap.p + (size_t)k * P; X.epoch = s->epoch & 0xffffu; }
+            if (feedback && hasClosest) { X.costOut = s->costMap.p + (size_t)k * (size_t)framePaths + (size_t)partStart; X.epoch = s->epoch & 0xffffu; }
             launch_shade(S, V, X, st);
         }
         if (heap) launch_compose_tree(W.lvlA.p, W.lvlB.p, s->lvlAlpha.p, Pc, P, R, W.sampleColor.p, wantF32 ? W.sampleF32.p : nullptr, st);
@@ -604,7 +618,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             const size_t words = (size_t)cntStride + (size_t)qStride;
             if ((rc2 = W.cnts.ensure(words)) || (rc2 = ensure_pinned(words * sizeof(int) + nb2 + 64))) return rc2;
             unsigned *q = reinterpret_cast<unsigned *>(W.cnts.p + cntStride);
-            long long pathBase = 0, curChunk = chunkPaths;
+            long long pathBase = 0, curChunk = chunkPaths;   // (ray-tree frames are never split: partStart == 0)
             while (pathBase < total) {
                 const int Pc = (int)((total - pathBase) < curChunk ? (total - pathBase) : curChunk);
                 HIPCHECK(hipMemsetAsync(W.cnts.p, 0, words * sizeof(int), st));
@@ -645,8 +659,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         if (!fast || !W.cntsClean || W.cnts.p != cntsBefore) HIPCHECK(hipMemsetAsync(W.cnts.p, 0, W.cnts.cap * sizeof(int), st));
         W.cntsClean = false;
         for (int c = 0; c < nChunks; c++) {
-            const long long pathBase = (long long)c * chunkPaths;
-            const int Pc = (int)((total - pathBase) < chunkPaths ? (total - pathBase) : chunkPaths);
+            const long long localBase = (long long)c * chunkPaths, pathBase = partStart + localBase;
+            const int Pc = (int)((total - localBase) < chunkPaths ? (total - localBase) : chunkPaths);
             if ((rc2 = enqueue_chunk(gp, W.cnts.p + (size_t)c * cntStride, queuesBase + (size_t)c * qStride, Pc, pathBase))) return rc2;
             if (!fuseResolve && (rc2 = post(Pc, pathBase))) return rc2;
             if (nChunks > 1) {   // frames of more than MAX_CHUNK_PATHS rays: xrt_progress follows the chunks
@@ -677,7 +691,10 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // valid pixels of this shard
     unsigned long long &validPixels = F.validPixels;
     validPixels = 0;
-    for (long long t = g.shardRank; t < totalTiles; t += g.shardCount) {
+    const long long slot0 = partStart / (512LL * g.samples), slot1 = (partStart + firstPaths + 512LL * g.samples - 1) / (512LL * g.samples);   // tile slots of this part
+    for (long long sl = slot0; sl < slot1; sl++) {
+        const long long t = sl * g.shardCount + g.shardRank;
+        if (t >= totalTiles) break;
         int tx = (int)(t % g.tilesX), ty = (int)(t / g.tilesX);
         int w = g.width - tx * XRT_TILE_W; if (w > XRT_TILE_W) w = XRT_TILE_W;
         int h = g.height - ty * XRT_TILE_H; if (h > XRT_TILE_H) h = XRT_TILE_H;
@@ -816,6 +833,7 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
         }
         stats->ms_intersect = mi;
         stats->intersect_launches = (uint32_t)F.pairs.size();
+        stats->pieces = 1;
     }
     return XRT_OK;
 }
@@ -943,7 +961,17 @@ int multi_begin(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *
     return XRT_OK;
 }
 
-// Counters add up over the ranks; times are the slowest rank's (the frame's critical path).
+// Counters add up over the pieces of a frame (ranks, halves); times are the slowest piece's (the frame's critical path).
+void add_stats(xrt_stats &acc, const xrt_stats &st, bool first) {
+    uint64_t *a = reinterpret_cast<uint64_t *>(&acc);
+    const uint64_t *b = reinterpret_cast<const uint64_t *>(&st);
+    for (size_t k = 0; k < offsetof(xrt_stats, ms_total) / sizeof(uint64_t); k++) a[k] += b[k];
+    if (st.ms_total > acc.ms_total) acc.ms_total = st.ms_total;
+    if (st.ms_intersect > acc.ms_intersect) acc.ms_intersect = st.ms_intersect;
+    if (first) acc.intersect_launches = st.intersect_launches;
+    acc.pieces += 1;
+}
+
 int multi_end(xrt_scene *s, int slot, int n, xrt_stats *stats) {
     int rc = XRT_OK;
     xrt_stats acc;
@@ -955,12 +983,7 @@ int multi_end(xrt_scene *s, int slot, int n, xrt_stats *stats) {
         std::memset(&st, 0, sizeof(st));
         const int rci = frame_finish(r, r->frames[slot], &st);
         if (rci != XRT_OK) { rc = rci; continue; }
-        uint64_t *a = reinterpret_cast<uint64_t *>(&acc);
-        const uint64_t *b = reinterpret_cast<const uint64_t *>(&st);
-        for (size_t k = 0; k < offsetof(xrt_stats, ms_total) / sizeof(uint64_t); k++) a[k] += b[k];
-        if (st.ms_total > acc.ms_total) acc.ms_total = st.ms_total;
-        if (st.ms_intersect > acc.ms_intersect) acc.ms_intersect = st.ms_intersect;
-        if (i == 0) acc.intersect_launches = st.intersect_launches;
+        add_stats(acc, st, i == 0);
     }
     (void)hipSetDevice(s->device);
     if (rc == XRT_OK && stats) *stats = acc;
@@ -984,14 +1007,32 @@ int open_frame(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *l
         d_out = s->frameOut[slot].p;
     }
     hipStream_t st0 = nullptr;
+    int nParts = 1;
     if (n == 1) {
-        if ((rc = frame_begin(s, s->frames[slot], cam, lights, nLights, opts, d_out, d_outF32, st))) return rc;
+        // Two halves on two streams?  Only plain single-pass frames that run long enough for the drain of their launches to
+        // matter, on streams of the library's choosing; by default only when no other frame is in flight to fill the gaps.
+        const bool plain = opts->use_multisampling != XRT_MS_ADAPTIVE && !(s->host->arrays.anyTransparent && opts->max_reflections > 0) && !opts->collect_stats;
+        const long long px64 = (long long)px * (opts->use_multisampling == XRT_MS_FIXED16 ? 16 : 1) / (opts->shard_count > 1 ? opts->shard_count : 1);
+        const bool alone = !s->frames[slot ^ 1].pending;
+        if (!st && plain && !s->oneStream && s->splitMode > 0 && (s->splitMode == 2 || alone) && s->lastFrameMs >= s->splitMinMs &&
+            s->lastFrameMs >= s->overlapMinMs && px64 >= 8 * 8192 && px64 <= (long long)s->maxChunkPaths)
+            nParts = s->splitParts;
+        for (int j = 0; j < nParts; j++)
+            if ((rc = frame_begin(s, s->frames[slot + 2 * j], cam, lights, nLights, opts, d_out, d_outF32, st, j, nParts))) {
+                for (int i = 0; i < j; i++) (void)frame_finish(s, s->frames[slot + 2 * i], nullptr);
+                return rc;
+            }
         st0 = s->frames[slot].w.lastStream;
     } else if ((rc = multi_begin(s, slot, cam, lights, nLights, opts, d_out, &st0))) return rc;
     xrt_scene::OpenFrame &O = s->open[slot];
     O.nGpus = n;
+    O.nParts = nParts;
     O.tail = n > 1 || host_out != nullptr;
     if (O.tail) {   // work enqueued behind the frame's own kernels: its end is an event of its own
+        for (int j = 1; j < nParts; j++) {   // (the other half ends with an event on its last kernel)
+            xrt_scene::FrameCtx &Fj = s->frames[slot + 2 * j];
+            HIPCHECK(hipStreamWaitEvent(st0, Fj.fast ? Fj.events[1] : Fj.done, 0));
+        }
         if (host_out && px) HIPCHECK(hipMemcpyAsync(host_out, d_out, px * sizeof(uint32_t), hipMemcpyDeviceToHost, st0));   // CurrentTarget.SetData (RT:123)
         if (!s->tailDone[slot]) HIPCHECK(hipEventCreateWithFlags(&s->tailDone[slot], hipEventDisableTiming));
         HIPCHECK(hipEventRecord(s->tailDone[slot], st0));
@@ -1001,7 +1042,21 @@ int open_frame(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *l
 
 int close_frame(xrt_scene *s, int slot, xrt_stats *stats) {
     xrt_scene::OpenFrame &O = s->open[slot];
-    int rc = O.nGpus > 1 ? multi_end(s, slot, O.nGpus, stats) : frame_finish(s, s->frames[slot], stats);
+    int rc = XRT_OK;
+    if (O.nGpus > 1) rc = multi_end(s, slot, O.nGpus, stats);
+    else if (O.nParts <= 1) rc = frame_finish(s, s->frames[slot], stats);
+    else {
+        xrt_stats acc;
+        std::memset(&acc, 0, sizeof(acc));
+        for (int j = 0; j < O.nParts; j++) {
+            xrt_stats st;
+            std::memset(&st, 0, sizeof(st));
+            const int rcj = frame_finish(s, s->frames[slot + 2 * j], &st);
+            if (rcj != XRT_OK) rc = rcj;
+            else add_stats(acc, st, j == 0);
+        }
+        if (rc == XRT_OK && stats) *stats = acc;
+    }
     if (O.tail) {
         const hipError_t e = hipEventSynchronize(s->tailDone[slot]);
         if (e != hipSuccess && rc == XRT_OK) rc = fail(XRT_E_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
@@ -1141,6 +1196,9 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     s->device = device;
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
     s->fakeGpus = getenv("XRT_FAKE_GPUS") != nullptr;
+    if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
+    if (const char *e = getenv("XRT_SPLIT_MS")) s->splitMinMs = (float)atof(e);
+    if (const char *e = getenv("XRT_SPLIT_PARTS")) { const int v = atoi(e); if (v >= 2 && v <= 4) s->splitParts = v; }
     if (const char *e = getenv("XRT_CULL_SAFETY")) { const double v = atof(e); if (v >= 0.0 && v <= 1e6) s->hs.cullSafety = v; }   // development: factor S of the object pre-cull margin (below 2 the bound is no longer proven)
     s->noRectCull = getenv("XRT_NO_RECT_CULL") != nullptr; s->oneStream = getenv("XRT_ONE_STREAM") != nullptr; s->noFeedback = getenv("XRT_NO_FEEDBACK") != nullptr;
     if (const char *e = getenv("XRT_OVERLAP_MS")) s->overlapMinMs = (float)atof(e);   // 0: every single-chunk frame gets its context's stream
@@ -1274,7 +1332,7 @@ int xrt_render(xrt_scene *scene, const xrt_camera *camera, const xrt_light *ligh
     if (camera->vp_width <= 0 || camera->vp_height <= 0) return fail(XRT_E_INVALID_ARG, "viewport must be positive");
     const size_t px = (size_t)camera->vp_width * (size_t)camera->vp_height;
     if (rgb_f32_out && (rc = scene->outF32.ensure(px * 3))) return rc;
-    if ((rc = open_frame(scene, 0, camera, lights, n_lights, opts, nullptr, rgb_f32_out ? scene->outF32.p : nullptr, rgba_out, scene->stream))) return rc;
+    if ((rc = open_frame(scene, 0, camera, lights, n_lights, opts, nullptr, rgb_f32_out ? scene->outF32.p : nullptr, rgba_out, nullptr))) return rc;
     if ((rc = close_frame(scene, 0, stats_out))) return rc;
     if (rgb_f32_out) HIPCHECK(hipMemcpy(rgb_f32_out, scene->outF32.p, px * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return XRT_OK;
@@ -1317,8 +1375,7 @@ int xrt_render_device(xrt_scene *scene, const xrt_camera *camera, const xrt_ligh
     if (!camera || !opts || !d_rgba_out) return fail(XRT_E_INVALID_ARG, "xrt_render_device: null argument");
     BusyGuard guard(scene);
     if (!guard.owned || scene->frames[0].pending || scene->frames[1].pending) return fail(XRT_E_BUSY, "Current render operation not finished.");
-    hipStream_t st = stream ? (hipStream_t)stream : scene->stream;
-    if ((rc = open_frame(scene, 0, camera, lights, n_lights, opts, (uint32_t *)d_rgba_out, nullptr, nullptr, st))) return rc;
+    if ((rc = open_frame(scene, 0, camera, lights, n_lights, opts, (uint32_t *)d_rgba_out, nullptr, nullptr, (hipStream_t)stream))) return rc;
     return close_frame(scene, 0, stats_out);
 }
 
