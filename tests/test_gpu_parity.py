@@ -867,7 +867,7 @@ def test_frames_split_in_two_halves_on_two_streams(xrt, monkeypatch, split):
     the path).  Same frame, same fp32 colour vector, same accounting as the unsplit render -- for 1 and 16 sub-rays, odd sizes,
     host and device output, and (XRT_SPLIT=2) also for pipelined frames with four contexts busy."""
     import torch
-    for spec in (xrt.configs.crate_grid_scene(333, 190), xrt.configs.heightfield_scene(320, 180, m=96),
+    for spec in (xrt.configs.crate_grid_scene(413, 230), xrt.configs.heightfield_scene(400, 225, m=96),
                  xrt.configs.heightfield_scene(200, 120, m=64, multisampling=xrt.abi.MS_FIXED16)):
         monkeypatch.setenv("XRT_SPLIT", "0")
         _, ref_tracer = xrt.configs.build_product(spec)
@@ -900,6 +900,50 @@ def test_frames_split_in_two_halves_on_two_streams(xrt, monkeypatch, split):
         assert np.array_equal(outs[0].cpu().numpy().view(np.uint32), want)
         for k in ("XRT_SPLIT", "XRT_SPLIT_MS", "XRT_OVERLAP_MS"):
             monkeypatch.delenv(k)
+
+
+def test_wave_packet_kernel_against_the_oracle(xrt, orc, monkeypatch):
+    """k_packet (packet.hip): one wavefront walks the mesh octree once for 64 rays.  XRT_PACKET=15 routes every ray population
+    of a one-body scene through it -- seam-1 batches included, i.e. incoherent random rays, rays leaving surfaces with an
+    ignored triangle, axis-parallel, zero and non-finite rays: the worst case for a packet, and it must still give the
+    reference's answers bit for bit (hit triangle, leaf id, u/v/d, world position), for the scene query and the per-mesh query;
+    frames with 1 and 16 sub-rays equal the oracle's too."""
+    monkeypatch.setenv("XRT_PACKET", "15")
+    specs = {"h64": xrt.configs.heightfield_scene(160, 90, m=64), "h224": xrt.configs.heightfield_scene(160, 90, m=224),
+             "soup": soup_spec(xrt, 2000, 7, 20, 0.15), "soup_deep": soup_spec(xrt, 300, 5, 4, 0.5)}
+    t = xrt.configs.SceneSpec("crate5_rot")
+    t.meshes.append((xrt.fixtures.crate(5), xrt.configs.material(0.5)))
+    t.objects.append(([0], (3.0, -2.0, 5.0), (0.3, 1.1, -0.4), (1.0, 1.3, 0.8)))
+    t.camera = xrt.configs.camera((0, 32, 64), (0, 8, 0))
+    t.lights = [xrt.configs.spot((0, 40, 60))]
+    specs["crate5_rot"] = t.with_size(128, 72)
+    for name, spec in specs.items():
+        scene, tracer = xrt.configs.build_product(spec)
+        o = orc.OracleScene(spec)
+        prim = tracer.GeneratePrimaryRays()
+        sets = [prim, random_rays(xrt, 20000, 5, radius=60.0 if name.startswith("h") else 3.0)]
+        nan = float("nan")
+        sets.append(xrt.rays_array([(0, 50, 0), (0, 50, 0), (0, 50, 0), (1e30, 0, 0), (0, 50, 0), (0, 4.0, 0), (0, 2, 0), (1, 2, 1)] * 9,
+                                   [(0, 0, 0), (nan, -1, 0), (0, -1, 0), (-1, 0, 0), (1e-7, -1, 1e-7), (0, 1, 0), (1, 0, 0), (0, 0, -1)] * 9))
+        for rays in sets:
+            ho = o.intersect(rays)
+            assert hits_equal(ho, scene.IntersectBatch(rays)) == {}, name
+            sec = secondary_rays(xrt, ho, seed=4)
+            if len(sec):
+                assert hits_equal(o.intersect(sec), scene.IntersectBatch(sec)) == {}, name
+        if spec.mesh_threshold == 50:   # Mesh.Init builds with the reference's threshold (MO:42)
+            mesh = scene.meshes[0]
+            mesh.Init()
+            assert hits_equal(o.mesh_intersect(0, prim[::2]), mesh.Octree.IntersectBatch(prim[::2])) == {}, name
+        rgba, rgbf = tracer_render(tracer, 2)
+        o_rgba, o_rgbf, o_st = orc.OracleScene(spec_with(spec, 2)).render(nthreads=8)
+        assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+        for k in ("rays_closest", "rays_shadow", "hits_closest", "shaded_hits"):
+            assert tracer.last_stats[k] == o_st[k], (name, k)
+    spec = xrt.configs.heightfield_scene(96, 54, m=224, multisampling=xrt.abi.MS_FIXED16)
+    _, tracer = xrt.configs.build_product(spec)
+    o_rgba, _, _ = orc.OracleScene(spec).render(nthreads=8, want_float=False)
+    assert np.array_equal(tracer.Render(), o_rgba)
 
 
 def test_changing_frame_parameters_between_pipelined_frames(xrt):

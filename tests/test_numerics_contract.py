@@ -14,9 +14,8 @@ CSRC = os.path.join(ROOT, "xna-ray-trace_amd", "csrc")
 
 @pytest.fixture(scope="module")
 def isa():
-    out = os.path.join(CSRC, "kernels.s")
     subprocess.check_call(["make", "-s", "-C", CSRC, "asm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    return open(out).read()
+    return open(os.path.join(CSRC, "kernels.s")).read() + "\n" + open(os.path.join(CSRC, "packet.s")).read()
 
 
 def kernels(isa_text):
@@ -67,7 +66,7 @@ def f64_units():
 
 def test_no_contracted_fma_in_any_kernel(isa):
     ks = kernels(isa)
-    assert any("k_intersect" in k for k in ks) and any("k_shade" in k for k in ks)
+    assert any("k_intersect" in k for k in ks) and any("k_shade" in k for k in ks) and any("k_packet" in k for k in ks)
     for name, lines in ks.items():
         text = "\n".join(lines)
         assert not re.search(r"\bv_(mad|mac)_f32|\bv_pk_fma_f32|\bv_fma_mix", text), name
@@ -103,3 +102,15 @@ def test_hot_kernel_resources(isa):
             want = 160 * 1024 // ((int(cap) + 27) * 1024 + (512 if int(cap) < 40 else 0))
         budget = {4: 128, 3: 168, 2: 256}[want]   # where LDS already limits the waves per SIMD the compiler may use their registers
         assert int(vgprs) <= budget and int(scratch) == 0 and int(occ) >= want, (name, vgprs, scratch, occ)
+
+
+def test_packet_kernel_resources(isa):
+    """k_packet: no scratch, and an SGPR allocation within what packet_blocks_per_cu (packet.hip) sizes its grid for -- the
+    occupancy API over-reports resident blocks in the 81-112 SGPR range (MI355X_MICROARCH.md, Correctness boundaries)."""
+    usage = open(os.path.join(CSRC, "packet.usage.txt")).read()
+    src = open(os.path.join(CSRC, "packet.hip")).read()
+    budget = int(re.search(r"constexpr int PK_SGPRS = (\d+);", src).group(1))
+    blocks = re.findall(r"Function Name: (\S*k_packet\S*).*?TotalSGPRs: (\d+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", usage, flags=re.S)
+    assert len(blocks) == 2
+    for name, sgprs, vgprs, scratch in blocks:
+        assert int(sgprs) <= budget and int(vgprs) <= 72 and int(scratch) == 0, (name, sgprs, vgprs, scratch)

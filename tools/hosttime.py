@@ -9,8 +9,12 @@ scene, tracer = xrt.configs.build_product(spec)
 outs = [torch.zeros(spec.width * spec.height, dtype=torch.int32, device="cuda") for _ in range(2)]
 frs = [tracer.PrepareDevice(o.data_ptr()) for o in outs]
 fr = frs[0]
-for _ in range(5):
+for _ in range(3):
     fr()
+ts = [frs[0].begin(), frs[1].begin()]   # both frame contexts sized before the clock starts
+frs[0].end(ts[0]); frs[1].end(ts[1])
+ts = [frs[0].begin(), frs[1].begin()]
+frs[0].end(ts[0]); frs[1].end(ts[1])
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 tb = te = 0.0
 t0 = time.perf_counter()

@@ -1,0 +1,57 @@
+// device_util.h — small device helpers shared by kernels.hip and packet.hip (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/xrt.h"
+#include "traverse.h"
+
+namespace xrt {
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// OR of v over the 64 lanes (DPP row shifts + the two row broadcasts, result read from lane 63): wave-uniform
+__device__ __forceinline__ int wave_or(int v) {
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+struct alignas(16) Hit16 { int i0, i1, i2, i3; };
+
+__device__ __forceinline__ void store_hit(xrt_hit *dst, const HitOut &h) {
+    Hit16 *p = reinterpret_cast<Hit16 *>(dst);
+    p[0] = Hit16{h.hit, h.object, h.mesh, h.tri};
+    p[1] = Hit16{h.leaf, f2i(h.u), f2i(h.v), f2i(h.d)};
+    p[2] = Hit16{f2i(h.wx), f2i(h.wy), f2i(h.wz), h.cost};   // (reserved word: scheduling feedback)
+}
+__device__ __forceinline__ void load_ray(const xrt_ray *src, v3 &o, v3 &d, int &im, int &it) {
+    const f4 *p = reinterpret_cast<const f4 *>(src);
+    f4 a = p[0], b = p[1];
+    o = mk(a.x, a.y, a.z);
+    d = mk(a.w, b.x, b.y);
+    im = f2i(b.z);
+    it = f2i(b.w);
+}
+__device__ __forceinline__ void store_ray(xrt_ray *dst, v3 o, v3 d, int im, int it) {
+    f4 *p = reinterpret_cast<f4 *>(dst);
+    p[0] = f4{o.x, o.y, o.z, d.x};
+    p[1] = f4{d.y, d.z, i2f(im), i2f(it)};
+}
+constexpr int DEAD_RAY = -2;   // ignore_mesh marker of a path without a pixel (edge tiles)
+
+// "Long ray first" scheduling.  One ray that skims a large mesh takes thousands of dependent steps, and a launch ends
+// when its slowest ray does; started last, such a ray keeps a single wave alive long after the other 4095 have
+// left.  Producers (k_raygen, k_shade) therefore estimate a ray's length inside the scene's root box, list the long
+// ones and mark them in the ray record (bit 30 of ignore_tri set to the opposite of its sign bit); the traversal
+// kernel takes the listed rays first and passes over them when it meets them again in the array.  Scheduling only:
+// every ray is traced exactly once, by the same code.
+constexpr int HEAVY_BIT = 0x40000000;
+__device__ __forceinline__ bool heavy_marked(int ignoreTri) { return (((ignoreTri >> 30) ^ (ignoreTri >> 31)) & 1) != 0; }
+}  // namespace xrt

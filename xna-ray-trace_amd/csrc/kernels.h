@@ -51,6 +51,22 @@ struct IntersectArgs {
     int nMul2 = 0, nCap2 = 0;
 };
 
+// k_packet (packet.hip): one wavefront traces 64 consecutive rays of a coherent population together -- a shared walk of the
+// mesh octree with per-lane box / triangle tests.  Same answers as k_intersect (same tests, same arg-min rule).
+struct PacketArgs {
+    const xrt_ray *rays = nullptr;
+    xrt_hit *hits = nullptr;
+    const int *index = nullptr;   // optional compact list of ray indices
+    const int *nDev = nullptr;    // when non-null the ray count is (*nDev) * nMul, else n
+    int nMul = 1, n = 0, nCap = 0;
+    unsigned *queue = nullptr;    // zeroed work-queue word of this launch
+    int mode = MODE_SINGLE, meshId = 0;
+    int unmark = 0;               // rays may carry the long-ray mark of their producer (device_util.h)
+};
+bool packet_supported(int mode, int meshDepth);
+int  packet_blocks_per_cu(int mode);
+void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+
 // reference-work counters accumulated on the device (same order as the head of xrt_stats)
 enum { C_RAYS = 0, C_HITS, C_SCENE_NODES, C_INSTANCES, C_MESH_AABB, C_MESH_QUERIES, C_NODES, C_REFS, C_TRIS, C_COUNT };
 

@@ -17,15 +17,11 @@
 //
 // Built with -ffp-contract=off: every result must be bit-identical to the oracle.
 #include "kernels.h"
+#include "device_util.h"
 
 #include <hip/hip_ext.h>
 
 namespace xrt {
-
-__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
-__device__ __forceinline__ int lanes_below(unsigned long long m) {
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-}
 
 struct LdsStack {
     unsigned *base;   // &stk[wave][0][lane]
@@ -33,37 +29,6 @@ struct LdsStack {
     __device__ __forceinline__ void set(int i, unsigned v) { base[i * 64] = v; }
 };
 
-struct alignas(16) Hit16 { int i0, i1, i2, i3; };
-
-__device__ __forceinline__ void store_hit(xrt_hit *dst, const HitOut &h) {
-    Hit16 *p = reinterpret_cast<Hit16 *>(dst);
-    p[0] = Hit16{h.hit, h.object, h.mesh, h.tri};
-    p[1] = Hit16{h.leaf, f2i(h.u), f2i(h.v), f2i(h.d)};
-    p[2] = Hit16{f2i(h.wx), f2i(h.wy), f2i(h.wz), h.cost};   // (reserved word: scheduling feedback)
-}
-__device__ __forceinline__ void load_ray(const xrt_ray *src, v3 &o, v3 &d, int &im, int &it) {
-    const f4 *p = reinterpret_cast<const f4 *>(src);
-    f4 a = p[0], b = p[1];
-    o = mk(a.x, a.y, a.z);
-    d = mk(a.w, b.x, b.y);
-    im = f2i(b.z);
-    it = f2i(b.w);
-}
-__device__ __forceinline__ void store_ray(xrt_ray *dst, v3 o, v3 d, int im, int it) {
-    f4 *p = reinterpret_cast<f4 *>(dst);
-    p[0] = f4{o.x, o.y, o.z, d.x};
-    p[1] = f4{d.y, d.z, i2f(im), i2f(it)};
-}
-constexpr int DEAD_RAY = -2;   // ignore_mesh marker of a path without a pixel (edge tiles)
-
-// "Long ray first" scheduling.  One ray that skims a large mesh takes thousands of dependent steps, and a launch ends
-// when its slowest ray does; started last, such a ray keeps a single wave alive long after the other 4095 have
-// left.  Producers (k_raygen, k_shade) therefore estimate a ray's length inside the scene's root box, list the long
-// ones and mark them in the ray record (bit 30 of ignore_tri set to the opposite of its sign bit); the traversal
-// kernel takes the listed rays first and passes over them when it meets them again in the array.  Scheduling only:
-// every ray is traced exactly once, by the same code.
-constexpr int HEAVY_BIT = 0x40000000;
-__device__ __forceinline__ bool heavy_marked(int ignoreTri) { return (((ignoreTri >> 30) ^ (ignoreTri >> 31)) & 1) != 0; }
 __device__ __forceinline__ bool predict_heavy(const SceneView &S, v3 o, v3 d, float heavyPath) {
     const f4 lo = S.snodes[0], hi = S.snodes[1];
     float tmin = 0.0f, tmax = FLT_MAX;
@@ -605,8 +570,10 @@ __device__ __forceinline__ bool path_pixel(const RayGenParams &g, long long pix,
     if (t >= (long long)g.tilesX * g.tilesY) return false;
     const unsigned ti = (unsigned)t;   // tilesX * tilesY < 2^31: one 32-bit division instead of two 64-bit ones
     const int ty = (int)(ti / (unsigned)g.tilesX), tx = (int)(ti - (unsigned)ty * (unsigned)g.tilesX);
-    x = tx * XRT_TILE_W + (within & 63);
-    y = ty * XRT_TILE_H + (within >> 6);
+    int wx, wy;
+    tile_slot_xy(within, wx, wy);
+    x = tx * XRT_TILE_W + wx;
+    y = ty * XRT_TILE_H + wy;
     return x < g.width && y < g.height;
 }
 
@@ -1176,7 +1143,9 @@ __global__ __launch_bounds__(256) void k_detile(int width, int height, int shard
         long long t = slot * shardCount + rank;
         if (t >= (long long)tilesX * tilesY) continue;
         const unsigned ti = (unsigned)t, tyq = ti / (unsigned)tilesX;
-        int x = (int)(ti - tyq * (unsigned)tilesX) * XRT_TILE_W + (within & 63), y = (int)tyq * XRT_TILE_H + (within >> 6);
+        int wx, wy;
+        tile_slot_xy(within, wx, wy);
+        int x = (int)(ti - tyq * (unsigned)tilesX) * XRT_TILE_W + wx, y = (int)tyq * XRT_TILE_H + wy;
         if (x < width && y < height) out[(size_t)y * width + x] = gathered[(long long)rank * rankStride + rem];
     }
 }

@@ -246,8 +246,8 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
         A.objects.push_back(r);
     }
     // never hand out empty arrays (a zero-size allocation has no address)
-    if (A.refN.empty()) A.refN.assign(1, f4{0, 0, 0, i2f(-1)});
-    if (A.refG.empty()) A.refG.assign(3, g3{0, 0, 0});
+    // two dummy references at the end: the wave-packet kernel requests the next triangle's record before it knows the leaf has ended
+    for (int k = 0; k < 2; k++) { A.refN.push_back(f4{0, 0, 0, i2f(-1)}); for (int j = 0; j < 3; j++) A.refG.push_back(g3{0, 0, 0}); }
     if (A.srefs.empty()) A.srefs.assign(1, -1);
     if (A.objMesh.empty()) A.objMesh.assign(1, -1);
     if (A.shade.empty()) A.shade.assign(SHADE_F4, f4{0, 0, 0, 0});

@@ -147,13 +147,49 @@ XRT_HD int hit8_fast(const RayPre &r, int dmask, v3 pmin, v3 half) {
     }
     return m;
 }
+// hit8_fast with the answer indexed by child: bit c <-> child c (the wave-packet kernel shares one visiting order
+// among lanes whose front-to-back orders differ).
+XRT_HD int hit8_fast_children(const RayPre &r, int dmask, v3 pmin, v3 half) {
+    const float x0 = pmin.x + half.x * 0.0f, x1 = pmin.x + half.x * 1.0f, x2 = x1 + half.x;
+    const float y0 = pmin.y + half.y * 0.0f, y1 = pmin.y + half.y * 1.0f, y2 = y1 + half.y;
+    const float z0 = pmin.z + half.z * 0.0f, z1 = pmin.z + half.z * 1.0f, z2 = z1 + half.z;
+    const float tx0 = (x0 - r.o.x) * r.inv.x, tx1 = (x1 - r.o.x) * r.inv.x, tx2 = (x2 - r.o.x) * r.inv.x;
+    const float ty0 = (y0 - r.o.y) * r.inv.y, ty1 = (y1 - r.o.y) * r.inv.y, ty2 = (y2 - r.o.y) * r.inv.y;
+    const float tz0 = (z0 - r.o.z) * r.inv.z, tz1 = (z1 - r.o.z) * r.inv.z, tz2 = (z2 - r.o.z) * r.inv.z;
+    const bool nx = (dmask & 4) != 0, ny = (dmask & 2) != 0, nz = (dmask & 1) != 0;
+    const float nearX[2] = {nx ? tx1 : tx0, nx ? tx2 : tx1}, farX[2] = {nx ? tx0 : tx1, nx ? tx1 : tx2};
+    const float nearY[2] = {ny ? ty1 : ty0, ny ? ty2 : ty1}, farY[2] = {ny ? ty0 : ty1, ny ? ty1 : ty2};
+    const float nearZ[2] = {nz ? tz1 : tz0, nz ? tz2 : tz1}, farZ[2] = {nz ? tz0 : tz1, nz ? tz1 : tz2};
+    int m = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int i = (c >> 2) & 1, j = (c >> 1) & 1, k = c & 1;
+        const float num = fmaxf(fmaxf(fmaxf(nearX[i], 0.0f), nearY[j]), nearZ[k]);
+        const float num2 = fminf(fminf(fminf(farX[i], FLT_MAX), farY[j]), farZ[k]);
+        if (!(num > num2)) m |= 1 << c;
+    }
+    return m;
+}
+// The same decisions with the literal box test (a ray with a parallel axis or a non-finite component, MO:331).
+XRT_HD int hit8_slow_children(const RayPre &r, v3 pmin, v3 half) {
+    int m = 0;
+    for (int c = 0; c < 8; c++) {
+        v3 cmin, cmax;
+        child_box(pmin, half, c, cmin, cmax);
+        float key;
+        if (slab(r, cmin.x, cmin.y, cmin.z, cmax.x, cmax.y, cmax.z, key)) m |= 1 << c;
+    }
+    return m;
+}
 XRT_HD bool is_finite(float x) { return fabsf(x) <= FLT_MAX; }
 XRT_HD int child_ref_offset(unsigned long long offLo, unsigned long long offHi, int c) {
     unsigned long long w = (c & 4) ? offHi : offLo;
     return (int)((w >> (16 * (c & 3))) & 0xffffull);
 }
 
-XRT_HD void begin_mesh_query(Lane &L, const SceneView &S, int mesh) {
+// enter == false (the wave-packet kernel, packet.hip): stop after the root's own box test -- state ST_NODE then only says
+// "the ray is inside the root box of an interior root"; the packet enters the root block itself.
+XRT_HD void begin_mesh_query(Lane &L, const SceneView &S, int mesh, bool enter = true) {
     const MeshRec &mr = S.meshes[mesh];
     L.mesh = mesh;
     L.sp = 0;
@@ -170,6 +206,7 @@ XRT_HD void begin_mesh_query(Lane &L, const SceneView &S, int mesh) {
         }
         return;
     }
+    if (!enter) return;
     L.bmin = mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]);
     L.half = half_of(L.bmin, mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]));
     load_block(L, S, mr.rootBlock);
@@ -179,7 +216,7 @@ XRT_HD void begin_mesh_query(Lane &L, const SceneView &S, int mesh) {
 
 // Start of a query.  ignore (mesh, tri) is the `ignoreTriangle` identity (MO:290).
 template <class SC>
-XRT_HD void lane_begin(Lane &L, SC &C, const SceneView &S, v3 o, v3 d, int ignoreMesh, int ignoreTri, int rayIndex, int mode, int meshId) {
+XRT_HD void lane_begin(Lane &L, SC &C, const SceneView &S, v3 o, v3 d, int ignoreMesh, int ignoreTri, int rayIndex, int mode, int meshId, bool enter = true) {
     L.rayIndex = rayIndex;
     L.cost = 0;
     L.weird = (is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(d.x) && is_finite(d.y) && is_finite(d.z)) ? 0 : 1;
@@ -224,14 +261,14 @@ XRT_HD void lane_begin(Lane &L, SC &C, const SceneView &S, v3 o, v3 d, int ignor
         const MeshRec &mr = S.meshes[0];
         float k;
         if (!slab(L.r, mr.bmin[0], mr.bmin[1], mr.bmin[2], mr.bmax[0], mr.bmax[1], mr.bmax[2], k)) return;
-        begin_mesh_query(L, S, 0);
+        begin_mesh_query(L, S, 0, enter);
     } else {
         L.r = make_ray(o, d);
         C.w = L.r;
         L.dmask = dir_mask(d);
         C.sblk = 0; C.smask = 0;
         C.obj = -1;
-        begin_mesh_query(L, S, meshId);
+        begin_mesh_query(L, S, meshId, enter);
     }
 }
 

@@ -91,7 +91,13 @@ struct xrt_scene {
     bool resident = false;
     int numCUs = 256;
     int stackNeeded = 2;
-    int blocksPerCU = 1, blocksPerCUMesh = 1;
+    int blocksPerCU = 1, blocksPerCUMesh = 1, blocksPerCUPacket = 1;
+    bool packetOk = false;   // the scene's rays can take the wave-packet kernel (one body, one mesh with a real octree)
+    // Which ray populations take the wave-packet kernel.  -1 (default): all three of a frame with 16 sub-rays per pixel -- a wave
+    // then holds 4 pixels x 16 samples, rays that visit the same leaves (measured on the 1M-triangle frame: 7.3 against 11.1 ms);
+    // none otherwise (64 pixels of a 1-sample frame fan out over too many leaves: 5 x slower than the per-lane kernel).
+    // XRT_PACKET=<mask> forces it: bit 0 primary rays, 1 shadow rays, 2 closest-hit rays of later generations, 3 seam-1 batches.
+    int packetMask = -1;
     int sceneMode = MODE_SCENE;   // MODE_SINGLE when the scene is one SceneObject with one Mesh
     hipStream_t stream = nullptr;
     // per-frame work buffers
@@ -437,7 +443,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         return rc;
     if (wantF32 && (rc = W.sampleF32.ensure((size_t)P * 3))) return rc;
     const int cntStride = 3 * (R + 2);          // per chunk: cnt[R+2], scnt[R+2], then the long-ray list lengths [R+2]
-    const int qStride = 2 * (R + 1);
+    constexpr int QW = 3;   // per launch step k: the lane kernel's queue word and one for each packet launch (closest, shadow)
+    const int qStride = QW * (R + 2);
     // The common frame (one chunk, no supersampling levels, no ray tree, no counting pass) puts nothing but its kernels
     // on the stream: counters come back through k_compose's epilogue and the frame's events ride on raygen / compose.
     const bool fast = !adaptive && !heap && firstPaths <= chunkPaths && !opts->collect_stats;
@@ -523,9 +530,14 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         // "long ray first" (kernels.hip): the producer of generation k lists its long rays, launch #k takes them first
         const bool feedback = fast && s->deepMeshes && s->costMap.p != nullptr;
         const bool listLong = s->heavyPath > 0.0f || feedback;
+        // which segments the wave-packet kernel traces (coherent populations; packet.hip): bit 0 primary rays, bit 1 shadow
+        // rays, bit 2 the closest-hit rays of later generations
+        const int pkMask = s->packetMask >= 0 ? s->packetMask : (gp.samples >= 16 ? 7 : 0);
+        auto packet_closest = [&](int k) { return s->packetOk && !heap && (k == 0 ? (pkMask & 1) : (pkMask & 4)) != 0; };
+        const bool packetShadow = s->packetOk && !heap && (pkMask & 2) != 0;
         auto heavy_for = [&](int k) {
             HeavyArgs H;
-            if (listLong && (k == 0 || !heap)) {
+            if (listLong && (k == 0 || !heap) && !packet_closest(k)) {   // (packets are not scheduled ray by ray)
                 H.list = W.heavyList.p; H.count = hcnt + k; H.path = s->heavyPath;
                 if (feedback) { H.costMap = s->costMap.p + (size_t)k * (size_t)framePaths + (size_t)partStart; H.epoch = s->epoch & 0xffffu; H.costThreshold = s->costT[k]; }
             }
@@ -547,21 +559,38 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             B.rays = W.shadowRays.p; B.hits = W.shadowHits.p; B.index = nullptr; B.nDev = hasShadow ? scnt + (k - 1) : nullptr; B.nMul = nL; B.n = 0;
             B.nCap = (int)((long long)shadowCap * nL);
             for (IntersectArgs *a : {&C, &B}) {
-                a->queue = q + k; a->mode = s->sceneMode; a->meshId = 0;
+                a->queue = q + QW * k; a->mode = s->sceneMode; a->meshId = 0;
                 a->refillMin = s->tune[0]; a->nodeBurst = s->tune[1]; a->leafBurst = s->tune[2]; a->coopMax = s->tune[3]; a->firstBatch = s->firstBatch;
             }
-            if (hasClosest || hasShadow) {
-                IntersectArgs A = hasClosest ? C : B;
-                if (hasClosest && hasShadow) { A.rays2 = B.rays; A.hits2 = B.hits; A.nDev2 = B.nDev; A.nMul2 = B.nMul; A.nCap2 = B.nCap; }
+            // segments of coherent rays go to the wave-packet kernel, the others (together, one launch) to the per-lane kernel
+            const bool pkC = hasClosest && packet_closest(k), pkB = hasShadow && packetShadow;
+            auto launch_pk = [&](const IntersectArgs &I, int word, long long nHost) -> int {
+                PacketArgs PA;
+                PA.rays = I.rays; PA.hits = I.hits; PA.index = I.index; PA.nDev = I.nDev; PA.nMul = I.nMul; PA.n = I.n; PA.nCap = I.nCap;
+                PA.queue = q + QW * k + 1 + word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0;
+                hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
+                if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
+                pairs.push_back({ev, ev + 1}); ev += 2;
+                int grid = s->numCUs * s->blocksPerCUPacket;
+                if (nHost >= 0) { const long long want = (nHost + 255) / 256; if (want < grid) grid = (int)(want < 1 ? 1 : want); }
+                launch_packet(S, PA, grid, st, a0, a1);
+                return XRT_OK;
+            };
+            if (pkC && (rc = launch_pk(C, 0, k == 0 ? Pc : -1))) return rc;
+            if (pkB && (rc = launch_pk(B, 1, -1))) return rc;
+            const bool laneC = hasClosest && !pkC, laneB = hasShadow && !pkB;
+            if (laneC || laneB) {
+                IntersectArgs A = laneC ? C : B;
+                if (laneC && laneB) { A.rays2 = B.rays; A.hits2 = B.hits; A.nDev2 = B.nDev; A.nMul2 = B.nMul; A.nCap2 = B.nCap; }
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 pairs.push_back({ev, ev + 1}); ev += 2;
                 if (s->waveTimes.p && k < 16) A.debugTimes = s->waveTimes.p + (size_t)k * 3 * 8192;
                 launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st, a0, a1);
-                if (opts->collect_stats) {   // generation 0: the live list; culled rays are added in frame_finish
-                    if (hasClosest) launch_count(S, C, s->counters.p, st);
-                    if (hasShadow) launch_count(S, B, s->counters.p + C_COUNT, st);
-                }
+            }
+            if ((hasClosest || hasShadow) && opts->collect_stats) {   // generation 0: the live list; culled rays are added in frame_finish
+                if (hasClosest) launch_count(S, C, s->counters.p, st);
+                if (hasShadow) launch_count(S, B, s->counters.p + C_COUNT, st);
             }
             ShadeArgs X;
             std::memset(&X, 0, sizeof(X));
@@ -851,7 +880,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1070,13 +1099,13 @@ int close_frame(xrt_scene *s, int slot, xrt_stats *stats) {
 int queue_word_for(xrt_scene *s, hipStream_t st, unsigned **word) {
     constexpr size_t MAX_STREAMS = 1024;
     int rc;
-    if ((rc = s->queues.ensure(MAX_STREAMS))) return rc;
+    if ((rc = s->queues.ensure(MAX_STREAMS * 2))) return rc;
     auto it = s->queueOfStream.find(st);
     if (it == s->queueOfStream.end()) {
         if (s->queueOfStream.size() >= MAX_STREAMS) return fail(XRT_E_UNSUPPORTED, "xrt_scene_intersect_device: more than %zu distinct streams on one scene", MAX_STREAMS);
         it = s->queueOfStream.emplace(st, (int)s->queueOfStream.size()).first;
     }
-    *word = s->queues.p + it->second;
+    *word = s->queues.p + (size_t)it->second * 2;   // word 0: k_intersect's queue head, word 1: k_packet's
     return XRT_OK;
 }
 
@@ -1089,7 +1118,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
     if ((rc = queue_word_for(s, st, &queue)) || (rc = s->counters.ensure(2 * C_COUNT + 8))) return rc;
     // the reference-work counters are shared with the frames' counting pass: exact counts need the scene to itself
     if (stats && in_flight(s)) return fail(XRT_E_BUSY, "xrt_scene_intersect with stats while a render is in flight");
-    HIPCHECK(hipMemsetAsync(queue, 0, sizeof(unsigned), st));
+    HIPCHECK(hipMemsetAsync(queue, 0, 2 * sizeof(unsigned), st));
     IntersectArgs A;
     A.rays = d_rays; A.hits = d_hits; A.index = nullptr; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.nCap = 0; A.queue = queue; A.mode = mode; A.meshId = meshId;
     A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.coopMax = s->tune[3]; A.firstBatch = s->firstBatch;
@@ -1099,7 +1128,15 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
         if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
         HIPCHECK(hipMemsetAsync(s->counters.p, 0, 2 * C_COUNT * sizeof(unsigned long long), st));
     }
-    if (n > 0) launch_intersect(s->view, A, s->stackNeeded, persistent_grid(s, n), st, a0, a1);
+    const bool meshOk = mode != MODE_MESH || (meshId >= 0 && meshId < (int)s->host->meshTrees.size() && !s->host->meshTrees[(size_t)meshId].rootIsLeaf);
+    if (n > 0 && s->packetMask >= 0 && (s->packetMask & 8) && mode != MODE_SCENE && packet_supported(mode, s->host->arrays.meshDepth) && meshOk) {   // (testing aid: arbitrary batches through the packet kernel)
+        PacketArgs PA;
+        PA.rays = d_rays; PA.hits = d_hits; PA.n = (int)n; PA.queue = queue + 1; PA.mode = mode; PA.meshId = meshId;
+        int grid = s->numCUs * packet_blocks_per_cu(mode);
+        const long long want = (n + 255) / 256;
+        if (want < grid) grid = (int)want;
+        launch_packet(s->view, PA, grid, st, a0, a1);
+    } else if (n > 0) launch_intersect(s->view, A, s->stackNeeded, persistent_grid(s, n), st, a0, a1);
     if (stats) {
         if (n > 0) launch_count(s->view, A, s->counters.p, st);
     }
@@ -1143,6 +1180,8 @@ int scene_upload(xrt_scene *scene) {
     if (getenv("XRT_NO_SINGLE")) scene->sceneMode = MODE_SCENE;
     scene->blocksPerCU = intersect_blocks_per_cu(scene->stackNeeded, scene->sceneMode);
     scene->blocksPerCUMesh = intersect_blocks_per_cu(scene->stackNeeded, MODE_MESH);
+    scene->packetOk = packet_supported(scene->sceneMode, A.meshDepth);
+    scene->blocksPerCUPacket = packet_blocks_per_cu(scene->sceneMode);
     scene->firstBatch = (A.meshDepth == 0) ? 256 : 64;   // every mesh is a single leaf: rays are cheap, avoid queue traffic
     if (const char *e = getenv("XRT_FIRST_BATCH")) { int v = atoi(e); if (v >= 64 && v <= 4096 && v % 64 == 0) scene->firstBatch = v; }
     {   // "long ray first": worth it only where rays can be long, i.e. where some mesh has a real octree
@@ -1196,6 +1235,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     s->device = device;
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
     s->fakeGpus = getenv("XRT_FAKE_GPUS") != nullptr;
+    if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 15) s->packetMask = v; }
     if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
     if (const char *e = getenv("XRT_SPLIT_MS")) s->splitMinMs = (float)atof(e);
     if (const char *e = getenv("XRT_SPLIT_PARTS")) { const int v = atoi(e); if (v >= 2 && v <= 4) s->splitParts = v; }
@@ -1450,7 +1490,9 @@ int xrt_generate_primary_rays(xrt_scene *scene, const xrt_camera *camera, xrt_ra
     for (long long i = 0; i < slots; i++) {   // tile order -> row-major
         long long t = i >> 9;
         int within = (int)(i & 511);
-        int x = (int)(t % g.tilesX) * XRT_TILE_W + (within & 63), y = (int)(t / g.tilesX) * XRT_TILE_H + (within >> 6);
+        int wx, wy;
+        tile_slot_xy(within, wx, wy);
+        int x = (int)(t % g.tilesX) * XRT_TILE_W + wx, y = (int)(t / g.tilesX) * XRT_TILE_H + wy;
         if (x < g.width && y < g.height) rays_out[(size_t)y * g.width + x] = tmp[(size_t)i];
     }
     return XRT_OK;

@@ -116,6 +116,16 @@ struct LightRec {       // 64 B
     int    pad0, pad1;
 };
 
+// Position of path slot `within` (0..511) inside its 64x8-pixel tile.  A wavefront takes 64 consecutive slots; laid out as
+// eight 8x8-pixel blocks side by side they cover a square patch of the image instead of a 64-pixel line, so the 64 rays of a
+// wave stay close together in the scene (fewer distinct octree leaves per wave, for the per-lane and the wave-packet kernel
+// alike).  Every kernel, the host's ray export and the tile-shard layout (xrt.h XRT_TILE_*, dist.py) use this one map.
+XRT_HD void tile_slot_xy(int within, int &x, int &y) {
+    const int blk = within >> 6, i = within & 63;
+    x = blk * 8 + (i & 7);
+    y = i >> 3;
+}
+
 // ---- Vector3 (XNA definitions) ---------------------------------------------------------
 XRT_HD v3 mk(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
 XRT_HD v3 add(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -201,14 +211,39 @@ XRT_HD bool slab(const RayPre &r, float mnx, float mny, float mnz, float mxx, fl
 
 // RayExtensions.IntersectsTriangleBackfaceCulling (RE:42-75), split at the back-face test.
 XRT_HD float facing(v3 N, v3 D) { return (N.x * D.x + N.y * D.y) + N.z * D.z; }   // RE:49; culled when > 0 (RE:50)
-XRT_HD bool tri_test_front(v3 O, v3 D, v3 v1, v3 E1, v3 E2, float &u, float &v, float &dist) {
-    v3 T = mk(O.x - v1.x, O.y - v1.y, O.z - v1.z);    // RE:46
+// The reference divides first and tests afterwards: (distance, u, v) = inv * (row1, row2, row3), inv = 1f / det, accepted when all
+// three are >= 0 and u + v <= 1 (RE:66-74).  A product fl(a * inv) is certainly negative -- so the triangle is certainly rejected --
+// when a and det have opposite sign bits and the product can neither underflow to (-)0, which compares >= 0, nor be a NaN:
+// sign(inv) == sign(det) always (1f / +-0 = +-inf), |det| <= 2^60 keeps |inv| >= 2^-61, |a| >= 2^-60 then keeps |a * inv| >= 2^-121,
+// far above the smallest subnormal, and the comparisons are false for NaNs.  Most rejected triangles are rejected by the sign of
+// u alone, before the second cross product, two dot products and the division; the accepted ones get the reference's arithmetic.
+XRT_HD bool certainly_negative(float a, float det) {
+    return ((f2i(a) ^ f2i(det)) < 0) && fabsf(a) >= 8.6736174e-19f /* 2^-60 */ && fabsf(det) <= 1.1529215e18f /* 2^60 */;
+}
+// Stage A: everything up to the sign of u.  Returns false when the triangle is certainly rejected (u < 0).
+XRT_HD bool tri_stage_a(v3 O, v3 D, v3 v1, v3 E1, v3 E2, v3 &T, float &det, float &row2) {
+    T = mk(O.x - v1.x, O.y - v1.y, O.z - v1.z);      // RE:46
     v3 P = cross(D, E2);                              // RE:58
+    det = dot(P, E1);                                 // RE:66 (the divisor)
+    row2 = dot(P, T);                                 // RE:63
+    return !certainly_negative(row2, det);            // u < 0
+}
+// Stage B: the rest of RE:59-74 for a triangle that survived stage A.
+XRT_HD bool tri_stage_b(v3 D, v3 E1, v3 E2, v3 T, float det, float row2, float &u, float &v, float &dist) {
+    u = 0.0f; v = 0.0f; dist = 0.0f;
     v3 Q = cross(T, E1);                              // RE:59
-    float row1 = dot(Q, E2), row2 = dot(P, T), row3 = dot(Q, D);   // RE:62-64
-    float inv = 1.0f / dot(P, E1);                    // RE:66
+    const float row3 = dot(Q, D);                     // RE:64
+    const float row1 = dot(Q, E2);                    // RE:62
+    if (certainly_negative(row3, det) || certainly_negative(row1, det)) return false;   // v < 0 or distance < 0
+    float inv = 1.0f / det;                           // RE:66
     dist = row1 * inv; u = row2 * inv; v = row3 * inv;
     return u >= 0.0f && v >= 0.0f && dist >= 0.0f && (u + v) <= 1.0f;   // RE:71-74
+}
+XRT_HD bool tri_test_front(v3 O, v3 D, v3 v1, v3 E1, v3 E2, float &u, float &v, float &dist) {
+    u = 0.0f; v = 0.0f; dist = 0.0f;
+    v3 T; float det, row2;
+    if (!tri_stage_a(O, D, v1, E1, E2, T, det, row2)) return false;
+    return tri_stage_b(D, E1, E2, T, det, row2, u, v, dist);
 }
 
 // ---- Color (RT:584,705,726,732) ---------------------------------------------------------------------------

@@ -23,6 +23,16 @@ def shard_layout(width, height, world):
     return tx, ty, (tx * ty + world - 1) // world
 
 
+def _tile_to_slots(tile):
+    """(TILE_H, TILE_W) pixels -> the 512 path slots of a tile: eight 8x8-pixel blocks side by side, each row-major
+    (xrt_core.h tile_slot_xy)."""
+    return tile.reshape(abi.TILE_H, abi.TILE_W // 8, 8).transpose(1, 0, 2).reshape(-1)
+
+
+def _slots_to_tile(slots):
+    return slots.reshape(abi.TILE_W // 8, abi.TILE_H, 8).transpose(1, 0, 2).reshape(abi.TILE_H, abi.TILE_W)
+
+
 def pack_shard(frame, width, height, rank, world):
     """Host mirror of what xrt_render_device writes for a shard: frame (H*W uint32) -> this rank's
     tile-contiguous buffer (tiles_per_rank*512).  Used by the CPU (gloo) tests."""
@@ -37,7 +47,7 @@ def pack_shard(frame, width, height, rank, world):
         tile = np.zeros((abi.TILE_H, abi.TILE_W), dtype=np.uint32)
         h, w = min(abi.TILE_H, height - y0), min(abi.TILE_W, width - x0)
         tile[:h, :w] = img[y0:y0 + h, x0:x0 + w]
-        out[slot * 512:(slot + 1) * 512] = tile.reshape(-1)
+        out[slot * 512:(slot + 1) * 512] = _tile_to_slots(tile)
     return out
 
 
@@ -46,7 +56,7 @@ def detile_host(gathered, width, height, world, rank_stride=0, offset=0):
     tx, ty, tpr = shard_layout(width, height, world)
     flat = np.asarray(gathered, dtype=np.uint32).reshape(-1)
     stride = rank_stride or tpr * 512
-    g = np.stack([flat[offset + r * stride: offset + r * stride + tpr * 512] for r in range(world)]).reshape(world, tpr, abi.TILE_H, abi.TILE_W)
+    g = np.stack([flat[offset + r * stride: offset + r * stride + tpr * 512] for r in range(world)]).reshape(world, tpr, 512)
     img = np.zeros((height, width), dtype=np.uint32)
     for rank in range(world):
         for slot in range(tpr):
@@ -55,7 +65,7 @@ def detile_host(gathered, width, height, world, rank_stride=0, offset=0):
                 break
             x0, y0 = (t % tx) * abi.TILE_W, (t // tx) * abi.TILE_H
             h, w = min(abi.TILE_H, height - y0), min(abi.TILE_W, width - x0)
-            img[y0:y0 + h, x0:x0 + w] = g[rank, slot, :h, :w]
+            img[y0:y0 + h, x0:x0 + w] = _slots_to_tile(g[rank, slot])[:h, :w]
     return img.reshape(-1)
 
 
