@@ -7,8 +7,8 @@ One step = one frame of the workload: every pixel's CastRay tree (closest-hit, s
 queries).  Default workload is the configuration BASELINE.json quotes its target on and which fits one GPU:
 C5 = the 1M-triangle mesh at 1920x1080, depth 3, 16 sub-rays per pixel; C2 / C3 / C4 are reported as short side
 measurements in "other_configs" at N=1.  The `roofline` block carries three fractions of the dominant kernel
-(k_intersect) -- reference-algorithm bytes, measured HBM traffic and VALU issue (the latter two from the
-committed rocprofv3 PMC passes of THIS build, profiles/pmc_k_intersect.json, divided by launch durations measured live
+(the traversal launches: k_packet / k_intersect) -- reference-algorithm bytes, measured HBM traffic and VALU issue (the latter two from the
+committed rocprofv3 PMC passes of THIS build, profiles/pmc_traversal.json, divided by launch durations measured live
 with HIP events) -- and names as `bound` whichever physical limit is closest.
 For N > 1 the driver starts one process per GPU (torch.distributed.run); the frame is sharded by 64x8 image
 tiles (total work fixed -> "strong" scaling), each rank renders its tiles from its own scene replica, and the
@@ -48,7 +48,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 # 2 cycles on a SIMD-32 with >= 2 waves resident, chip table "Max clock 2400 MHz") = 78.6 T lane-operations per second
 # (= the 157.3 TFLOP/s vector peak, which counts a fused multiply-add as two; this path is built with contraction off)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-KERNEL_SOURCES = ("kernels.hip", "kernels.h", "traverse.h", "xrt_core.h")
+SCALAR_PEAK_TINST = 256 * 2.4e9 / 1e12   # one scalar-unit instruction per cycle per CU (empirical)
+KERNEL_SOURCES = ("kernels.hip", "packet.hip", "kernels.h", "device_util.h", "traverse.h", "xrt_core.h")
 
 
 def build_id():
@@ -64,7 +65,7 @@ def load_pmc(config):
     """Per-launch PMC averages of k_intersect for `config` (tools/pmc_collect.py, separate rocprofv3 --pmc passes), or None
     when the committed file was taken on another build of the kernel."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_intersect.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traversal.json")))
     except Exception:
         return None
     if pmc.get("build_id") != build_id():
@@ -315,7 +316,7 @@ def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_fra
     fr = {"algorithmic": {"achieved": round(alg, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / HBM_PEAK_GBS, 4),
                           "bytes_per_launch": int(alg_bytes_per_launch), "what": "reference-algorithm bytes (SURVEY 8d), an equivalent rate: may exceed 1"}}
     traffic = None
-    bound, top = "unmeasured (no PMC pass of this kernel build in profiles/pmc_k_intersect.json)", None
+    bound, top = "unmeasured (no PMC pass of this kernel build in profiles/pmc_traversal.json)", None
     if pmc and t > 0:
         traffic = int((2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024)
         hbm = traffic / t / 1e9
@@ -326,11 +327,20 @@ def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_fra
                       "issue_frac": round(issue / VALU_PEAK_TLANEOPS, 4), "lane_utilisation": round(pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_INSTS_VALU"] * 64.0), 3),
                       "valu_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]),
                       "waves_waiting_frac": round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 3) if pmc.get("SQ_WAVE_CYCLES") else None}
-        bound = "valu" if fr["valu"]["issue_frac"] >= fr["hbm"]["frac"] else "hbm"
+        cands = {"valu": fr["valu"]["issue_frac"], "hbm": fr["hbm"]["frac"]}
+        if pmc.get("SQ_INSTS_SALU") is not None:
+            # the scalar unit (SALU, branches, scalar loads) is shared by a CU's four SIMDs: one instruction per cycle per CU
+            # (empirical ceiling: the first k_packet saturated at 0.89 per cycle per CU; MI355X_MICROARCH.md gives no figure)
+            sc = (pmc["SQ_INSTS_SALU"] + pmc.get("SQ_INSTS_BRANCH", 0.0) + pmc.get("SQ_INSTS_SMEM", 0.0)) / t / 1e12
+            fr["scalar"] = {"achieved": round(sc, 3), "peak": round(SCALAR_PEAK_TINST, 3), "unit": "Tinst/s", "frac": round(sc / SCALAR_PEAK_TINST, 4),
+                            "scalar_instructions_per_launch": int(pmc["SQ_INSTS_SALU"] + pmc.get("SQ_INSTS_BRANCH", 0.0) + pmc.get("SQ_INSTS_SMEM", 0.0))}
+            fr["scalar"]["issue_frac"] = fr["scalar"]["frac"]
+            cands["scalar"] = fr["scalar"]["frac"]
+        bound = max(cands, key=cands.get)
         top = fr[bound]
-    out = {"bound": bound, "kernel": "k_intersect",
+    out = {"bound": bound, "kernel": "traversal launches of a frame: k_packet (wave-packet form, coherent rays) + k_intersect (per-lane form)",
            "achieved": top["achieved"] if top else None, "peak": top["peak"] if top else None, "unit": top["unit"] if top else None,
-           "frac": (top["issue_frac"] if bound == "valu" else top["frac"]) if top else None,
+           "frac": (top["issue_frac"] if bound in ("valu", "scalar") else top["frac"]) if top else None,
            "traffic": traffic, "ms_per_launch": round(ms_per_launch, 5), "launches_per_frame": launches_per_frame, "fractions": fr,
            "pmc_build_id": build_id() if pmc else None,
            "note": "branchy scalar fp32 traversal, scene resident in the 256 MiB Infinity Cache: not HBM-bound. `frac` is the named bound's "

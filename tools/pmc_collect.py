@@ -1,10 +1,10 @@
-"""rocprofv3 --pmc counter CSVs -> profiles/pmc_k_intersect.json (what bench.py's roofline block reads).
+"""rocprofv3 --pmc counter CSVs -> profiles/pmc_traversal.json (what bench.py's roofline block reads).
 
-    python tools/pmc_collect.py <dir> [--out profiles/pmc_k_intersect.json] [--merge]
+    python tools/pmc_collect.py <dir> [--out profiles/pmc_traversal.json] [--merge]
 
 <dir> holds one sub-directory per pass, named pmc_<pass>_<config> (tools/refresh_profiles.sh): separate passes for FETCH_SIZE,
 WRITE_SIZE (they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots") and the SQ set.  Per config the counters are
-averaged over ALL k_intersect dispatches of `bench.py --config <config>` (every frame has the same launches).  FETCH_SIZE /
+averaged over ALL traversal dispatches (k_intersect, the per-lane kernel, and k_packet, the wave-packet kernel) of `bench.py --config <config>` (every frame has the same launches).  FETCH_SIZE /
 WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so bench.py doubles it (MI355X_MICROARCH.md, HBM).
 The file is stamped with the hash of the kernel sources: bench.py quotes it only for that build."""
 import argparse, collections, csv, glob, json, os, re, sys
@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 def build_id():
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip", "kernels.h", "traverse.h", "xrt_core.h"):
+    for f in ("kernels.hip", "packet.hip", "kernels.h", "device_util.h", "traverse.h", "xrt_core.h"):
         h.update(open(os.path.join(ROOT, "xna-ray-trace_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -23,8 +23,8 @@ def build_id():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "pmc_k_intersect.json"))
-    ap.add_argument("--kernel", default="k_intersect")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "pmc_traversal.json"))
+    ap.add_argument("--kernel", default="k_intersect|k_packet", help="regex: the traversal kernels (per-lane and wave-packet form)")
     args = ap.parse_args()
     configs = collections.defaultdict(dict)
     for d in sorted(glob.glob(os.path.join(args.dir, "pmc_*_*"))):
@@ -37,7 +37,7 @@ def main():
         tot, n = collections.defaultdict(float), collections.Counter()
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                if args.kernel in r["Kernel_Name"]:
+                if re.search(args.kernel, r["Kernel_Name"]):
                     tot[r["Counter_Name"]] += float(r["Counter_Value"])
                     n[r["Counter_Name"]] += 1
         for k in tot:
@@ -45,7 +45,7 @@ def main():
             configs[cfg][name] = tot[k] / n[k]
             configs[cfg].setdefault("dispatches", {})[k] = n[k]
     out = {"build_id": build_id(), "kernel": args.kernel,
-           "note": "per k_intersect launch, averaged over every launch of `bench.py --config <cfg> --no-extra --no-cpu --no-host` under rocprofv3 --pmc "
+           "note": "per traversal launch (k_intersect and k_packet together), averaged over every launch of `bench.py --config <cfg> --no-extra --no-cpu --no-host` under rocprofv3 --pmc "
                    "(separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*); FETCH_SIZE/WRITE_SIZE in KB, FETCH_SIZE counts half of streamed read bytes on gfx950",
            "configs": configs}
     need = ("FETCH_SIZE_KB", "WRITE_SIZE_KB", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): refreshes the profile evidence under gpurun_out/final for the current build.
-#   1. separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ set) of the bench of every config -> tools/pmc_collect.py ->
-#      profiles/pmc_k_intersect.json (stamped with the kernel sources' hash; bench.py's roofline block reads it)
+#   1. separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ wave/VALU set | SQ scalar set) of the bench of every config -> tools/pmc_collect.py ->
+#      profiles/pmc_traversal.json (stamped with the kernel sources' hash; bench.py's roofline block reads it)
 #   2. rocprofv3 --kernel-trace --stats of the default `python3 bench.py` command (the bench line is kept next to it)
 # Usage: tools/refresh_profiles.sh [configs...]   (default: C5 C3 C2 C4)
 set -e -o pipefail
@@ -11,16 +11,17 @@ rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CFGS=${@:-C5 C3 C2 C4}
+SC="SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES"
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU"
 for c in $CFGS; do
-  for pass in fetch write sq; do
-    case $pass in fetch) CTR="FETCH_SIZE";; write) CTR="WRITE_SIZE";; sq) CTR="$SQ";; esac
+  for pass in fetch write sq sc; do
+    case $pass in fetch) CTR="FETCH_SIZE";; write) CTR="WRITE_SIZE";; sq) CTR="$SQ";; sc) CTR="$SC";; esac
     echo "== pmc $pass $c"
     timeout -k 10 400 rocprofv3 --pmc $CTR --output-format csv -d $OUT/pmc_${pass}_$c -- python3 $R/bench.py --config $c --no-extra --no-cpu --no-host --steps 4 --warmup 1 > $OUT/pmc_${pass}_$c.log 2>&1
   done
 done
-python3 $R/tools/pmc_collect.py $OUT --out $OUT/pmc_k_intersect.json > /dev/null
-cp $OUT/pmc_k_intersect.json $R/profiles/pmc_k_intersect.json   # so that the bench below quotes it (same build)
+python3 $R/tools/pmc_collect.py $OUT --out $OUT/pmc_traversal.json > /dev/null
+cp $OUT/pmc_traversal.json $R/profiles/pmc_traversal.json   # so that the bench below quotes it (same build)
 echo "== kernel trace of the default bench"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py > $OUT/bench_under_rocprof.log 2>&1
 grep '^{"metric"' $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_line_under_rocprof.json
