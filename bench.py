@@ -346,9 +346,14 @@ def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_fra
            "note": "branchy scalar fp32 traversal, scene resident in the 256 MiB Infinity Cache: not HBM-bound. `frac` is the named bound's "
                    "(valu: VALU instruction-issue slots used, of which fractions.valu.frac did useful lane work); durations = HIP events on "
                    "the launches of the timed region; PMC = rocprofv3 passes of this build (profiles/), per launch"}
-    if pmc:
-        out["pmc_ms_per_launch"] = pmc.get("ms_per_launch")
     if serial:
+        if pmc and serial.get("ms_per_launch"):   # the same counters over the duration of a launch that has the GPU to itself
+            ts = serial["ms_per_launch"] * 1e-3
+            serial["fractions"] = {"hbm": round(traffic / ts / 1e9 / HBM_PEAK_GBS, 4),
+                                   "valu_issue": round(pmc["SQ_INSTS_VALU"] * 64.0 / ts / 1e12 / VALU_PEAK_TLANEOPS, 4),
+                                   "valu_useful": round(pmc["SQ_THREAD_CYCLES_VALU"] / ts / 1e12 / VALU_PEAK_TLANEOPS, 4)}
+            if "scalar" in fr:
+                serial["fractions"]["scalar"] = round(fr["scalar"]["scalar_instructions_per_launch"] / ts / 1e12 / SCALAR_PEAK_TINST, 4)
         out["serialised"] = serial
     return out
 
