@@ -19,6 +19,7 @@ namespace RayTraceProject.Native
         public float reflectiveness; public int transparent; public float refractionIndex;
         public int interpolateNormals, useTexture, texWidth, texHeight, reserved;
         public IntPtr texArgb;   // BitmapData.Scan0 of the Format32bppArgb lock (Material.cs:65)
+        public IntPtr texPArgb;  // Material.Texture.ColorData pinned (RayTracerTexture.cs:24-33: the premultiplied copy GetColorBilinear reads); IntPtr.Zero = same as texArgb
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -65,6 +66,9 @@ namespace RayTraceProject.Native
         [DllImport(Lib)] public static extern int xrt_scene_add_object(IntPtr scene, int[] meshIds, int nMeshes, float[] world, float[] invWorld,
                                                                       float[] bbox, float[] worldBbox, out int objectId);
         [DllImport(Lib)] public static extern int xrt_scene_build(IntPtr scene, int meshThreshold, int sceneThreshold);
+        // scene file: the content-pipeline step writes it once (instead of .xnb reflection serialisation of Model.Tag), the game loads it
+        [DllImport(Lib)] public static extern int xrt_scene_save(IntPtr scene, [MarshalAs(UnmanagedType.LPStr)] string path);
+        [DllImport(Lib)] public static extern int xrt_scene_load(int device, [MarshalAs(UnmanagedType.LPStr)] string path, out IntPtr scene);
         [DllImport(Lib)] public static extern int xrt_scene_intersect(IntPtr scene, [In] XrtRay[] rays, int[] ignoreObject, long n,
                                                                      [Out] XrtHit[] hits, IntPtr stats);
         [DllImport(Lib)] public static extern unsafe int xrt_render(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,

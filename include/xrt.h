@@ -90,7 +90,10 @@ typedef struct xrt_hit {
 } xrt_hit;
 
 /* Material (MAT:25-69, 234-268). tex_argb = the locked Format32bppArgb bitmap (MAT:65): row-major,
- * top-down, 0xAARRGGBB, tex_width*tex_height words; may be NULL when use_texture == 0. */
+ * top-down, 0xAARRGGBB, tex_width*tex_height words; may be NULL when use_texture == 0.
+ * tex_pargb = Material.Texture.ColorData, the Format32bppPArgb (premultiplied) copy RayTracerTexture makes of the same
+ * file (TEX:24-33): the bilinear filter reads ITS words (MAT:186-189) while the point sampler reads tex_argb (MAT:150).
+ * The host has both arrays; NULL means "same as tex_argb" (true for every image without an alpha channel). */
 typedef struct xrt_material {
     float           reflectiveness;
     int32_t         transparent;
@@ -101,6 +104,7 @@ typedef struct xrt_material {
     int32_t         tex_height;
     int32_t         reserved;
     const uint32_t *tex_argb;
+    const uint32_t *tex_pargb;
 } xrt_material;
 
 /* Inputs of RayTracer.Render ray generation (RT:395-397): Camera.View, Camera.Projection and the
@@ -205,6 +209,13 @@ int xrt_scene_add_object(xrt_scene *scene, const int32_t *mesh_ids, int32_t n_me
  * OctreeSpatialManager.Build (OSM:64-113, 218-248; threshold OSM:50); then uploads to HBM.
  * Pass 0 for the reference defaults (50 / 20). */
 int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_threshold);
+
+/* Scene file -- what the reference keeps as .xnb content (the processor's Model.Tag, TMP:113-117: meshes with their materials):
+ * xrt_scene_save writes the meshes, materials, texels and bodies of `scene` exactly as they were added (little-endian, version
+ * tagged; format in scene_host.cpp); xrt_scene_load is xrt_scene_create followed by the same add_mesh / add_object calls.  The
+ * octrees are not stored: call xrt_scene_build after loading (it reproduces them, MO:56-96 / OSM:64-113). */
+int xrt_scene_save(const xrt_scene *scene, const char *path);
+int xrt_scene_load(int device, const char *path, xrt_scene **scene_out);
 
 /* Inspection of the built trees (test support). mesh_id >= 0: that mesh's MeshOctree; mesh_id == -1:
  * the scene octree (refs are object ids). Call with NULL arrays to get the counts. Nodes are returned

@@ -51,6 +51,7 @@ struct Material {
     bool UseTexture = false;
     int Width = 0, Height = 0;
     std::vector<uint32_t> argb;   // BitmapData.Scan0 of the Format32bppArgb lock (MAT:65)
+    std::vector<uint32_t> colorData;   // Texture.ColorData: the Format32bppPArgb copy (TEX:24-33) GetColorBilinear indexes (MAT:186-189)
 
     static constexpr float BYTE_RECIPROCAL = 1.0f / 255.0f;   // MAT:27
 
@@ -100,8 +101,8 @@ struct Material {
         int y2 = (int)((uv.Y + tdy) * (float)(Height - 1));
         auto texel = [&](int xx, int yy) {   // the C# indexes a managed int[] (IndexOutOfRangeException when outside); guarded here
             int64_t idx = (int64_t)Width * yy + xx;
-            if (idx < 0 || idx >= (int64_t)argb.size()) idx = 0;
-            uint32_t w = argb[(size_t)idx];
+            if (idx < 0 || idx >= (int64_t)colorData.size()) idx = 0;
+            uint32_t w = colorData[(size_t)idx];   // MAT:186-189: Texture.ColorData, not Scan0
             return V3((float)((w >> 16) & 0xFF), (float)((w >> 8) & 0xFF), (float)(w & 0xFF));
         };
         Vector3 baseColor = texel(x, y), blendXColor = texel(x2, y), blendYColor = texel(x, y2), blendXYColor = texel(x2, y2);
@@ -803,6 +804,8 @@ int orc_scene_add_mesh(orc_scene *s, const float *v, const float *n, const float
         if (!m->tex_argb || m->tex_width <= 0 || m->tex_height <= 0) { s->error = "use_texture without texels"; return -1; }
         mm.Width = m->tex_width; mm.Height = m->tex_height;
         mm.argb.assign(m->tex_argb, m->tex_argb + (size_t)m->tex_width * m->tex_height);
+        const uint32_t *pa = m->tex_pargb ? m->tex_pargb : m->tex_argb;
+        mm.colorData.assign(pa, pa + (size_t)m->tex_width * m->tex_height);
     }
     mesh->MeshBoundingBox = BoundingBox{V3(bbox[0], bbox[1], bbox[2]), V3(bbox[3], bbox[4], bbox[5])};
     s->meshes.push_back(std::move(mesh));
@@ -1051,6 +1054,7 @@ void orc_kat_spot_light(const xrt_light *l, const float pos[3], const float norm
 int orc_kat_lookup_uv(const xrt_material *m, const float uv[2], int address, int filtering, float out[3]) {
     Material mm; mm.UseTexture = true; mm.Width = m->tex_width; mm.Height = m->tex_height;
     mm.argb.assign(m->tex_argb, m->tex_argb + (size_t)m->tex_width * m->tex_height);
+    { const uint32_t *pa = m->tex_pargb ? m->tex_pargb : m->tex_argb; mm.colorData.assign(pa, pa + (size_t)m->tex_width * m->tex_height); }
     Vector3 c;
     bool ok = mm.LookupUV(Vector2{uv[0], uv[1]}, address, filtering, c);
     if (!ok) return -1;

@@ -75,6 +75,10 @@ def material_abi(m):
         keep = np.ascontiguousarray(m["texture"], dtype=np.uint32)
         a.tex_height, a.tex_width = keep.shape
         a.tex_argb = keep.ctypes.data_as(C.POINTER(C.c_uint32))
+        if m.get("texture_pargb") is not None:
+            keep2 = np.ascontiguousarray(m["texture_pargb"], dtype=np.uint32)
+            a.tex_pargb = keep2.ctypes.data_as(C.POINTER(C.c_uint32))
+            keep = (keep, keep2)
     return a, keep
 
 

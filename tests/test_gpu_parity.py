@@ -281,6 +281,31 @@ def test_texture_address_modes_and_filters(xrt, orc, address, filtering):
     assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
 
 
+def test_bilinear_filter_reads_the_premultiplied_copy(xrt, orc):
+    """GetColorBilinear indexes Material.Texture.ColorData -- the Format32bppPArgb copy RayTracerTexture makes of the file
+    (TEX:24-33, MAT:186-189) -- while the point sampler reads the Format32bppArgb lock (MAT:150).  For a texture with alpha the
+    two arrays differ; the host passes both (xrt_material.tex_pargb).  How GDI+ rounds the premultiplication is the host's
+    business (closed source): this test makes its own premultiplied copy and checks that each filter reads its own array."""
+    rng = np.random.default_rng(3)
+    argb = rng.integers(0, 2 ** 32, size=(64, 128), dtype=np.uint64).astype(np.uint32)
+    a = (argb >> 24) & 0xff
+    pre = lambda c: ((c * a + 127) // 255).astype(np.uint32)
+    pargb = (a << 24) | (pre((argb >> 16) & 0xff) << 16) | (pre((argb >> 8) & 0xff) << 8) | pre(argb & 0xff)
+    frames = {}
+    for filtering in (xrt.abi.FILTER_POINT, xrt.abi.FILTER_BILINEAR):
+        for with_p in (False, True):
+            spec = xrt.configs.crate_scene(160, 90, max_reflections=1)
+            spec.meshes[0] = (spec.meshes[0][0], xrt.configs.material(0.5, texture=argb, texture_pargb=pargb.astype(np.uint32) if with_p else None))
+            spec.filtering = filtering
+            _, tracer = xrt.configs.build_product(spec)
+            rgba, rgbf = tracer.Render(want_float=True)
+            o_rgba, o_rgbf, _ = orc.OracleScene(spec).render(nthreads=8)
+            assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+            frames[(filtering, with_p)] = rgba.copy()
+    assert np.array_equal(frames[(xrt.abi.FILTER_POINT, False)], frames[(xrt.abi.FILTER_POINT, True)])          # the point sampler never reads it
+    assert not np.array_equal(frames[(xrt.abi.FILTER_BILINEAR, False)], frames[(xrt.abi.FILTER_BILINEAR, True)])  # the bilinear filter does
+
+
 def test_default_game_scene(xrt, orc):
     """G1: the reference's own default workload (Game1.cs:98-138: 4 Transparent spheres of Sphere.fbx, interpolated
     normals, MaxReflections 8 -> a 511-node ray tree per pixel), at reduced resolution against the oracle."""
@@ -1019,6 +1044,46 @@ def test_reference_content_scene(xrt, orc):
     spec2.multisampling, spec2.multisample_quality = xrt.abi.MS_ADAPTIVE, 1
     _, tracer2 = xrt.configs.build_product(spec2)
     assert np.array_equal(tracer2.Render(), orc.OracleScene(spec2).render(nthreads=8, want_float=False)[0])
+
+
+def test_reference_content_scene2(xrt, orc):
+    """Assets imported with the ModelProcessor rotation parameters of the content project (glass prism2.fbx, chesspiece.fbx,
+    fbx.import_mesh `rotation`) on a ground whose texture the host mirror reads from a FILE (Material(textureFilePath) ->
+    Material.Init, MAT:59-69 / TMP:121-131): hits and frames bit-identical to the oracle, plain / ray tree / 16 sub-rays /
+    adaptive, point and bilinear filtering."""
+    spec = xrt.configs.content_scene2(192, 108)
+    scene, tracer = xrt.configs.build_product(spec)
+    assert scene.meshes[0].MeshMaterial.TextureFilePath and scene.meshes[0].MeshMaterial.Texture.shape == (512, 512)
+    o = orc.OracleScene(spec)
+    prim = tracer.GeneratePrimaryRays()
+    assert prim.tobytes() == o.primary_rays().tobytes()
+    ho = o.intersect(prim)
+    assert hits_equal(ho, scene.IntersectBatch(prim)) == {}
+    sec = secondary_rays(xrt, ho, seed=9)
+    assert hits_equal(o.intersect(sec), scene.IntersectBatch(sec)) == {}
+    for ms, filt in ((xrt.abi.MS_OFF, xrt.abi.FILTER_POINT), (xrt.abi.MS_OFF, xrt.abi.FILTER_BILINEAR), (xrt.abi.MS_FIXED16, xrt.abi.FILTER_POINT),
+                     (xrt.abi.MS_ADAPTIVE, xrt.abi.FILTER_BILINEAR)):
+        s2 = xrt.configs.content_scene2(96 if ms != xrt.abi.MS_OFF else 192, 54 if ms != xrt.abi.MS_OFF else 108)
+        s2.multisampling, s2.multisample_quality, s2.filtering = ms, 1, filt
+        _, t2 = xrt.configs.build_product(s2)
+        rgba, rgbf = t2.Render(want_float=True)
+        o_rgba, o_rgbf, o_st = orc.OracleScene(s2).render(nthreads=8)
+        assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+        assert t2.last_stats["rays_closest"] == o_st["rays_closest"] and t2.last_stats["rays_shadow"] == o_st["rays_shadow"]
+
+
+def test_scene_file_renders_like_the_scene_it_was_saved_from(xrt, tmp_path):
+    """xrt_scene_save -> xrt_scene_load -> xrt_scene_build on the GPU: same hits, same frame."""
+    spec = xrt.configs.content_scene2(160, 90)
+    scene, tracer = xrt.configs.build_product(spec)
+    want = tracer.Render().copy()
+    rays = tracer.GeneratePrimaryRays()
+    hits = scene.IntersectBatch(rays)
+    path = str(tmp_path / "content2.xrts")
+    scene.Save(path)
+    tracer.CurrentScene = xrt.api.OctreeSpatialManager.Load(path)
+    assert hits_equal(hits, tracer.CurrentScene.IntersectBatch(rays)) == {}
+    assert np.array_equal(tracer.Render(), want)
 
 
 def test_ray_tree_overflow_retries_with_fewer_paths(xrt, monkeypatch):

@@ -301,6 +301,20 @@ def test_fbx_import_of_the_reference_assets(xrt):
     for name, ntri in (("torus.fbx", 1152), ("cube.fbx", 12), ("ground.fbx", 2)):
         ms, up = fbx.load_fbx(os.path.join(REF_CONTENT, name))
         assert fbx.import_mesh(ms[0], up).ntri == ntri
+    # ModelProcessor rotation parameters (contentproj:112-122,186-195,197-206): prism2 and chesspiece equal their committed
+    # fixtures, a rotation of 180 degrees about Y mirrors x and z of the unrotated import, winding still agrees with the normals
+    zc = np.load(os.path.join(ROOT, "tests", "golden", "content_meshes.npz"))
+    for name, asset, kw in (("prism", "prism2.fbx", dict(rotation=(-90.0, 0.0, 0.0), diffuse_color=(255, 255, 255, 100))),
+                            ("chesspiece", "chesspiece.fbx", dict(scale=3.0, rotation=(-90.0, 0.0, 0.0)))):
+        ms, up = fbx.load_fbx(os.path.join(REF_CONTENT, asset))
+        got = fbx.import_mesh(ms[0], up, **kw)
+        assert np.array_equal(got.v, zc[name + "_v"]) and np.array_equal(got.n, zc[name + "_n"]) and np.array_equal(got.color, zc[name + "_color"])
+        assert ((got.surface_normal * got.n[:, 0, :]).sum(axis=1) > 0).mean() > 0.99
+    ms, up = fbx.load_fbx(os.path.join(REF_CONTENT, "wossy.fbx"))
+    plain, turned = fbx.import_mesh(ms[0], up, scale=32.0), fbx.import_mesh(ms[0], up, scale=32.0, rotation=(0.0, 180.0, 0.0))
+    assert turned.ntri == plain.ntri == 9420
+    assert np.allclose(turned.v[..., 0], -plain.v[..., 0], atol=2e-4) and np.allclose(turned.v[..., 2], -plain.v[..., 2], atol=2e-4)
+    assert np.array_equal(turned.v[..., 1], plain.v[..., 1])
 
 
 def test_default_game_scene_traversal(xrt, orc, emul):
@@ -314,6 +328,54 @@ def test_default_game_scene_traversal(xrt, orc, emul):
     assert hits_equal(ho, e.intersect(rays)) == {}
     sec = secondary_rays(xrt, ho)
     assert hits_equal(o.intersect(sec), e.intersect(sec)) == {}
+
+
+def test_reference_content_scene2_on_the_cpu(xrt, orc, emul):
+    """The assets that need the processor's rotation parameters (glass prism, chess piece) on the file-textured ground."""
+    spec = xrt.configs.content_scene2(96, 54)
+    o, e = orc.OracleScene(spec), emul.EmulScene(spec)
+    prim = o.primary_rays()
+    o_hits = o.intersect(prim)
+    assert (o_hits["hit"] != 0).mean() > 0.3 and len(np.unique(o_hits["mesh"][o_hits["hit"] != 0])) == 3
+    assert hits_equal(o_hits, e.intersect(prim)) == {}
+    sec = secondary_rays(xrt, o_hits, seed=6)
+    assert hits_equal(o.intersect(sec), e.intersect(sec)) == {}
+
+
+def test_scene_file_round_trip(xrt, tmp_path):
+    """xrt_scene_save / xrt_scene_load (host-only scenes, no GPU): the loaded scene rebuilds byte-identical octrees for every
+    mesh and for the bodies -- textures, premultiplied copy and shared meshes included; corrupt files are refused."""
+    spec = xrt.configs.content_scene2(64, 36)
+    rng = np.random.default_rng(1)
+    argb = rng.integers(0, 2 ** 32, size=(8, 16), dtype=np.uint64).astype(np.uint32)
+    spec.meshes.append((xrt.fixtures.crate(2), xrt.configs.material(0.4, texture=argb, texture_pargb=(argb & np.uint32(0xff7f7f7f)))))
+    spec.objects.append(([3, 0], (9.0, 1.0, 2.0), (0.1, 0.2, 0.3), (1.0, 2.0, 0.5)))
+    scene, _ = xrt.configs.build_product(spec, device=-1)
+    path = str(tmp_path / "scene.xrts")
+    scene.Save(path)
+    loaded = xrt.api.OctreeSpatialManager.Load(path, device=-1)
+    import ctypes as C
+
+    def trees(handle, n_meshes):
+        out = []
+        for mid in range(-1, n_meshes):
+            nn, nr = C.c_int64(0), C.c_int64(0)
+            xrt.abi.check(xrt.abi.lib().xrt_scene_get_tree(handle, mid, None, C.byref(nn), None, C.byref(nr)))
+            nodes = np.zeros(nn.value, dtype=xrt.NODE_DTYPE)
+            refs = np.zeros(max(nr.value, 1), dtype=np.int32)
+            xrt.abi.check(xrt.abi.lib().xrt_scene_get_tree(handle, mid, nodes.ctypes.data_as(C.POINTER(xrt.abi.xrt_node_info)), C.byref(nn),
+                                                           refs.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nr)))
+            out.append((nodes.tobytes(), refs[: nr.value].tobytes()))
+        return out
+    assert trees(scene.handle, 4) == trees(loaded.handle, 4)
+    scene.Save(str(tmp_path / "again.xrts"))
+    loaded.Save(str(tmp_path / "loaded.xrts"))
+    assert open(str(tmp_path / "again.xrts"), "rb").read() == open(str(tmp_path / "loaded.xrts"), "rb").read() == open(path, "rb").read()
+    data = open(path, "rb").read()
+    for bad in (data[: len(data) // 2], b"XRTSCENX" + data[8:], data[:8] + b"\x09\0\0\0" + data[12:]):
+        open(str(tmp_path / "bad.xrts"), "wb").write(bad)
+        with pytest.raises(ValueError):
+            xrt.api.OctreeSpatialManager.Load(str(tmp_path / "bad.xrts"), device=-1)
 
 
 def test_reference_content_scene_on_the_cpu():

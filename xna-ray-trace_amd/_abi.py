@@ -40,7 +40,8 @@ class xrt_hit(C.Structure):
 class xrt_material(C.Structure):
     _fields_ = [("reflectiveness", C.c_float), ("transparent", C.c_int32), ("refraction_index", C.c_float),
                 ("interpolate_normals", C.c_int32), ("use_texture", C.c_int32), ("tex_width", C.c_int32),
-                ("tex_height", C.c_int32), ("reserved", C.c_int32), ("tex_argb", C.POINTER(C.c_uint32))]
+                ("tex_height", C.c_int32), ("reserved", C.c_int32), ("tex_argb", C.POINTER(C.c_uint32)),
+                ("tex_pargb", C.POINTER(C.c_uint32))]
 
 
 class xrt_camera(C.Structure):
@@ -92,6 +93,8 @@ SYMBOLS = {
     "xrt_scene_add_mesh": (C.c_int, [C.c_void_p, _F, _F, _F, _F, _F, C.c_int32, _P(xrt_material), _F, _P(C.c_int32)]),
     "xrt_scene_add_object": (C.c_int, [C.c_void_p, _P(C.c_int32), C.c_int32, _F, _F, _F, _F, _P(C.c_int32)]),
     "xrt_scene_build": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "xrt_scene_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "xrt_scene_load": (C.c_int, [C.c_int, C.c_char_p, _P(C.c_void_p)]),
     "xrt_scene_get_tree": (C.c_int, [C.c_void_p, C.c_int32, _P(xrt_node_info), _P(C.c_int64), _P(C.c_int32), _P(C.c_int64)]),
     "xrt_scene_intersect": (C.c_int, [C.c_void_p, _P(xrt_ray), _P(C.c_int32), C.c_int64, _P(xrt_hit), _P(xrt_stats)]),
     "xrt_scene_intersect_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -26,13 +26,25 @@ def _fp(a):
 class Material:
     """Material.cs:25-269 (shading inputs; texels as the Format32bppArgb lock of MAT:65)."""
 
-    def __init__(self, reflectiveness=0.0, useTexture=False, transparent=False, refractionIndex=0.0, texture=None):
+    def __init__(self, reflectiveness=0.0, useTexture=False, transparent=False, refractionIndex=0.0, texture=None, texture_pargb=None, textureFilePath=None):
         self.Reflectiveness = float(reflectiveness)
         self.UseTexture = bool(useTexture)
         self.Transparent = bool(transparent)
         self.RefractionIndex = float(refractionIndex)
         self.InterpolateNormals = False
         self.Texture = None if texture is None else np.ascontiguousarray(texture, dtype=np.uint32)
+        # Material.Texture.ColorData: the premultiplied Format32bppPArgb copy the bilinear filter reads (TEX:24-33, MAT:186-189)
+        self.TexturePArgb = None if texture_pargb is None else np.ascontiguousarray(texture_pargb, dtype=np.uint32)
+        self.TextureFilePath = textureFilePath   # MAT:45-53; TracerModelProcessor.CreateMaterial passes its TextureFilePath parameter (TMP:121-131)
+
+    def Init(self):
+        """Material.Init (MAT:59-69): Bitmap.FromFile(textureFilePath) locked as Format32bppArgb.  Files without an alpha channel
+        (24-bpp BMP, what the reference's content uses) need no separate premultiplied copy."""
+        if self.UseTexture and self.Texture is None:
+            if not self.TextureFilePath:
+                raise ValueError("UseTexture without a texture file")   # Bitmap.FromFile(null) throws, MAT:63
+            from . import fixtures
+            self.Texture = fixtures.load_bmp_argb(self.TextureFilePath)
 
     def _to_abi(self):
         m = abi.xrt_material()
@@ -43,9 +55,13 @@ class Material:
         m.use_texture = int(self.UseTexture)
         if self.UseTexture:
             if self.Texture is None:
-                raise ValueError("UseTexture without a texture")   # Bitmap.FromFile would throw, MAT:63
+                self.Init()
             m.tex_height, m.tex_width = self.Texture.shape
             m.tex_argb = self.Texture.ctypes.data_as(C.POINTER(C.c_uint32))
+            if self.TexturePArgb is not None:
+                if self.TexturePArgb.shape != self.Texture.shape:
+                    raise ValueError("Texture.ColorData must have the size of the bitmap")
+                m.tex_pargb = self.TexturePArgb.ctypes.data_as(C.POINTER(C.c_uint32))
         return m
 
 
@@ -237,6 +253,21 @@ class OctreeSpatialManager(ISpatialManager):
             abi.check(abi.lib().xrt_scene_add_object(self._scene.handle, ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids),
                                                      _fp(world), _fp(inv), _fp(bb), _fp(wbb), C.byref(oid)))
         abi.check(abi.lib().xrt_scene_build(self._scene.handle, self.meshItemTreshold, self.itemTreshold))
+
+    def Save(self, path):
+        """xrt_scene_save: the built scene's meshes, materials, texels and bodies as one file (the reference's .xnb content)."""
+        abi.check(abi.lib().xrt_scene_save(self.handle, str(path).encode()))
+
+    @classmethod
+    def Load(cls, path, device=0):
+        """xrt_scene_load + xrt_scene_build: a spatial manager whose geometry lives only in the library (Bodies stays empty;
+        meshes are known by id).  What a game does at start-up with the file its content build wrote."""
+        sm = cls(device)
+        sm._scene = _Scene.__new__(_Scene)
+        sm._scene.handle = C.c_void_p()
+        abi.check(abi.lib().xrt_scene_load(int(device), str(path).encode(), C.byref(sm._scene.handle)))
+        abi.check(abi.lib().xrt_scene_build(sm._scene.handle, sm.meshItemTreshold, sm.itemTreshold))
+        return sm
 
     @property
     def handle(self):

@@ -34,9 +34,9 @@ class SceneSpec:
         return self
 
 
-def material(reflectiveness=0.5, transparent=False, refraction_index=0.0, interpolate_normals=False, texture=None):
+def material(reflectiveness=0.5, transparent=False, refraction_index=0.0, interpolate_normals=False, texture=None, texture_pargb=None):
     return dict(reflectiveness=reflectiveness, transparent=transparent, refraction_index=refraction_index,
-                interpolate_normals=interpolate_normals, use_texture=texture is not None, texture=texture)
+                interpolate_normals=interpolate_normals, use_texture=texture is not None, texture=texture, texture_pargb=texture_pargb)
 
 
 def spot(pos, angle=math.pi / 2):
@@ -183,7 +183,10 @@ def build_product(spec, device=0):
     from . import api
     meshes = []
     for data, m in spec.meshes:
-        mat = api.Material(m["reflectiveness"], m["use_texture"], m["transparent"], m["refraction_index"], m["texture"])
+        if m.get("texture_file"):   # the product loads the file itself (Material.Init, MAT:59-69)
+            mat = api.Material(m["reflectiveness"], m["use_texture"], m["transparent"], m["refraction_index"], textureFilePath=m["texture_file"])
+        else:
+            mat = api.Material(m["reflectiveness"], m["use_texture"], m["transparent"], m["refraction_index"], m["texture"], m.get("texture_pargb"))
         mat.InterpolateNormals = m["interpolate_normals"]
         meshes.append(api.Mesh(data, mat, device=device))
     scene = api.OctreeSpatialManager(device)
@@ -212,3 +215,30 @@ def build_product(spec, device=0):
         L.Direction, L.Color, L.Intensity = l["direction"], l["color"], l["intensity"]
         tracer.Lights.append(L)
     return scene, tracer
+
+
+def content_scene2(width=320, height=180, max_reflections=3):
+    """More of the reference's content, the assets whose content-project entries carry ModelProcessor rotation parameters:
+    the glass prism (prism2.fbx, RotationX -90, alpha 100/255, refraction index 1.32, flat normals -- contentproj:112-122) and
+    the chess piece (chesspiece.fbx, RotationX -90, Scale 3 -- contentproj:186-195) on the ground plane, whose texture comes from
+    a FILE through Material(textureFilePath) as TracerModelProcessor.CreateMaterial does (TMP:121-131; the crate's Diffuse.bmp
+    standing in for the absent C:\\Projects\\textures\\smiley.bmp).  Geometry = tests/golden/content_meshes.npz."""
+    import os
+    s = SceneSpec("reference_content2")
+    z = np.load(os.path.join(fixtures._GOLDEN, "content_meshes.npz"))
+
+    def md(name):
+        return fixtures.MeshData(z[name + "_v"], z[name + "_n"], z[name + "_uv"], z[name + "_color"])
+    ground = material(0.5, interpolate_normals=False, texture=None)
+    ground["use_texture"], ground["texture_file"] = True, fixtures.CRATE_TEXTURE
+    ground["texture"] = fixtures.load_bmp_argb(fixtures.CRATE_TEXTURE)   # (what the oracle is given; the product reads the file itself)
+    s.meshes.append((md("plane"), ground))
+    s.meshes.append((md("prism"), material(0.5, transparent=True, refraction_index=float(f32(1.32)), interpolate_normals=False)))
+    s.meshes.append((md("chesspiece"), material(0.5, interpolate_normals=True)))
+    s.objects.append(([0], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    s.objects.append(([1], (-3.0, 0.0, 4.0), (0.0, 0.6, 0.0), (3.0, 3.0, 3.0)))           # prism
+    s.objects.append(([2], (2.0, 0.0, -1.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))           # chess piece
+    s.camera = camera((0, 9, 20), (0, 2, 0))
+    s.lights = [spot((5, 18, 14))]
+    s.max_reflections = max_reflections
+    return s.with_size(width, height)

@@ -696,7 +696,7 @@ __device__ __forceinline__ v3 lookup_uv(const ShadeView &V, const MaterialRec &M
         if (((int)(ox - ux)) % 2 == 0) ux = 1.0f - ux;
         if (((int)(oy - uy)) % 2 == 0) uy = 1.0f - uy;
     }
-    if (V.filtering == XRT_FILTER_BILINEAR) {   // MAT:162-232 (Texture.ColorData == the Argb words for opaque textures)
+    if (V.filtering == XRT_FILTER_BILINEAR) {   // MAT:162-232
         const float tdx = 1.0f / (float)M.texWidth, tdy = 1.0f / (float)M.texHeight;   // MAT:67
         const double remX = remainder((double)ux, (double)tdx), remY = remainder((double)uy, (double)tdy);   // Math.IEEERemainder, exact
         ux -= (float)remX;
@@ -706,7 +706,7 @@ __device__ __forceinline__ v3 lookup_uv(const ShadeView &V, const MaterialRec &M
         auto texel = [&](int xx, int yy) {
             long long idx = (long long)M.texWidth * yy + xx;
             if (idx < 0 || idx >= (long long)M.texWidth * M.texHeight) idx = 0;
-            uint32_t w = V.texels[M.texOffset + idx];
+            uint32_t w = V.texels[M.texOffsetP + idx];   // MAT:186-189: Texture.ColorData
             return mk((float)((w >> 16) & 0xffu), (float)((w >> 8) & 0xffu), (float)(w & 0xffu));
         };
         const v3 c00 = texel(bx, by), c10 = texel(bx2, by), c01 = texel(bx, by2), c11 = texel(bx2, by2);

@@ -17,7 +17,8 @@ struct HostMesh {
     float reflectiveness = 0, refractionIndex = 0;
     bool transparent = false, interpolateNormals = false, useTexture = false;
     int texW = 0, texH = 0;
-    std::vector<uint32_t> texels;
+    std::vector<uint32_t> texels;    // the Format32bppArgb lock (MAT:65)
+    std::vector<uint32_t> texelsP;   // Texture.ColorData, the premultiplied copy (TEX:24-33); empty: same as texels
 };
 
 struct HostObject {

@@ -2,6 +2,7 @@
 #include "scene_host.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 namespace xrt {
@@ -33,6 +34,7 @@ int HostScene::add_mesh(const float *v, const float *n, const float *uv, const f
         if (!m->tex_argb || m->tex_width <= 0 || m->tex_height <= 0) { err = "xrt_scene_add_mesh: UseTexture without texels (Bitmap.FromFile would throw, MAT:63)"; return -1; }
         hm.texW = m->tex_width; hm.texH = m->tex_height;
         hm.texels.assign(m->tex_argb, m->tex_argb + (size_t)m->tex_width * m->tex_height);
+        if (m->tex_pargb) hm.texelsP.assign(m->tex_pargb, m->tex_pargb + (size_t)m->tex_width * m->tex_height);
     }
     meshes.push_back(std::move(hm));
     built = false;
@@ -208,6 +210,8 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
         mat.texOffset = (int)A.texels.size();
         mat.texWidth = m.texW; mat.texHeight = m.texH;
         A.texels.insert(A.texels.end(), m.texels.begin(), m.texels.end());
+        mat.texOffsetP = mat.texOffset;
+        if (!m.texelsP.empty()) { mat.texOffsetP = (int)A.texels.size(); A.texels.insert(A.texels.end(), m.texelsP.begin(), m.texelsP.end()); }
         A.materials.push_back(mat);
         A.anyTransparent = A.anyTransparent || m.transparent;
         A.anyTexture = A.anyTexture || m.useTexture;
@@ -259,6 +263,85 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
     if (A.leafNB.empty()) A.leafNB.assign(16, f4{0, 0, 0, 0});
     if (A.childDfs.empty()) A.childDfs.assign(8, -1);
     built = true;
+    return true;
+}
+
+// ---- scene file -----------------------------------------------------------------------------------------------------------
+// "XRTSCENE" u32 version=1 u32 nMeshes u32 nObjects, then per mesh: i32 ntri, f32 bbox[6], f32 reflectiveness, f32 refractionIndex,
+// i32 flags (1 transparent, 2 interpolateNormals, 4 useTexture, 8 has premultiplied texels), i32 texW, i32 texH, f32 v[9n] n[9n]
+// uv[6n] sn[3n] color[4n], u32 texels[texW*texH] (if 4), u32 texelsP[texW*texH] (if 8); per object: i32 nMeshes, i32 ids[],
+// f32 world[16] invWorld[16] bbox[6] worldBbox[6].
+namespace {
+struct FileW {
+    FILE *f; bool ok = true;
+    template <class T> void put(const T *p, size_t n) { if (ok && n && fwrite(p, sizeof(T), n, f) != n) ok = false; }
+    template <class T> void one(T v) { put(&v, 1); }
+};
+struct FileR {
+    FILE *f; bool ok = true;
+    template <class T> void get(T *p, size_t n) { if (ok && n && fread(p, sizeof(T), n, f) != n) ok = false; }
+    template <class T> T one() { T v{}; get(&v, 1); return v; }
+    template <class T> void vec(std::vector<T> &v, size_t n) { if (!ok) return; if (n > ((size_t)1 << 31)) { ok = false; return; } v.resize(n); get(v.data(), n); }
+};
+}  // namespace
+
+bool HostScene::save(const char *path, std::string &err) const {
+    FILE *f = path ? fopen(path, "wb") : nullptr;
+    if (!f) { err = "xrt_scene_save: cannot open the file for writing"; return false; }
+    FileW w{f};
+    w.put("XRTSCENE", 8);
+    w.one<uint32_t>(1); w.one<uint32_t>((uint32_t)meshes.size()); w.one<uint32_t>((uint32_t)objects.size());
+    for (const HostMesh &m : meshes) {
+        w.one<int32_t>(m.ntri); w.put(m.bbox, 6); w.one<float>(m.reflectiveness); w.one<float>(m.refractionIndex);
+        w.one<int32_t>((m.transparent ? 1 : 0) | (m.interpolateNormals ? 2 : 0) | (m.useTexture ? 4 : 0) | (m.texelsP.empty() ? 0 : 8));
+        w.one<int32_t>(m.texW); w.one<int32_t>(m.texH);
+        w.put(m.v.data(), m.v.size()); w.put(m.n.data(), m.n.size()); w.put(m.uv.data(), m.uv.size()); w.put(m.sn.data(), m.sn.size());
+        w.put(m.color.data(), m.color.size());
+        if (m.useTexture) w.put(m.texels.data(), m.texels.size());
+        if (!m.texelsP.empty()) w.put(m.texelsP.data(), m.texelsP.size());
+    }
+    for (const HostObject &o : objects) {
+        w.one<int32_t>((int32_t)o.meshes.size()); w.put(o.meshes.data(), o.meshes.size());
+        w.put(o.world, 16); w.put(o.invWorld, 16); w.put(o.bbox, 6); w.put(o.worldBbox, 6);
+    }
+    const bool ok = w.ok && fclose(f) == 0;
+    if (!ok) err = "xrt_scene_save: write failed";
+    return ok;
+}
+
+bool HostScene::load(const char *path, std::string &err) {
+    FILE *f = path ? fopen(path, "rb") : nullptr;
+    if (!f) { err = "xrt_scene_load: cannot open the file"; return false; }
+    FileR r{f};
+    char magic[8] = {0};
+    r.get(magic, 8);
+    const uint32_t version = r.one<uint32_t>(), nm = r.one<uint32_t>(), no = r.one<uint32_t>();
+    if (!r.ok || std::memcmp(magic, "XRTSCENE", 8) != 0 || version != 1 || nm > (1u << 24) || no > (1u << 24)) { fclose(f); err = "xrt_scene_load: not a version-1 xrt scene file"; return false; }
+    std::vector<HostMesh> ms(nm);
+    std::vector<HostObject> os(no);
+    for (HostMesh &m : ms) {
+        m.ntri = r.one<int32_t>(); r.get(m.bbox, 6); m.reflectiveness = r.one<float>(); m.refractionIndex = r.one<float>();
+        const int flags = r.one<int32_t>();
+        m.texW = r.one<int32_t>(); m.texH = r.one<int32_t>();
+        if (!r.ok || m.ntri < 0 || m.ntri >= (1 << 28) || m.texW < 0 || m.texH < 0 || (long long)m.texW * m.texH > (1LL << 30)) { r.ok = false; break; }
+        m.transparent = (flags & 1) != 0; m.interpolateNormals = (flags & 2) != 0; m.useTexture = (flags & 4) != 0;
+        const size_t n = (size_t)m.ntri;
+        r.vec(m.v, n * 9); r.vec(m.n, n * 9); r.vec(m.uv, n * 6); r.vec(m.sn, n * 3); r.vec(m.color, n * 4);
+        if (m.useTexture) r.vec(m.texels, (size_t)m.texW * m.texH);
+        if (flags & 8) r.vec(m.texelsP, (size_t)m.texW * m.texH);
+    }
+    for (HostObject &o : os) {
+        if (!r.ok) break;
+        const int k = r.one<int32_t>();
+        if (!r.ok || k < 0 || k > (1 << 20)) { r.ok = false; break; }
+        r.vec(o.meshes, (size_t)k);
+        for (int id : o.meshes) if (id < 0 || id >= (int)nm) r.ok = false;
+        r.get(o.world, 16); r.get(o.invWorld, 16); r.get(o.bbox, 6); r.get(o.worldBbox, 6);
+    }
+    fclose(f);
+    if (!r.ok) { err = "xrt_scene_load: truncated or corrupt scene file"; return false; }
+    meshes = std::move(ms); objects = std::move(os);
+    built = false;
     return true;
 }
 

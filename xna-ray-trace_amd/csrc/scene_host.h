@@ -42,6 +42,10 @@ struct HostScene {
     int add_object(const int *meshIds, int n, const float *world, const float *invWorld, const float *bbox,
                    const float *worldBbox, std::string &err);
     bool build(int meshThreshold, int sceneThreshold, std::string &err);
+    // Scene file (xrt_scene_save / xrt_scene_load): the meshes, materials, texels and bodies exactly as they were added --
+    // what the reference keeps in .xnb files (Model.Tag, TMP:113-117) -- little-endian, no pointers.  The trees are rebuilt on load.
+    bool save(const char *path, std::string &err) const;
+    bool load(const char *path, std::string &err);
     SceneView host_view() const;   // pointers into `arrays` (CPU single-stepping in tests/emul only)
 };
 

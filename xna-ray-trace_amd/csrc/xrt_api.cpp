@@ -1302,6 +1302,26 @@ int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_thre
     return scene_upload(scene);
 }
 
+int xrt_scene_save(const xrt_scene *scene, const char *path) {
+    if (!scene || !path) return fail(XRT_E_INVALID_ARG, "xrt_scene_save: null argument");
+    std::string err;
+    if (!scene->hs.save(path, err)) return fail(XRT_E_INVALID_ARG, "%s (%s)", err.c_str(), path);
+    return XRT_OK;
+}
+
+int xrt_scene_load(int device, const char *path, xrt_scene **scene_out) {
+    if (!scene_out || !path) return fail(XRT_E_INVALID_ARG, "xrt_scene_load: null argument");
+    int rc = xrt_scene_create(device, scene_out);
+    if (rc != XRT_OK) return rc;
+    std::string err;
+    if (!(*scene_out)->hs.load(path, err)) {
+        delete *scene_out;
+        *scene_out = nullptr;
+        return fail(XRT_E_INVALID_ARG, "%s (%s)", err.c_str(), path);
+    }
+    return XRT_OK;
+}
+
 int xrt_scene_get_tree(const xrt_scene *scene, int32_t mesh_id, xrt_node_info *nodes, int64_t *n_nodes_inout, int32_t *refs,
                        int64_t *n_refs_inout) {
     if (!scene || !n_nodes_inout || !n_refs_inout) return fail(XRT_E_INVALID_ARG, "xrt_scene_get_tree: null argument");

@@ -97,7 +97,8 @@ struct MaterialRec {    // 32 B (MAT:234-268)
     int   flags;        // bit0 transparent, bit1 interpolateNormals, bit2 useTexture
     int   texOffset;    // into texels[]
     int   texWidth, texHeight;
-    int   pad0, pad1;
+    int   texOffsetP;   // Texture.ColorData (premultiplied copy, TEX:24-33) for the bilinear filter; == texOffset when the host gave none
+    int   pad1;
 };
 constexpr int MAT_TRANSPARENT = 1, MAT_INTERP = 2, MAT_TEXTURE = 4;
 

@@ -160,8 +160,15 @@ def load_fbx(path):
     return load_ascii(data.decode("latin-1"))
 
 
-def import_mesh(fm, up_axis=1, scale=1.0, diffuse_color=(255, 255, 255, 255), apply_node_transform=True, flip_v=True):
-    """FbxMesh -> fixtures.MeshData with TracerModelProcessor semantics (see module docstring)."""
+def import_mesh(fm, up_axis=1, scale=1.0, diffuse_color=(255, 255, 255, 255), apply_node_transform=True, flip_v=True,
+                rotation=(0.0, 0.0, 0.0)):
+    """FbxMesh -> fixtures.MeshData with TracerModelProcessor semantics (see module docstring).
+
+    `scale` and `rotation` (degrees) are the ModelProcessor parameters Scale / RotationX / RotationY / RotationZ of the content
+    project (contentproj:116,190,203,224): the base processor transforms the whole scene before TracerModelProcessor bakes the
+    absolute transforms into the vertices (TMP:105-107,179-181).  XNA's ModelProcessor is closed source; the build's definition:
+    scene transform = CreateScale(Scale) * CreateRotationX * CreateRotationY * CreateRotationZ, applied after the importer's
+    axis conversion; normals take the rotation part (its inverse transpose is itself)."""
     if apply_node_transform:
         rad = [f32(np.deg2rad(float(a))) for a in fm.rotation]
         world, _, _ = xna.build_world(fm.scaling, rad, fm.translation, np.zeros(6, dtype=np.float32))
@@ -171,17 +178,26 @@ def import_mesh(fm, up_axis=1, scale=1.0, diffuse_color=(255, 255, 255, 255), ap
     inv = xna.invert(world)
     invT = [inv[4 * j + i] for i in range(4) for j in range(4)]
     s = f32(scale)
+    rotated = any(float(a) != 0.0 for a in rotation)
+    rot = None
+    if rotated:   # CreateRotationX * CreateRotationY * CreateRotationZ (MathHelper.ToRadians of the parameters), no translation, unit scale
+        rot, _, _ = xna.build_world((1.0, 1.0, 1.0), [f32(np.deg2rad(float(a))) for a in rotation], (0.0, 0.0, 0.0), np.zeros(6, dtype=np.float32))
 
     def pos(p):
         v = xna.transform(xna.vec3(*[float(x) for x in p]), world)
         if up_axis == 2:
             v = [v[0], v[2], -v[1]]
-        return tuple(float(c * s) for c in v)
+        v = [c * s for c in v]
+        if rotated:
+            v = xna.transform(xna.vec3(*[float(c) for c in v]), rot)
+        return tuple(float(c) for c in v)
 
     def nrm(nv):
         v = xna.transform(xna.vec3(*[float(x) for x in nv]), invT)
         if up_axis == 2:
             v = [v[0], v[2], -v[1]]
+        if rotated:
+            v = xna.transform(xna.vec3(*[float(c) for c in v]), rot)
         return tuple(float(c) for c in xna.normalize(v))
     tris, nrms, uvs = [], [], []
     pv = 0   # polygon-vertex counter
