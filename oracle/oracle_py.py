@@ -9,7 +9,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# XRT_ORACLE_LIB=liboracle_asan.so: the sanitizer build (make -C oracle liboracle_asan.so; run the CPU suite with libasan preloaded,
+# tools/asan_cpu_suite.sh)
+LIB_PATH = os.path.join(_HERE, os.environ.get("XRT_ORACLE_LIB", "liboracle.so"))
 _pkg = importlib.import_module("xna-ray-trace_amd")
 abi, xna = _pkg.abi, _pkg.xna
 RAY_DTYPE, HIT_DTYPE, NODE_DTYPE = _pkg.RAY_DTYPE, _pkg.HIT_DTYPE, _pkg.NODE_DTYPE
@@ -19,7 +21,7 @@ _F = C.POINTER(C.c_float)
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    subprocess.check_call(["make", "-s", "-C", _HERE, os.path.basename(LIB_PATH)])
 
 
 def lib():

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB = os.path.join(_HERE, "emul", "libemul.so")
+LIB = os.path.join(_HERE, "emul", os.environ.get("XRT_EMUL_LIB", "libemul.so"))   # XRT_EMUL_LIB=libemul_asan.so: tools/asan_cpu_suite.sh
 _pkg = importlib.import_module("xna-ray-trace_amd")
 abi, xna = _pkg.abi, _pkg.xna
 RAY_DTYPE, HIT_DTYPE, NODE_DTYPE = _pkg.RAY_DTYPE, _pkg.HIT_DTYPE, _pkg.NODE_DTYPE
@@ -22,6 +22,8 @@ def build():
     csrc = os.path.join(_ROOT, "xna-ray-trace_amd", "csrc")
     srcs = [os.path.join(_HERE, "emul", "emul.cpp"), os.path.join(csrc, "scene_build.cpp"), os.path.join(csrc, "scene_host.cpp")]
     deps = srcs + [os.path.join(csrc, h) for h in ("traverse.h", "xrt_core.h", "scene_host.h", "scene_build.h")]
+    if os.environ.get("XRT_EMUL_LIB"):
+        return   # a prebuilt variant
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared", "-o", LIB] + srcs)

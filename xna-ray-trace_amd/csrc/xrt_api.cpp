@@ -3,6 +3,8 @@
 // uses the HIP runtime API); all arithmetic of the path runs in kernels.hip.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <atomic>
 #include <algorithm>
 #include <cmath>
@@ -49,6 +51,36 @@ int fail(int code, const char *fmt, ...) {
 // single-chunk path (no host round trips, two frames overlapping).
 constexpr int MAX_CHUNK_PATHS = 1 << 25;
 constexpr int HEAP_RAY_CAP = 1 << 22;      // rays per generation of a ray-tree chunk
+
+// roctx ranges around the stages of a frame, for `rocprofv3 --marker-trace --kernel-trace`: XRT_ROCTX=1 loads the
+// marker library on first use (no load-time dependency, nothing is called otherwise).  The ranges bracket the ENQUEUE of a
+// stage on the host; the kernels they enqueue carry the same names in the kernel trace.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    bool on = false;
+    Roctx() {
+        if (!getenv("XRT_ROCTX")) return;
+        for (const char *n : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (void *h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) { on = true; return; }
+            }
+        }
+    }
+};
+Roctx &roctx() { static Roctx r; return r; }
+struct Range {   // RAII: a named range for the enclosing scope
+    bool on;
+    explicit Range(const char *fmt, int k = 0) : on(roctx().on) {
+        if (!on) return;
+        char buf[64];
+        snprintf(buf, sizeof(buf), fmt, k);
+        roctx().push(buf);
+    }
+    ~Range() { if (on) roctx().pop(); }
+};
 
 template <class T>
 struct DevBuf {
@@ -544,7 +576,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             return H;
         };
         // cnt[0] counts the primary rays that reach the scene's root box; index0 lists them
-        launch_raygen(gp, S, rays[0], W.lvlB.p, W.index0.p, cnt, Pc, pathBase, heavy_for(0), st, fast ? e0 : nullptr);
+        { Range r("xrt raygen"); launch_raygen(gp, S, rays[0], W.lvlB.p, W.index0.p, cnt, Pc, pathBase, heavy_for(0), st, fast ? e0 : nullptr); }
         xrt_hit *hitsOf[2] = {W.hits.p, W.hits1.p};
         SlotRec *slotOf[2] = {W.slot0.p, W.slot1.p};
         for (int k = 0; k <= R + 1; k++) {
@@ -576,6 +608,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 launch_packet(S, PA, grid, st, a0, a1);
                 return XRT_OK;
             };
+            Range ri("xrt intersect #%d", k);
             if (pkC && (rc = launch_pk(C, 0, k == 0 ? Pc : -1))) return rc;
             if (pkB && (rc = launch_pk(B, 1, -1))) return rc;
             const bool laneC = hasClosest && !pkC, laneB = hasShadow && !pkB;
@@ -592,6 +625,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 if (hasClosest) launch_count(S, C, s->counters.p, st);
                 if (hasShadow) launch_count(S, B, s->counters.p + C_COUNT, st);
             }
+            if (ri.on) { roctx().pop(); ri.on = false; }
+            Range rs("xrt shade #%d", k);
             ShadeArgs X;
             std::memset(&X, 0, sizeof(X));
             X.level = k; X.doA = hasClosest ? 1 : 0; X.doB = k >= 1 ? 1 : 0;
@@ -608,6 +643,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             if (feedback && hasClosest) { X.costOut = s->costMap.p + (size_t)k * (size_t)framePaths + (size_t)partStart; X.epoch = s->epoch & 0xffffu; }
             launch_shade(S, V, X, st);
         }
+        Range rc_("xrt compose");
         if (heap) launch_compose_tree(W.lvlA.p, W.lvlB.p, s->lvlAlpha.p, Pc, P, R, W.sampleColor.p, wantF32 ? W.sampleF32.p : nullptr, st);
         else {
             ResolveArgs RA;
@@ -1025,6 +1061,7 @@ int multi_end(xrt_scene *s, int slot, int n, xrt_stats *stats) {
 int open_frame(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts, uint32_t *d_out,
                float *d_outF32, uint32_t *host_out, hipStream_t st) {
     if (!cam || !opts) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
+    Range rf("xrt frame (ticket %d)", slot);
     if (opts->n_gpus < 0) return fail(XRT_E_INVALID_ARG, "n_gpus must not be negative");
     const int n = opts->n_gpus > 1 ? opts->n_gpus : 1;
     if (n > 1 && d_outF32) return fail(XRT_E_UNSUPPORTED, "rgb_f32_out with n_gpus > 1");
