@@ -292,7 +292,7 @@ int xrt_render_device_end(xrt_scene *scene, int32_t ticket, xrt_stats *stats_out
 
 /* Image-tile shard geometry: tiles are XRT_TILE_W x XRT_TILE_H pixels, numbered row-major, tile t is
  * owned by rank t % shard_count and stored at slot t / shard_count of that rank's buffer.  Inside a tile's 512 words
- * the pixels are stored as eight 8x8-pixel blocks, left to right, each block row-major (the order the wavefronts
+ * the pixels are stored as eight 8x8-pixel blocks, left to right, Z-order inside a block (the order the wavefronts
  * trace them in); xrt_detile_device undoes it. */
 #define XRT_TILE_W 64
 #define XRT_TILE_H 8

@@ -90,18 +90,23 @@ def test_no_contracted_fma_in_any_kernel(isa):
 
 
 def test_hot_kernel_resources(isa):
-    """k_intersect must stay within 128 VGPRs without scratch (4 waves per SIMD, MI355X_MICROARCH.md register table).
-    Scene mode parks 27 words per lane in LDS, so its deep-stack variants trade a wave for that: (T + 27) KB + 256 B per block."""
+    """k_intersect's register budget (MI355X_MICROARCH.md register table).  Scene mode: <= 128 VGPRs without scratch, 4 waves per
+    SIMD; it parks 27 words per lane in LDS, so its deep-stack variants trade a wave for that: (T + 27) KB + 256 B per block.
+    One-body and per-mesh modes: 5 waves per SIMD (96 VGPRs) at the price of at most 8 spilled registers (measured: C5 per-lane
+    frames -8 %, the others unchanged); their 40-level variants keep 4 waves (40 KB of LDS stack per block)."""
     usage = open(os.path.join(CSRC, "kernels.usage.txt")).read()
     blocks = re.findall(r"Function Name: (\S*k_intersectILi(\d+)ELi(\d)E\S*).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
                         usage, flags=re.S)
     assert len(blocks) == 15
     for name, cap, mode, vgprs, scratch, occ in blocks:
-        want = 4
-        if int(mode) == 0 and int(cap) > 12:
-            want = 160 * 1024 // ((int(cap) + 27) * 1024 + (512 if int(cap) < 40 else 0))
-        budget = {4: 128, 3: 168, 2: 256}[want]   # where LDS already limits the waves per SIMD the compiler may use their registers
-        assert int(vgprs) <= budget and int(scratch) == 0 and int(occ) >= want, (name, vgprs, scratch, occ)
+        if int(mode) == 0:
+            want, spill = 4, 0
+            if int(cap) > 12:
+                want = 160 * 1024 // ((int(cap) + 27) * 1024 + (512 if int(cap) < 40 else 0))
+        else:
+            want, spill = (5, 32) if int(cap) < 40 else (4, 0)
+        budget = {5: 96, 4: 128, 3: 168, 2: 256}[want]   # where LDS already limits the waves per SIMD the compiler may use their registers
+        assert int(vgprs) <= budget and int(scratch) <= spill and int(occ) >= want, (name, vgprs, scratch, occ)
 
 
 def test_packet_kernel_resources(isa):

@@ -62,6 +62,7 @@ struct PacketArgs {
     unsigned *queue = nullptr;    // zeroed work-queue word of this launch
     int mode = MODE_SINGLE, meshId = 0;
     int unmark = 0;               // rays may carry the long-ray mark of their producer (device_util.h)
+    int staticDiv = 4;            // 1/staticDiv of the packets are dealt statically (0: none)
 };
 bool packet_supported(int mode, int meshDepth);
 int  packet_blocks_per_cu(int mode);

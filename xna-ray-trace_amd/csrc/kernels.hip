@@ -241,7 +241,7 @@ template <int T> __device__ __forceinline__ unsigned char *coop_memory() {
 }
 
 template <int T, int M>
-__global__ __launch_bounds__(256, 4) void k_intersect(SceneView S, IntersectArgs A) {
+__global__ __launch_bounds__(256, (M == MODE_SCENE) ? 4 : 5) void k_intersect(SceneView S, IntersectArgs A) {
     __shared__ unsigned stk[4 * T * 64];
     unsigned *const parkMem = park_memory<M>();
     unsigned char *const coopOwn = coop_memory<T>();

@@ -48,15 +48,15 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
     int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
     if (A.nCap > 0 && n > A.nCap) n = A.nCap;
     const int nPk = (n + 63) >> 6;
-    // Work distribution.  Half of the packets are dealt statically and strided -- wave w takes packets w, w + nWaves, .. -- so that
+    // Work distribution.  A quarter (PacketArgs::staticDiv) of the packets are dealt statically and strided -- wave w takes packets w, w + nWaves, .. -- so that
     // every wave sees a fair sample of the image (rays skimming the surface near the horizon cost tens of times the average) while
-    // neighbouring waves work on neighbouring packets at the same time (their leaves are in cache); the other half comes from a
+    // neighbouring waves work on neighbouring packets at the same time (their leaves are in cache); the rest comes from a
     // queue, guided: 1/(2 * waves) of what is left per atomic, at most 8 packets, at least one.  (Measured against the
     // alternatives on the 16-sub-ray frame: one ticket per packet from eight sharded queue words -- equal for primary rays, 40 %
     // slower for shadow and reflection packets; runs of 8 packets scattered over the image -- 20 % slower, the cache locality
     // between neighbouring waves is worth more than the balance.)  The grid is sized to be resident at once (packet_blocks_per_cu).
     const int nWaves = (int)gridDim.x * 4, waveId = (int)blockIdx.x * 4 + wave;
-    const int staticPer = nPk / (nWaves * 2), qBase = nWaves * staticPer;
+    const int staticPer = A.staticDiv > 0 ? nPk / (nWaves * A.staticDiv) : 0, qBase = nWaves * staticPer;
     int sNext = 0, dNext = 0, dEnd = 0, left = nPk - qBase;
     for (;;) {
         int pk;

@@ -130,6 +130,7 @@ struct xrt_scene {
     // none otherwise (64 pixels of a 1-sample frame fan out over too many leaves: 5 x slower than the per-lane kernel).
     // XRT_PACKET=<mask> forces it: bit 0 primary rays, 1 shadow rays, 2 closest-hit rays of later generations, 3 seam-1 batches.
     int packetMask = -1;
+    int packetStaticDiv = 4;   // XRT_PK_STATIC (development): 1/2 .. 1/8 measured within 2 % of each other on C5
     int sceneMode = MODE_SCENE;   // MODE_SINGLE when the scene is one SceneObject with one Mesh
     hipStream_t stream = nullptr;
     // per-frame work buffers
@@ -599,7 +600,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             auto launch_pk = [&](const IntersectArgs &I, int word, long long nHost) -> int {
                 PacketArgs PA;
                 PA.rays = I.rays; PA.hits = I.hits; PA.index = I.index; PA.nDev = I.nDev; PA.nMul = I.nMul; PA.n = I.n; PA.nCap = I.nCap;
-                PA.queue = q + QW * k + 1 + word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0;
+                PA.queue = q + QW * k + 1 + word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv;
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 pairs.push_back({ev, ev + 1}); ev += 2;
@@ -1272,6 +1273,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     s->device = device;
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
     s->fakeGpus = getenv("XRT_FAKE_GPUS") != nullptr;
+    if (const char *e = getenv("XRT_PK_STATIC")) { const int v = atoi(e); if (v >= 0 && v <= 64) s->packetStaticDiv = v; }
     if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 15) s->packetMask = v; }
     if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
     if (const char *e = getenv("XRT_SPLIT_MS")) s->splitMinMs = (float)atof(e);

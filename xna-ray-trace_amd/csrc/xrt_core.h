@@ -118,13 +118,15 @@ struct LightRec {       // 64 B
 };
 
 // Position of path slot `within` (0..511) inside its 64x8-pixel tile.  A wavefront takes 64 consecutive slots; laid out as
-// eight 8x8-pixel blocks side by side they cover a square patch of the image instead of a 64-pixel line, so the 64 rays of a
+// eight 8x8-pixel blocks side by side (Z-order inside a block) they cover a square patch of the image instead of a 64-pixel line, so the 64 rays of a
 // wave stay close together in the scene (fewer distinct octree leaves per wave, for the per-lane and the wave-packet kernel
 // alike).  Every kernel, the host's ray export and the tile-shard layout (xrt.h XRT_TILE_*, dist.py) use this one map.
 XRT_HD void tile_slot_xy(int within, int &x, int &y) {
     const int blk = within >> 6, i = within & 63;
-    x = blk * 8 + (i & 7);
-    y = i >> 3;
+    // Z-order inside the 8x8 block: consecutive slots stay together at every scale (4 slots = a 2x2 quad, 16 = 4x4), so the
+    // 4 pixels x 16 samples of a wave of a 16-sub-ray frame are a 2x2 quad, not a 4x1 strip
+    x = blk * 8 + ((i & 1) | ((i >> 1) & 2) | ((i >> 2) & 4));
+    y = ((i >> 1) & 1) | ((i >> 2) & 2) | ((i >> 3) & 4);
 }
 
 // ---- Vector3 (XNA definitions) ---------------------------------------------------------

@@ -23,14 +23,27 @@ def shard_layout(width, height, world):
     return tx, ty, (tx * ty + world - 1) // world
 
 
+def _slot_xy():
+    """x, y of the 512 path slots of a tile: eight 8x8-pixel blocks side by side, Z-order inside a block (xrt_core.h tile_slot_xy)."""
+    w = np.arange(512)
+    blk, i = w >> 6, w & 63
+    x = blk * 8 + ((i & 1) | ((i >> 1) & 2) | ((i >> 2) & 4))
+    y = ((i >> 1) & 1) | ((i >> 2) & 2) | ((i >> 3) & 4)
+    return x, y
+
+
+_SLOT_X, _SLOT_Y = _slot_xy()
+
+
 def _tile_to_slots(tile):
-    """(TILE_H, TILE_W) pixels -> the 512 path slots of a tile: eight 8x8-pixel blocks side by side, each row-major
-    (xrt_core.h tile_slot_xy)."""
-    return tile.reshape(abi.TILE_H, abi.TILE_W // 8, 8).transpose(1, 0, 2).reshape(-1)
+    """(TILE_H, TILE_W) pixels -> the 512 path slots of a tile."""
+    return tile[_SLOT_Y, _SLOT_X]
 
 
 def _slots_to_tile(slots):
-    return slots.reshape(abi.TILE_W // 8, abi.TILE_H, 8).transpose(1, 0, 2).reshape(abi.TILE_H, abi.TILE_W)
+    tile = np.zeros((abi.TILE_H, abi.TILE_W), dtype=slots.dtype)
+    tile[_SLOT_Y, _SLOT_X] = slots
+    return tile
 
 
 def pack_shard(frame, width, height, rank, world):
