@@ -425,7 +425,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.config], "width": res["width"], "height": res["height"], "triangles": res["tris"],
                        "instances": res["instances"], "rays_per_frame": int(rays_frame),
-                       "rays_closest_per_frame": int(st["rays_closest"]), "rays_shadow_per_frame": int(st["rays_shadow"]),
+                       "rays_closest_per_frame": int(st["rays_closest"]) if world == 1 else None, "rays_shadow_per_frame": int(st["rays_shadow"]) if world == 1 else None,
                        "parallelism": "image tiles 64x8 round-robin x%d" % world, "scene_build_s": round(res["build_s"], 3)},
             "roofline": roofline_block(args.config if world == 1 else "(N > 1: no PMC pass)", bytes_per_launch, ms_per_launch, launches // max(args.steps, 1), serial),
         }
