@@ -492,15 +492,20 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             st = W.stream;
         } else st = s->stream;
     }
+    // which ray populations the wave-packet kernel traces this frame (packet.hip): bit 0 primary rays, 1 shadow rays, 2 closest-hit
+    // rays of later generations
+    const int pkMask = (s->packetOk && !heap) ? (s->packetMask >= 0 ? s->packetMask : (g.samples >= 16 ? 7 : 0)) : 0;
+    const bool laneClosest = (pkMask & 5) != 5;   // some closest-hit generation is traced ray by ray: the long-ray feedback has a reader
+    const bool wantFeedback = fast && s->deepMeshes && !s->noFeedback && laneClosest;
     {   // The other context's frame may still be running on another stream.  Two single-chunk frames share nothing they
         // write except scheduling hints; anything else (counting pass, supersampling levels, ray tree, a cost map
-        // about to be reallocated) runs alone.
-        const bool remap = fast && s->deepMeshes && (s->costMapPaths != (size_t)framePaths || s->costMap.cap < (size_t)(R + 1) * (size_t)framePaths);
+        // about to be reallocated or released) runs alone.
+        const bool remap = wantFeedback ? (s->costMapPaths != (size_t)framePaths || s->costMap.cap < (size_t)(R + 1) * (size_t)framePaths) : (s->costMap.p != nullptr);
         for (xrt_scene::FrameCtx &O : s->frames)
             if (&O != &F && O.pending && O.w.lastStream != st && (!fast || !O.fast || remap)) HIPCHECK(hipEventSynchronize(O.fast ? O.events[1] : O.done));
         W.lastStream = st;
     }
-    if (fast && s->deepMeshes && !s->noFeedback) {
+    if (wantFeedback) {
         const size_t need = (size_t)(R + 1) * (size_t)framePaths;
         if (s->costMapPaths != (size_t)framePaths || s->costMap.cap < need) {   // new frame geometry: forget
             if ((rc = s->costMap.ensure(need))) return rc;
@@ -563,11 +568,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         // "long ray first" (kernels.hip): the producer of generation k lists its long rays, launch #k takes them first
         const bool feedback = fast && s->deepMeshes && s->costMap.p != nullptr;
         const bool listLong = s->heavyPath > 0.0f || feedback;
-        // which segments the wave-packet kernel traces (coherent populations; packet.hip): bit 0 primary rays, bit 1 shadow
-        // rays, bit 2 the closest-hit rays of later generations
-        const int pkMask = s->packetMask >= 0 ? s->packetMask : (gp.samples >= 16 ? 7 : 0);
-        auto packet_closest = [&](int k) { return s->packetOk && !heap && (k == 0 ? (pkMask & 1) : (pkMask & 4)) != 0; };
-        const bool packetShadow = s->packetOk && !heap && (pkMask & 2) != 0;
+        auto packet_closest = [&](int k) { return (k == 0 ? (pkMask & 1) : (pkMask & 4)) != 0; };
+        const bool packetShadow = (pkMask & 2) != 0;
         auto heavy_for = [&](int k) {
             HeavyArgs H;
             if (listLong && (k == 0 || !heap) && !packet_closest(k)) {   // (packets are not scheduled ray by ray)
