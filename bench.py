@@ -461,7 +461,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(spec)
         if world == 1 and not args.no_extra and args.scale == 1.0:
             other = {}
-            for name, k in (("C2", 20), ("C3", 5), ("C4", 3)):
+            for name, k in (("C2", 20), ("C3", 5), ("C4", 3), ("G1", 5)):   # G1: the scene the reference's own Stopwatch would time (Game1.cs)
                 if name == args.config:
                     continue
                 try:
