@@ -310,6 +310,16 @@ def test_fbx_import_of_the_reference_assets(xrt):
         got = fbx.import_mesh(ms[0], up, **kw)
         assert np.array_equal(got.v, zc[name + "_v"]) and np.array_equal(got.n, zc[name + "_n"]) and np.array_equal(got.color, zc[name + "_color"])
         assert ((got.surface_normal * got.n[:, 0, :]).sum(axis=1) > 0).mean() > 0.99
+    # binary FBX 7.1 (zlib-compressed arrays, Geometry -> Model connections): the last two of the content directory's 17 files
+    ms, up = fbx.load_fbx(os.path.join(REF_CONTENT, "dna_exported_from_max2011.FBX"))
+    assert len(ms) == 40 and all(len(m.polygons) == 1596 for m in ms[:3])
+    dna = fbx.import_mesh(ms[0], up)
+    assert dna.ntri == 1728 and ((dna.surface_normal * dna.n[:, 0, :]).sum(axis=1) > 0).all()
+    ms, up = fbx.load_fbx(os.path.join(REF_CONTENT, "Sony_3D_Logo_by_Peter_Iliev_fbx.FBX"))
+    assert len(ms) == 1 and fbx.import_mesh(ms[0], up).ntri == 3268
+    import glob
+    files = sorted(glob.glob(os.path.join(REF_CONTENT, "*.fbx")) + glob.glob(os.path.join(REF_CONTENT, "*.FBX")))
+    assert len(files) == 17 and all(len(fbx.load_fbx(f)[0]) >= 1 for f in files)
     ms, up = fbx.load_fbx(os.path.join(REF_CONTENT, "wossy.fbx"))
     plain, turned = fbx.import_mesh(ms[0], up, scale=32.0), fbx.import_mesh(ms[0], up, scale=32.0, rotation=(0.0, 180.0, 0.0))
     assert turned.ntri == plain.ntri == 9420

@@ -1,4 +1,4 @@
-"""Asset ingestion: FBX 6.x (ASCII 6.1 as written by Blender, binary 6100 as written by 3ds Max)
+"""Asset ingestion: FBX 6.x (ASCII 6.1 as written by Blender, binary 6100 as written by 3ds Max) and binary 7.1-7.4
 -> the triangle arrays a `Mesh` carries, with the semantics of RayTracePipeline/TracerModelProcessor.cs:
 vertices are baked with the node's absolute transform (TMP:179-181), normals with its inverse transpose and
 re-normalised (TMP:191-197), surfaceNormal = normalize(cross(v3-v1, v2-v1)) (TMP:199-203), the mesh AABB starts at
@@ -153,9 +153,132 @@ def load_binary(b):
     return [fm], (int(up[0]) if up else 1)
 
 
+# ---- binary FBX 7.x (7100-7400: 32-bit record offsets) ---------------------------------------------------------------------
+# Header: 21-byte magic, 2 bytes, uint32 version.  Node record: uint32 endOffset, numProperties, propertyListLen; uint8 nameLen; name;
+# properties; nested records up to endOffset (a 13-byte zero record closes a list).  Property: a type byte, then Y int16, C bool,
+# I int32, F float, D double, L int64; S / R: uint32 length + bytes; arrays f d l i b: uint32 count, encoding (1 = zlib), byte
+# length, data.
+class _Node:
+    __slots__ = ("name", "props", "children")
+
+    def __init__(self, name, props, children):
+        self.name, self.props, self.children = name, props, children
+
+    def find(self, name):
+        return [c for c in self.children if c.name == name]
+
+    def first(self, name):
+        r = self.find(name)
+        return r[0] if r else None
+
+
+def _read_prop7(b, pos):
+    import zlib
+    t = b[pos:pos + 1]
+    pos += 1
+    scalar = {b"Y": "<h", b"C": "<?", b"I": "<i", b"F": "<f", b"D": "<d", b"L": "<q"}
+    if t in scalar:
+        fmt = scalar[t]
+        return struct.unpack_from(fmt, b, pos)[0], pos + struct.calcsize(fmt)
+    if t in (b"S", b"R"):
+        n = struct.unpack_from("<I", b, pos)[0]
+        raw = bytes(b[pos + 4:pos + 4 + n])
+        return (raw.decode("latin-1") if t == b"S" else raw), pos + 4 + n
+    arr = {b"f": "<f4", b"d": "<f8", b"l": "<i8", b"i": "<i4", b"b": "u1"}
+    if t in arr:
+        count, enc, nbytes = struct.unpack_from("<III", b, pos)
+        raw = bytes(b[pos + 12:pos + 12 + nbytes])
+        if enc == 1:
+            raw = zlib.decompress(raw)
+        return np.frombuffer(raw, dtype=arr[t], count=count), pos + 12 + nbytes
+    raise ValueError("FBX 7: unknown property type %r at %d" % (t, pos - 1))
+
+
+def _read_node7(b, pos):
+    end, nprops, _plen = struct.unpack_from("<III", b, pos)
+    nlen = b[pos + 12]
+    if end == 0:
+        return None, pos + 13
+    name = bytes(b[pos + 13:pos + 13 + nlen]).decode("latin-1")
+    p = pos + 13 + nlen
+    props = []
+    for _ in range(nprops):
+        v, p = _read_prop7(b, p)
+        props.append(v)
+    children = []
+    while p < end:
+        c, p = _read_node7(b, p)
+        if c is None:
+            break
+        children.append(c)
+    return _Node(name, props, children), end
+
+
+def load_binary7(b):
+    """Binary FBX 7.x: Objects/Geometry (Vertices, PolygonVertexIndex, LayerElementNormal, LayerElementUV), the Model each geometry
+    is connected to (Connections "OO") for its Lcl transform, GlobalSettings/UpAxis."""
+    version = struct.unpack_from("<I", b, 23)[0]
+    if version >= 7500:
+        raise ValueError("FBX %d: 64-bit record offsets are not read" % version)
+    pos, top = 27, []
+    while pos < len(b) - 13:
+        n, pos = _read_node7(b, pos)
+        if n is None:
+            break
+        top.append(n)
+    root = _Node("", [], top)
+
+    def p70(node, key, default):
+        pr = node.first("Properties70") if node is not None else None
+        if pr is not None:
+            for p in pr.find("P"):
+                if p.props and p.props[0] == key:
+                    return [x for x in p.props[4:]]
+        return default
+    gs = root.first("GlobalSettings")
+    up = int(p70(gs, "UpAxis", [1])[0])
+    objects = root.first("Objects")
+    models = {m.props[0]: m for m in objects.find("Model")} if objects is not None else {}
+    parent = {}
+    conns = root.first("Connections")
+    if conns is not None:
+        for c in conns.find("C"):
+            if c.props and c.props[0] == "OO":
+                parent[c.props[1]] = c.props[2]
+    meshes = []
+    for g in (objects.find("Geometry") if objects is not None else []):
+        verts, pvi = g.first("Vertices"), g.first("PolygonVertexIndex")
+        if verts is None or pvi is None:
+            continue
+        fm = FbxMesh(str(g.props[1]).split("\x00")[0] if len(g.props) > 1 else "mesh")   # ("name\0\1Geometry")
+        fm.vertices = np.asarray(verts.props[0], dtype=np.float64).reshape(-1, 3)
+        fm.polygons = _split_polygons([int(x) for x in pvi.props[0]])
+        ln = g.first("LayerElementNormal")
+        if ln is not None and ln.first("Normals") is not None:
+            fm.normals = np.asarray(ln.first("Normals").props[0], dtype=np.float64).reshape(-1, 3)
+            fm.normal_mapping = ln.first("MappingInformationType").props[0]
+            ni = ln.first("NormalsIndex")
+            if ni is not None and ln.first("ReferenceInformationType").props[0] == "IndexToDirect":
+                fm.normals = fm.normals[np.asarray(ni.props[0], dtype=np.int64)]
+        lu = g.first("LayerElementUV")
+        if lu is not None and lu.first("UV") is not None:
+            fm.uvs = np.asarray(lu.first("UV").props[0], dtype=np.float64).reshape(-1, 2)
+            fm.uv_mapping = lu.first("MappingInformationType").props[0]
+            ui = lu.first("UVIndex")
+            fm.uv_index = [int(x) for x in ui.props[0]] if ui is not None else None
+        model = models.get(parent.get(g.props[0]))
+        fm.translation = tuple(float(x) for x in p70(model, "Lcl Translation", [0.0, 0.0, 0.0])[:3])
+        fm.rotation = tuple(float(x) for x in p70(model, "Lcl Rotation", [0.0, 0.0, 0.0])[:3])
+        fm.scaling = tuple(float(x) for x in p70(model, "Lcl Scaling", [1.0, 1.0, 1.0])[:3])
+        meshes.append(fm)
+    return meshes, up
+
+
 def load_fbx(path):
     data = open(path, "rb").read()
     if data.startswith(b"Kaydara FBX Binary"):
+        if struct.unpack_from("<I", data, 23)[0] >= 7000:
+            return load_binary7(data)
         return load_binary(data)
     return load_ascii(data.decode("latin-1"))
 
