@@ -57,8 +57,17 @@ namespace RayTraceProject.Spatial
                         texWidth = mat.UseTexture ? mat.TextureWidth : 0, texHeight = mat.UseTexture ? mat.TextureHeight : 0,
                         texArgb = mat.UseTexture ? mat.TextureScan0 : IntPtr.Zero
                     };
+                    // the bilinear filter reads Material.Texture.ColorData, the premultiplied Format32bppPArgb copy (RayTracerTexture.cs:24-33,
+                    // Material.cs:186-189): pinned for the call (the library copies it)
+                    System.Runtime.InteropServices.GCHandle pin = default(System.Runtime.InteropServices.GCHandle);
+                    if (mat.UseTexture && mat.Texture != null && mat.Texture.ColorData != null)
+                    {
+                        pin = System.Runtime.InteropServices.GCHandle.Alloc(mat.Texture.ColorData, System.Runtime.InteropServices.GCHandleType.Pinned);
+                        xm.texPArgb = pin.AddrOfPinnedObject();
+                    }
                     int id;
-                    Xrt.Check(Xrt.xrt_scene_add_mesh(this.scene, v, n, uv, sn, col, t.Length, ref xm, B(mesh.MeshBoundingBox), out id));
+                    try { Xrt.Check(Xrt.xrt_scene_add_mesh(this.scene, v, n, uv, sn, col, t.Length, ref xm, B(mesh.MeshBoundingBox), out id)); }
+                    finally { if (pin.IsAllocated) pin.Free(); }
                     this.meshIds[mesh] = id; this.meshesById.Add(mesh);
                 }
             foreach (SceneObject so in this.objects)
@@ -70,6 +79,16 @@ namespace RayTraceProject.Spatial
                                                    B(so.WorldBoundingBox), out oid));
             }
             Xrt.Check(Xrt.xrt_scene_build(this.scene, 0, 0));   // thresholds 50 / 20 (MeshOctree.cs:42, OctreeSpatialManager.cs:50)
+        }
+
+        // Scene file (what the content pipeline would write instead of .xnb reflection data, TracerModelProcessor.cs:113-117):
+        // Save after Build(); Load replaces Build() at start-up (Bodies stays as the game filled it: object ids follow its order).
+        public void Save(string path) { Xrt.Check(Xrt.xrt_scene_save(this.scene, path)); }
+        public void Load(string path)
+        {
+            if (this.scene != IntPtr.Zero) Xrt.Check(Xrt.xrt_scene_destroy(this.scene));
+            Xrt.Check(Xrt.xrt_scene_load(0, path, out this.scene));
+            Xrt.Check(Xrt.xrt_scene_build(this.scene, 0, 0));
         }
 
         static void Put3(float[] a, int o, Vector3 p) { a[o] = p.X; a[o + 1] = p.Y; a[o + 2] = p.Z; }
