@@ -44,6 +44,7 @@ struct IntersectArgs {
     const int *heavyIdx = nullptr, *nHeavy = nullptr;   // rays of segment 1 to take first (marked in their records)
     unsigned long long *debugTimes = nullptr;   // [3 * waves]: start / out-of-rays / exit clocks (100 MHz) per wave, development aid
     int coopMax = 32;   // at most this many lanes in a leaf: their triangle lists are dealt to the whole wave
+    int batchMax = 64;  // largest guided batch a wave takes per queue atomic (multiple of 16)
     // optional second segment traced by the same launch: rays2[0 .. (*nDev2) * nMul2) -> hits2 (no index list)
     const xrt_ray *rays2 = nullptr;
     xrt_hit *hits2 = nullptr;

@@ -102,7 +102,6 @@ __device__ __forceinline__ int block_append(int *counter, bool flag, int *ldsCou
 }
 
 // ---- the hot kernel ------------------------------------------------------------------------------------------
-constexpr int RAY_BATCH_MAX = 512; // largest guided batch a wave takes per queue atomic
 
 // Scene mode keeps the scene-level half of every lane's query (SceneLane, 27 words: world ray, scene cursor, best answer
 // so far) in LDS: only advance_scene and the final answer touch it, through these proxies, one word at a time where it
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? 4 : 5) void k_intersect(Sc
     unsigned long long tStart = 0, tDry = 0;
     if (A.debugTimes) tStart = wall_clock64();
 #endif
-    auto guided = [&](int done) { int c = (n - done) / (nWaves * 2); c &= ~63; return c < 64 ? 64 : (c > RAY_BATCH_MAX ? RAY_BATCH_MAX : c); };
+    auto guided = [&](int done) { int c = (n - done) / (nWaves * 2); c &= ~15; const int lo = A.batchMax < 64 ? A.batchMax : 64; return c < lo ? lo : (c > A.batchMax ? A.batchMax : c); };
     unsigned pfBase = 0;
     int pfChunk = 0;
     if (!exhausted && (int)qOffset < n) {   // there is dynamic work beyond the static batches

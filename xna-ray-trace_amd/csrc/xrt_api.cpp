@@ -130,6 +130,11 @@ struct xrt_scene {
     // none otherwise (64 pixels of a 1-sample frame fan out over too many leaves: 5 x slower than the per-lane kernel).
     // XRT_PACKET=<mask> forces it: bit 0 primary rays, 1 shadow rays, 2 closest-hit rays of later generations, 3 seam-1 batches.
     int packetMask = -1;
+    // Largest guided batch of k_intersect (XRT_BATCH_MAX).  Round 1 let a wave reserve up to 512 rays per atomic; per-wave clocks
+    // (make WAVE_TIMES=1, tools/wave_times.py) showed the median wave of a C3 / C4 launch leaving at 57 % of the launch and the
+    // tail growing with the frame size -- waves stuck with eight expensive rays per lane while the queue was empty.  64: C3 3.9 ->
+    // 3.4 ms, C4 11.4 -> 9.4 ms per blocking frame; 32 and 16 lose to contention on the queue word.
+    int batchMax = 64;
     int packetStaticDiv = 4;   // XRT_PK_STATIC (development): 1/2 .. 1/8 measured within 2 % of each other on C5
     int sceneMode = MODE_SCENE;   // MODE_SINGLE when the scene is one SceneObject with one Mesh
     hipStream_t stream = nullptr;
@@ -595,7 +600,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             B.nCap = (int)((long long)shadowCap * nL);
             for (IntersectArgs *a : {&C, &B}) {
                 a->queue = q + QW * k; a->mode = s->sceneMode; a->meshId = 0;
-                a->refillMin = s->tune[0]; a->nodeBurst = s->tune[1]; a->leafBurst = s->tune[2]; a->coopMax = s->tune[3]; a->firstBatch = s->firstBatch;
+                a->refillMin = s->tune[0]; a->nodeBurst = s->tune[1]; a->leafBurst = s->tune[2]; a->coopMax = s->tune[3]; a->batchMax = s->batchMax; a->firstBatch = s->firstBatch;
             }
             // segments of coherent rays go to the wave-packet kernel, the others (together, one launch) to the per-lane kernel
             const bool pkC = hasClosest && packet_closest(k), pkB = hasShadow && packetShadow;
@@ -919,7 +924,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->batchMax = s->batchMax;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1161,7 +1166,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
     HIPCHECK(hipMemsetAsync(queue, 0, 2 * sizeof(unsigned), st));
     IntersectArgs A;
     A.rays = d_rays; A.hits = d_hits; A.index = nullptr; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.nCap = 0; A.queue = queue; A.mode = mode; A.meshId = meshId;
-    A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.coopMax = s->tune[3]; A.firstBatch = s->firstBatch;
+    A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.coopMax = s->tune[3]; A.batchMax = s->batchMax; A.firstBatch = s->firstBatch;
     hipEvent_t a0 = nullptr, a1 = nullptr;
     if (stats) {
         a0 = get_event(s, 0); a1 = get_event(s, 1);
@@ -1275,6 +1280,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     s->device = device;
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
     s->fakeGpus = getenv("XRT_FAKE_GPUS") != nullptr;
+    if (const char *e = getenv("XRT_BATCH_MAX")) { const int v = atoi(e); if (v >= 16 && v <= 4096 && v % 16 == 0) s->batchMax = v; }
     if (const char *e = getenv("XRT_PK_STATIC")) { const int v = atoi(e); if (v >= 0 && v <= 64) s->packetStaticDiv = v; }
     if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 15) s->packetMask = v; }
     if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
