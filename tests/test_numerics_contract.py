@@ -92,7 +92,7 @@ def test_no_contracted_fma_in_any_kernel(isa):
 def test_hot_kernel_resources(isa):
     """k_intersect's register budget (MI355X_MICROARCH.md register table).  Scene mode: <= 128 VGPRs without scratch, 4 waves per
     SIMD; it parks 27 words per lane in LDS, so its deep-stack variants trade a wave for that: (T + 27) KB + 256 B per block.
-    One-body and per-mesh modes: 5 waves per SIMD (96 VGPRs) at the price of at most 8 spilled registers (measured: C5 per-lane
+    One-body and per-mesh modes: 5 waves per SIMD (96 VGPRs) at the price of at most 12 spilled registers (measured: C5 per-lane
     frames -8 %, the others unchanged); their 40-level variants keep 4 waves (40 KB of LDS stack per block)."""
     usage = open(os.path.join(CSRC, "kernels.usage.txt")).read()
     blocks = re.findall(r"Function Name: (\S*k_intersectILi(\d+)ELi(\d)E\S*).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
@@ -104,7 +104,7 @@ def test_hot_kernel_resources(isa):
             if int(cap) > 12:
                 want = 160 * 1024 // ((int(cap) + 27) * 1024 + (512 if int(cap) < 40 else 0))
         else:
-            want, spill = (5, 32) if int(cap) < 40 else (4, 0)
+            want, spill = (5, 48) if int(cap) < 40 else (4, 0)
         budget = {5: 96, 4: 128, 3: 168, 2: 256}[want]   # where LDS already limits the waves per SIMD the compiler may use their registers
         assert int(vgprs) <= budget and int(scratch) <= spill and int(occ) >= want, (name, vgprs, scratch, occ)
 
