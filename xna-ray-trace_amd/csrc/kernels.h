@@ -64,6 +64,7 @@ struct PacketArgs {
     int mode = MODE_SINGLE, meshId = 0;
     int unmark = 0;               // rays may carry the long-ray mark of their producer (device_util.h)
     int staticDiv = 4;            // 1/staticDiv of the packets are dealt statically (0: none)
+    int grabMax = 2;              // most packets a wave takes per queue atomic
 };
 bool packet_supported(int mode, int meshDepth);
 int  packet_blocks_per_cu(int mode);

@@ -27,7 +27,6 @@ namespace xrt {
 
 constexpr int PK_LEVELS = 24;        // deeper octrees than this fall back to k_intersect (scene_build limits depth to 20)
 constexpr int PK_FRAME_WORDS = 12;   // blk, next child position, order mask, lanes (2), parent box min (3), half (3), pad
-constexpr int PK_GRAB_MAX = 8;       // most packets a wave takes per queue atomic
 constexpr int PK_SGPRS = 112;        // SGPR allocation the kernel may reach (checked against the ISA in tests/test_numerics_contract.py)
 
 struct PkUniform {   // wave-uniform cursor
@@ -51,7 +50,7 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
     // Work distribution.  A quarter (PacketArgs::staticDiv) of the packets are dealt statically and strided -- wave w takes packets w, w + nWaves, .. -- so that
     // every wave sees a fair sample of the image (rays skimming the surface near the horizon cost tens of times the average) while
     // neighbouring waves work on neighbouring packets at the same time (their leaves are in cache); the rest comes from a
-    // queue, guided: 1/(2 * waves) of what is left per atomic, at most 8 packets, at least one.  (Measured against the
+    // queue, guided: 1/(2 * waves) of what is left per atomic, at most PacketArgs::grabMax packets, at least one.  (Measured against the
     // alternatives on the 16-sub-ray frame: one ticket per packet from eight sharded queue words -- equal for primary rays, 40 %
     // slower for shadow and reflection packets; runs of 8 packets scattered over the image -- 20 % slower, the cache locality
     // between neighbouring waves is worth more than the balance.)  The grid is sized to be resident at once (packet_blocks_per_cu).
@@ -64,7 +63,7 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
         else {
             if (dNext >= dEnd) {
                 int want = left / (nWaves * 2);
-                want = want < 1 ? 1 : (want > PK_GRAB_MAX ? PK_GRAB_MAX : want);
+                want = want < 1 ? 1 : (want > A.grabMax ? A.grabMax : want);
                 unsigned g = 0;
                 if (lane == 0) g = atomicAdd(A.queue, (unsigned)want);
                 dNext = qBase + rfl((int)g);

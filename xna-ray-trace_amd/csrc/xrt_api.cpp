@@ -135,6 +135,7 @@ struct xrt_scene {
     // tail growing with the frame size -- waves stuck with eight expensive rays per lane while the queue was empty.  64: C3 3.9 ->
     // 3.4 ms, C4 11.4 -> 9.4 ms per blocking frame; 32 and 16 lose to contention on the queue word.
     int batchMax = 64;
+    int packetGrabMax = 2;     // XRT_PK_GRAB (development): 8 -> 2 shortened the tail of a launch (C5 blocking 9.0 -> 7.8 ms); 1 loses to contention on the queue word
     int packetStaticDiv = 4;   // XRT_PK_STATIC (development): 1/2 .. 1/8 measured within 2 % of each other on C5
     int sceneMode = MODE_SCENE;   // MODE_SINGLE when the scene is one SceneObject with one Mesh
     hipStream_t stream = nullptr;
@@ -607,7 +608,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             auto launch_pk = [&](const IntersectArgs &I, int word, long long nHost) -> int {
                 PacketArgs PA;
                 PA.rays = I.rays; PA.hits = I.hits; PA.index = I.index; PA.nDev = I.nDev; PA.nMul = I.nMul; PA.n = I.n; PA.nCap = I.nCap;
-                PA.queue = q + QW * k + 1 + word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv;
+                PA.queue = q + QW * k + 1 + word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv; PA.grabMax = s->packetGrabMax;
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 pairs.push_back({ev, ev + 1}); ev += 2;
@@ -1281,6 +1282,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
     s->fakeGpus = getenv("XRT_FAKE_GPUS") != nullptr;
     if (const char *e = getenv("XRT_BATCH_MAX")) { const int v = atoi(e); if (v >= 16 && v <= 4096 && v % 16 == 0) s->batchMax = v; }
+    if (const char *e = getenv("XRT_PK_GRAB")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->packetGrabMax = v; }
     if (const char *e = getenv("XRT_PK_STATIC")) { const int v = atoi(e); if (v >= 0 && v <= 64) s->packetStaticDiv = v; }
     if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 15) s->packetMask = v; }
     if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
