@@ -214,6 +214,7 @@ struct xrt_scene {
     int splitMode = 1, splitParts = 2;
     float splitMinMs = 1.0f;
     int tune[4] = {24, 16, 48, 32};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
+    bool tuneGiven = false;           // XRT_TUNE was set: keep it
     std::atomic<bool> busy{false};
     std::atomic<float> progress{0.0f};
     // Seam 1 (xrt_scene_intersect / xrt_mesh_intersect / xrt_generate_primary_rays) is re-entrant like the reference's
@@ -925,7 +926,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->batchMax = s->batchMax;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->batchMax = s->batchMax; r->tuneGiven = s->tuneGiven;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1227,6 +1228,11 @@ int scene_upload(xrt_scene *scene) {
     scene->blocksPerCU = intersect_blocks_per_cu(scene->stackNeeded, scene->sceneMode);
     scene->blocksPerCUMesh = intersect_blocks_per_cu(scene->stackNeeded, MODE_MESH);
     scene->packetOk = packet_supported(scene->sceneMode, A.meshDepth);
+    // Refill threshold of k_intersect.  A two-level scene refills a wave only when ALL its lanes are idle: fresh rays start in the
+    // scene phase while the others are deep in a mesh, and every partial refill made the wave run that phase for a few lanes
+    // (measured with 8x8-pixel waves, whose rays take about equally long: C3 3.1 -> 2.45 ms, C4 8.9 -> 6.2 ms of traversal per frame).
+    // One-body scenes have no such phase and keep refilling at 24 idle lanes (64 costs them 6 %).
+    if (!scene->tuneGiven) scene->tune[0] = scene->sceneMode == MODE_SCENE ? 64 : 24;
     scene->blocksPerCUPacket = packet_blocks_per_cu(scene->sceneMode);
     scene->firstBatch = (A.meshDepth == 0) ? 256 : 64;   // every mesh is a single leaf: rays are cheap, avoid queue traffic
     if (const char *e = getenv("XRT_FIRST_BATCH")) { int v = atoi(e); if (v >= 64 && v <= 4096 && v % 64 == 0) scene->firstBatch = v; }
@@ -1297,6 +1303,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
         int v[4] = {0, 0, 0, s->tune[3]};
         if (sscanf(t, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) >= 3 && v[0] >= 1 && v[0] <= 64 && v[1] >= 1 && v[2] >= 1 && v[3] >= 0 && v[3] <= 64) {
             for (int i = 0; i < 4; i++) s->tune[i] = v[i];
+            s->tuneGiven = true;
         }
     }
     if (device >= 0) {
