@@ -210,8 +210,10 @@ struct xrt_scene {
     float overlapMinMs = 0.5f;   // frames at least this long run on per-context streams
     // A launch of persistent waves leaves the machine half empty while its last rays finish; a blocking single frame (what the
     // C# host's RenderInternal asks for) has no other frame to fill the gaps, so it is rendered as two halves of its tiles on
-    // two streams.  XRT_SPLIT=0 never, 1 (default) frames nobody else overlaps, 2 also pipelined frames.
-    int splitMode = 1, splitParts = 2;
+    // two streams.  XRT_SPLIT=0 never (default), 1 frames nobody else overlaps, 2 also pipelined frames.  It paid while a launch's
+    // waves were alive 55-60 % of its duration (C4 13.3 -> 10.9 ms); with 64-ray batches and whole-wave refills they are alive
+    // 75-95 % and the second set of launches costs what the overlap gains (C3 2.74 vs 2.91 ms, C4 7.1 vs 6.9, C5 7.9 vs 8.0).
+    int splitMode = 0, splitParts = 2;
     float splitMinMs = 1.0f;
     int tune[4] = {24, 16, 48, 32};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
     bool tuneGiven = false;           // XRT_TUNE was set: keep it
