@@ -162,8 +162,8 @@ def time_frames(tracer, outs, steps, warmup, rank, world, width, height, gathere
         return time_frames_sharded(tracer, outs, steps, warmup, rank, world, width, height, gathered_out)
     """One GPU.  W warm-up frames, then K timed frames bracketed by synchronize on both sides; frame i is enqueued before
     frame i-1 is waited for."""
-    # stream None: libxrt decides (frames of >= 0.5 ms of GPU time alternate between two streams of its own and overlap on
-    # the GPU; shorter ones share one stream).  A given stream serialises the frames: used for per-launch timings.
+    # stream None: libxrt decides (single-chunk frames of >= 0.05 ms of GPU time alternate between two streams of its own and
+    # overlap on the GPU).  A given stream serialises the frames: used for per-launch timings.
     renders = [tracer.PrepareDevice(o.data_ptr(), stream=stream) for o in outs]   # camera / lights marshalled once
     open_frames, acc = [], [0.0, 0]
 
@@ -219,7 +219,7 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
     rays = st0["rays_closest"] + st0["rays_shadow"]
     res = dict(rays=rays, seconds=dt, ms_intersect=ms_int, launches=launches, stats=st0, build_s=build_s, width=W, height=H,
                tris=sum(m[0].ntri for m in spec.meshes), instances=len(spec.objects), overlapped=False)
-    if world == 1 and dt / max(steps, 1) * 1e3 >= 0.4:
+    if world == 1 and dt / max(steps, 1) * 1e3 >= 0.04:
         # The frames of the timed region overlapped pairwise on the GPU (two streams), so a launch's duration includes time
         # it shared with the other frame's launches.  A short serialised pass (one explicit stream) gives the duration of a
         # launch that has the GPU to itself -- the figure a roofline of the kernel is about.
@@ -344,8 +344,9 @@ def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_fra
            "traffic": traffic, "ms_per_launch": round(ms_per_launch, 5), "launches_per_frame": launches_per_frame, "fractions": fr,
            "pmc_build_id": build_id() if pmc else None,
            "note": "branchy scalar fp32 traversal, scene resident in the 256 MiB Infinity Cache: not HBM-bound. `frac` is the named bound's "
-                   "(valu: VALU instruction-issue slots used, of which fractions.valu.frac did useful lane work); durations = HIP events on "
-                   "the launches of the timed region; PMC = rocprofv3 passes of this build (profiles/), per launch"}
+                   "(valu: VALU instruction-issue slots used, of which fractions.valu.frac did useful lane work); durations = every launch of the timed region "
+                   "times itself on the device clock, first wave's start to last wave's end (events on the dispatch packets cost ~5 us a launch; "
+                   "rocprofv3's dispatch-level durations are ~4 us per launch longer); PMC = rocprofv3 passes of this build (profiles/), per launch"}
     if serial:
         if pmc and serial.get("ms_per_launch"):   # the same counters over the duration of a launch that has the GPU to itself
             ts = serial["ms_per_launch"] * 1e-3

@@ -165,7 +165,10 @@ typedef struct xrt_stats {
     uint64_t pixels;
     uint64_t algorithmic_bytes;   /* SURVEY §8d formula over the counters above */
     double   ms_total;            /* device time of the whole call */
-    double   ms_intersect;        /* summed durations of the traversal kernel launches (HIP events) */
+    double   ms_intersect;        /* summed durations of the traversal kernel launches: first wave's start to last wave's end on the
+                                     device clock for plain single-chunk frames (an event on a dispatch packet costs ~5 us, so those
+                                     launches carry none; ~4 us per launch less than a profiler's dispatch-level duration), HIP events
+                                     on the launches otherwise, or always with XRT_LAUNCH_EVENTS=1 */
     uint32_t intersect_launches;
     uint32_t pieces;              /* the frame was rendered in this many concurrent pieces (halves on two streams, GPUs); 1 otherwise */
 } xrt_stats;

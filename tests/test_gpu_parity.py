@@ -543,6 +543,32 @@ def test_multi_chunk_frames(xrt, monkeypatch):
         assert tracer2.last_stats["intersect_launches"] > st_want["intersect_launches"]
 
 
+def test_launch_timing_device_clock_vs_events(xrt, monkeypatch):
+    """Plain single-chunk frames time their traversal launches on the device clock (device_util.h stamp_begin / stamp_end, folded by
+    k_compose's epilogue) instead of carrying two events per launch; XRT_LAUNCH_EVENTS=1 is the old way.  Same frame, same launch
+    count; the two figures agree within the run-to-run spread of a frame (its queue scheduling is not deterministic) plus the
+    dispatch overhead of a launch, a few microseconds each, which only the events see."""
+    spec = xrt.configs.config("C3", 0.5)
+    scene, tracer = xrt.configs.build_product(spec)
+    monkeypatch.setenv("XRT_LAUNCH_EVENTS", "1")
+    scene_e, tracer_e = xrt.configs.build_product(spec)
+    monkeypatch.delenv("XRT_LAUNCH_EVENTS")
+    ms_c, ms_e = [], []
+    for i in range(10):
+        a = tracer.Render().copy()
+        st_c = dict(tracer.last_stats)
+        b = tracer_e.Render().copy()
+        st_e = dict(tracer_e.last_stats)
+        assert np.array_equal(a, b)
+        assert st_c["intersect_launches"] == st_e["intersect_launches"] == spec.max_reflections + 2
+        if i >= 2:
+            ms_c.append(st_c["ms_intersect"]); ms_e.append(st_e["ms_intersect"])
+            assert 0 < st_c["ms_intersect"] < st_c["ms_total"]
+    c, e = min(ms_c), min(ms_e)
+    n = spec.max_reflections + 2
+    assert e * 0.85 - 0.012 * n <= c <= e * 1.15, (ms_c, ms_e)
+
+
 def test_overlapping_frames_on_two_streams(xrt, monkeypatch):
     """Frames that run long enough get one stream per frame context and overlap on the GPU (XRT_OVERLAP_MS=0 forces it
     for a test-sized frame): two different cameras in flight at once give the frames of the blocking renders, over

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/xrt.h"
+#include "kernels.h"
 #include "traverse.h"
 
 namespace xrt {
@@ -21,6 +22,18 @@ __device__ __forceinline__ int wave_or(int v) {
     v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
     v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
     return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Launch timing without events.  An event on a kernel's dispatch packet costs that launch and its successor ~5 us each on this
+// stack (a 0.16 ms frame of ten kernels ran 0.135 ms without them), so the traversal kernels of a single-chunk frame time
+// themselves on the 100 MHz device clock: wave 0 stamps the launch's start and its number of waves, every wave its own end;
+// k_compose's frame epilogue folds a row into (start, latest end) for the host.  Row layout: kernels.h STAMP_*.
+__device__ __forceinline__ void stamp_begin(unsigned long long *row) {
+    if (row && blockIdx.x == 0 && threadIdx.x == 0) { row[0] = wall_clock64(); row[1] = gridDim.x * (blockDim.x >> 6); }
+}
+__device__ __forceinline__ void stamp_end(unsigned long long *row) {   // every wave, once, on its way out
+    const unsigned slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row && lane_id() == 0 && slot < (unsigned)STAMP_SLOTS) row[STAMP_HEADER + slot] = wall_clock64();
 }
 
 struct alignas(16) Hit16 { int i0, i1, i2, i3; };

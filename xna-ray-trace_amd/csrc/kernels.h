@@ -45,12 +45,16 @@ struct IntersectArgs {
     unsigned long long *debugTimes = nullptr;   // [3 * waves]: start / out-of-rays / exit clocks (100 MHz) per wave, development aid
     int coopMax = 32;   // at most this many lanes in a leaf: their triangle lists are dealt to the whole wave
     int batchMax = 64;  // largest guided batch a wave takes per queue atomic (multiple of 16)
+    unsigned long long *stamps = nullptr;   // this launch's row of device-clock stamps (device_util.h), or null
     // optional second segment traced by the same launch: rays2[0 .. (*nDev2) * nMul2) -> hits2 (no index list)
     const xrt_ray *rays2 = nullptr;
     xrt_hit *hits2 = nullptr;
     const int *nDev2 = nullptr;
     int nMul2 = 0, nCap2 = 0;
 };
+
+// Row of device-clock stamps of one traversal launch (device_util.h stamp_begin / stamp_end): [start, waves, end[waves]]
+constexpr int STAMP_HEADER = 2, STAMP_SLOTS = 8192, STAMP_STRIDE = STAMP_HEADER + STAMP_SLOTS;
 
 // k_packet (packet.hip): one wavefront traces 64 consecutive rays of a coherent population together -- a shared walk of the
 // mesh octree with per-lane box / triangle tests.  Same answers as k_intersect (same tests, same arg-min rule).
@@ -65,6 +69,7 @@ struct PacketArgs {
     int unmark = 0;               // rays may carry the long-ray mark of their producer (device_util.h)
     int staticDiv = 4;            // 1/staticDiv of the packets are dealt statically (0: none)
     int grabMax = 2;              // most packets a wave takes per queue atomic
+    unsigned long long *stamps = nullptr;   // this launch's row of device-clock stamps (device_util.h), or null
 };
 bool packet_supported(int mode, int meshDepth);
 int  packet_blocks_per_cu(int mode);
@@ -120,6 +125,10 @@ struct ResolveArgs {
     int *cntSrc = nullptr;
     int *hostCnt = nullptr;
     int cntWords = 0, zeroWords = 0;
+    // ... and the traversal launches' clock stamps are folded into (start, end) pairs for the host (device_util.h)
+    const unsigned long long *stampSrc = nullptr;
+    unsigned long long *hostStamps = nullptr;
+    int stampRows = 0;
 };
 void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P /* level stride */, int maxReflections, uint32_t *sampleColor, float *sampleF32,
                     const ResolveArgs &RA, hipStream_t st, hipEvent_t stopEvent = nullptr);

@@ -242,6 +242,7 @@ template <int T> __device__ __forceinline__ unsigned char *coop_memory() {
 template <int T, int M>
 __global__ __launch_bounds__(256, (M == MODE_SCENE) ? 4 : 5) void k_intersect(SceneView S, IntersectArgs A) {
     __shared__ unsigned stk[4 * T * 64];
+    stamp_begin(A.stamps);
     unsigned *const parkMem = park_memory<M>();
     unsigned char *const coopOwn = coop_memory<T>();
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? 4 : 5) void k_intersect(Sc
             L.state = ST_IDLE;
         }
     }
+    stamp_end(A.stamps);
 }
 
 int intersect_stack_capacity(int needed) {
@@ -578,63 +580,88 @@ __device__ __forceinline__ bool path_pixel(const RayGenParams &g, long long pix,
 
 // Rays that miss the scene octree's root box are answered here (OSM:318-320: no cuboid collected -> return
 // false) and the others are appended, wave by wave, to a compact index list for the traversal kernel.
+// One global atomic per list covers RG_ROUNDS x 1024 consecutive paths of a block (2025 atomics on one word were 20 of
+// the kernel's 21 us on a 1080p frame): the rays are written first, the list slots afterwards.
+constexpr int RG_ROUNDS = 4;
 __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneView S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P,
                                                          long long pathBase, HeavyArgs H) {
-    __shared__ int ldsCounts[17];
+    __shared__ int ldsLive[RG_ROUNDS * 16], ldsHeavy[RG_ROUNDS * 16];
     const f4 rlo = S.snodes[0], rhi = S.snodes[1];
-    const int stride = (int)(gridDim.x * blockDim.x);
-    const int rounds = (P + stride - 1) / stride;
-    for (int it = 0; it < rounds; it++) {
-        const int p = it * stride + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-        bool live = false, heavy = false, record = true;
-        if (p < P) {
-            long long gp = pathBase + p;
-            const int sshift = g.samples == 16 ? 4 : (g.samples == 4 ? 2 : 0);   // samples is 1, 4 or 16
-            int s = (int)(gp & (long long)(g.samples - 1));
-            int x = 0, y = 0;
-            const bool listed = g.quadLevel > 0;   // quadrant centres come from a list, every entry is valid
-            if (!listed && !path_pixel(g, gp >> sshift, x, y)) {
-                if (!index) store_ray(rays + p, mk(0, 0, 0), mk(0, 0, 0), DEAD_RAY, -1);
-            } else if (index && !listed && (x < g.cullX0 || x > g.cullX1 || y < g.cullY0 || y > g.cullY1)) {
-                record = g.cullSkipsRecord == 0;   // cannot reach the root box (RayGenParams): live stays false
-            } else {
-                float sx = (float)x, sy = (float)y;
-                if (g.quadLevel >= 0) {   // RT:218-276: four rays at centre -+ size/4, order UL, UR, LL, LR
-                    if (listed) { sx = g.quadCx[gp >> 2]; sy = g.quadCy[gp >> 2]; }
-                    const float quarter = g.quadSize * 0.25f;
-                    sx = (s & 1) ? sx + quarter : sx - quarter;
-                    sy = (s & 2) ? sy + quarter : sy - quarter;
-                } else if (g.samples == 16) {   // XRT_MS_FIXED16: corner q = s/4 at +-0.25, sub-sample s%4 at +-0.125 (RT:218-305)
-                    int q = s >> 2, r = s & 3;
-                    sx = (sx + ((q & 1) ? 0.25f : -0.25f)) + ((r & 1) ? 0.125f : -0.125f);
-                    sy = (sy + ((q & 2) ? 0.25f : -0.25f)) + ((r & 2) ? 0.125f : -0.125f);
+    const int span = RG_ROUNDS * APPEND_BLOCK;
+    const int groups = (P + span - 1) / span;
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    for (int grp = (int)blockIdx.x; grp < groups; grp += (int)gridDim.x) {
+        int liveAt[RG_ROUNDS], heavyAt[RG_ROUNDS];   // rank among the flagged lanes of the wave, -1: not flagged
+#pragma unroll
+        for (int r = 0; r < RG_ROUNDS; r++) {
+            const int p = grp * span + r * APPEND_BLOCK + (int)threadIdx.x;
+            bool live = false, heavy = false, record = true;
+            if (p < P) {
+                long long gp = pathBase + p;
+                const int sshift = g.samples == 16 ? 4 : (g.samples == 4 ? 2 : 0);   // samples is 1, 4 or 16
+                int s = (int)(gp & (long long)(g.samples - 1));
+                int x = 0, y = 0;
+                const bool listed = g.quadLevel > 0;   // quadrant centres come from a list, every entry is valid
+                if (!listed && !path_pixel(g, gp >> sshift, x, y)) {
+                    if (!index) store_ray(rays + p, mk(0, 0, 0), mk(0, 0, 0), DEAD_RAY, -1);
+                } else if (index && !listed && (x < g.cullX0 || x > g.cullX1 || y < g.cullY0 || y > g.cullY1)) {
+                    record = g.cullSkipsRecord == 0;   // cannot reach the root box (RayGenParams): live stays false
+                } else {
+                    float sx = (float)x, sy = (float)y;
+                    if (g.quadLevel >= 0) {   // RT:218-276: four rays at centre -+ size/4, order UL, UR, LL, LR
+                        if (listed) { sx = g.quadCx[gp >> 2]; sy = g.quadCy[gp >> 2]; }
+                        const float quarter = g.quadSize * 0.25f;
+                        sx = (s & 1) ? sx + quarter : sx - quarter;
+                        sy = (s & 2) ? sy + quarter : sy - quarter;
+                    } else if (g.samples == 16) {   // XRT_MS_FIXED16: corner q = s/4 at +-0.25, sub-sample s%4 at +-0.125 (RT:218-305)
+                        int q = s >> 2, rr = s & 3;
+                        sx = (sx + ((q & 1) ? 0.25f : -0.25f)) + ((rr & 1) ? 0.125f : -0.125f);
+                        sy = (sy + ((q & 2) ? 0.25f : -0.25f)) + ((rr & 2) ? 0.125f : -0.125f);
+                    }
+                    v3 nearP = unproject(g, sx, sy, 0.0f);   // RT:415
+                    v3 farP = unproject(g, sx, sy, 1.0f);    // RT:419
+                    v3 dir = normalize(sub(farP, nearP));    // RT:420-421
+                    if (index) {
+                        RayPre w = make_ray(nearP, dir);
+                        float key;
+                        live = slab(w, rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, key);   // OSM:460 on the root
+                    }
+                    heavy = live && H.list && long_ray(S, H, p, nearP, dir);
+                    if (live || !index) store_ray(rays + p, nearP, dir, -1, heavy ? (-1 ^ HEAVY_BIT) : -1);   // a culled ray is never read again
                 }
-                v3 nearP = unproject(g, sx, sy, 0.0f);   // RT:415
-                v3 farP = unproject(g, sx, sy, 1.0f);    // RT:419
-                v3 dir = normalize(sub(farP, nearP));    // RT:420-421
-                if (index) {
-                    RayPre w = make_ray(nearP, dir);
-                    float key;
-                    live = slab(w, rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, key);   // OSM:460 on the root
-                }
-                heavy = live && H.list && long_ray(S, H, p, nearP, dir);
-                if (live || !index) store_ray(rays + p, nearP, dir, -1, heavy ? (-1 ^ HEAVY_BIT) : -1);   // a culled ray is never read again
+                if (index && !live && record) lvlB0[p] = f4{0, 0, 0, i2f(FLAG_MISS)};   // generation 0 ends here (RT:729-733)
             }
-            if (index && !live && record) lvlB0[p] = f4{0, 0, 0, i2f(FLAG_MISS)};   // generation 0 ends here (RT:729-733)
+            const unsigned long long ml = __ballot(live), mh = __ballot(heavy);
+            liveAt[r] = live ? lanes_below(ml) : -1;
+            heavyAt[r] = heavy ? lanes_below(mh) : -1;
+            if (lane == 0) { ldsLive[r * 16 + wave] = (int)__popcll(ml); ldsHeavy[r * 16 + wave] = (int)__popcll(mh); }
         }
-        if (index) {   // block-uniform
-            const int slot = block_append(count, live, ldsCounts);
-            if (live) index[slot] = p;
-            if (H.list) {
-                const int hs = block_append(H.count, heavy, ldsCounts);
-                if (heavy) H.list[hs] = p;
-            }
+        if (!index) continue;   // grid-uniform: no lists
+        __syncthreads();
+        if (wave < 2 && (wave == 0 || H.list)) {   // wave 0 reserves the block's range of the live list, wave 1 of the long-ray list
+            int *cells = wave == 0 ? ldsLive : ldsHeavy;
+            const int c = cells[lane];   // entry r * 16 + w: ascending path order
+            const int incl = wave_scan_add(c);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            int base = 0;
+            if (lane == 0 && total) base = atomicAdd(wave == 0 ? count : H.count, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            cells[lane] = base + incl - c;
         }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RG_ROUNDS; r++) {
+            const int p = grp * span + r * APPEND_BLOCK + (int)threadIdx.x;
+            if (liveAt[r] >= 0) index[ldsLive[r * 16 + wave] + liveAt[r]] = p;
+            if (heavyAt[r] >= 0) H.list[ldsHeavy[r * 16 + wave] + heavyAt[r]] = p;
+        }
+        __syncthreads();   // the cells are reused by the next group
     }
 }
 void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase,
                    const HeavyArgs &H, hipStream_t st, hipEvent_t startEvent) {
-    int blocks = (P + APPEND_BLOCK - 1) / APPEND_BLOCK;
+    static_assert(RG_ROUNDS * 16 == 64, "one wave scans the block's cells");
+    int blocks = (P + RG_ROUNDS * APPEND_BLOCK - 1) / (RG_ROUNDS * APPEND_BLOCK);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipExtLaunchKernelGGL(k_raygen, dim3(blocks), dim3(APPEND_BLOCK), 0, st, startEvent, nullptr, 0, g, S, rays, lvlB0, index, count, P, pathBase, H);
@@ -874,6 +901,27 @@ __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB,
             RA.cntSrc[i] = 0;
         }
         __threadfence_system();
+    }
+    if (RA.stampRows > 0) {   // (start, latest wave end) of traversal launch j: one block per launch where the grid has them
+        __shared__ unsigned long long latest[4];
+        const bool spread = (int)gridDim.x > RA.stampRows;
+        const int j0 = spread ? (int)blockIdx.x - 1 : (blockIdx.x == 0 ? 0 : RA.stampRows), j1 = spread ? min(j0 + 1, RA.stampRows) : RA.stampRows;
+        for (int j = j0; j >= 0 && j < j1; j++) {
+            const unsigned long long *row = RA.stampSrc + (size_t)j * STAMP_STRIDE;
+            const int nb = min((int)row[1], STAMP_SLOTS);
+            unsigned long long m = 0;
+            for (int b = (int)threadIdx.x; b < nb; b += (int)blockDim.x) { const unsigned long long t = row[STAMP_HEADER + b]; m = t > m ? t : m; }
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
+            if (lane_id() == 0) latest[threadIdx.x >> 6] = m;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < 4; w++) m = latest[w] > m ? latest[w] : m;
+                RA.hostStamps[2 * j] = row[0];
+                RA.hostStamps[2 * j + 1] = m;
+                __threadfence_system();
+            }
+            __syncthreads();
+        }
     }
     const int sshift = RA.g.samples == 16 ? 4 : (RA.g.samples == 4 ? 2 : 0);
     for (int p = (int)(blockIdx.x * blockDim.x + threadIdx.x); p < count; p += (int)(gridDim.x * blockDim.x)) {

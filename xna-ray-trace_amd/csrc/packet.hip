@@ -42,6 +42,7 @@ template <int M>
 __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, const f4 *__restrict__ refN, const g3 *__restrict__ refG,
                                                 const f4 *__restrict__ leafNB, const MeshRec *__restrict__ meshes, SceneView S, PacketArgs A) {
     __shared__ unsigned frames[4 * PK_LEVELS * PK_FRAME_WORDS];
+    stamp_begin(A.stamps);
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     unsigned *const stk = &frames[wave * PK_LEVELS * PK_FRAME_WORDS];
     int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
             store_hit(A.hits + idx, lane_result(L, C, S, M));
         }
     }
+    stamp_end(A.stamps);
 }
 
 bool packet_supported(int mode, int meshDepth) { return (mode == MODE_SINGLE || mode == MODE_MESH) && meshDepth > 0 && meshDepth + 1 < PK_LEVELS; }

@@ -154,6 +154,7 @@ struct xrt_scene {
         DevBuf<xrt_ray> rays0, rays1, shadowRays;
         DevBuf<xrt_hit> hits, hits1, shadowHits;
         DevBuf<int> path0, path1, index0, heavyList, cnts;
+        DevBuf<unsigned long long> stamps;      // device-clock stamps of the traversal launches (device_util.h), STAMP_STRIDE per launch
         DevBuf<SlotRec> slot0, slot1;
         DevBuf<f4> lvlA, lvlB;
         DevBuf<uint32_t> sampleColor;
@@ -166,7 +167,7 @@ struct xrt_scene {
         hipStream_t lastStream = nullptr;       // the stream the context's last frame ran on
         void release() {
             rays0.release(); rays1.release(); shadowRays.release(); hits.release(); hits1.release(); shadowHits.release();
-            path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); slot0.release(); slot1.release();
+            path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); stamps.release(); slot0.release(); slot1.release();
             lvlA.release(); lvlB.release(); sampleColor.release(); sampleF32.release(); lights.release();
             if (stream) (void)hipStreamDestroy(stream);
             stream = nullptr;
@@ -195,6 +196,8 @@ struct xrt_scene {
         bool pending = false;
         bool fast = false;           // no copy / fill / event-record commands: k_compose hands the counters over, events ride on kernels
         int *pinnedDev = nullptr;    // device view of `pinned`
+        int stampRows = 0;           // traversal launches that timed themselves (device_util.h); (start, end) pairs at pinned + stampOff
+        size_t stampOff = 0;
         // deferred accounting
         int tallyChunks = 0, cntStride = 0, R = 0, nL = 0;
         bool collect = false;
@@ -207,13 +210,16 @@ struct xrt_scene {
     long long heapRayCap = HEAP_RAY_CAP;         // XRT_HEAP_RAY_CAP=<n> forces small ray buffers (tests of the overflow / retry path)
     long long maxChunkPaths = MAX_CHUNK_PATHS;   // XRT_CHUNK_PATHS=<n> (multiple of 8192) forces smaller chunks (tests of the multi-chunk path)
     float lastFrameMs = 0.0f;    // GPU time of the last finished frame
-    float overlapMinMs = 0.5f;   // frames at least this long run on per-context streams
+    float overlapMinMs = 0.05f;  // frames at least this long run on per-context streams
     // A launch of persistent waves leaves the machine half empty while its last rays finish; a blocking single frame (what the
     // C# host's RenderInternal asks for) has no other frame to fill the gaps, so it is rendered as two halves of its tiles on
     // two streams.  XRT_SPLIT=0 never (default), 1 frames nobody else overlaps, 2 also pipelined frames.  It paid while a launch's
     // waves were alive 55-60 % of its duration (C4 13.3 -> 10.9 ms); with 64-ray batches and whole-wave refills they are alive
     // 75-95 % and the second set of launches costs what the overlap gains (C3 2.74 vs 2.91 ms, C4 7.1 vs 6.9, C5 7.9 vs 8.0).
     int splitMode = 0, splitParts = 2;
+    bool launchEvents = false;   // XRT_LAUNCH_EVENTS=1: single-chunk frames time their traversal launches with events on the dispatch packets, too
+    bool noLaunchTiming = false; // XRT_LAUNCH_TIMING=0: single-chunk frames do not time their traversal launches (xrt_stats.ms_intersect = 0)
+    int wallClockKHz = 0;        // rate of the device clock the launches stamp (hipDeviceAttributeWallClockRate)
     float splitMinMs = 1.0f;
     int tune[4] = {24, 16, 48, 32};   // refill threshold (idle lanes), octree-child steps and leaf steps per outer iteration
     bool tuneGiven = false;           // XRT_TUNE was set: keep it
@@ -491,11 +497,16 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // on the stream: counters come back through k_compose's epilogue and the frame's events ride on raygen / compose.
     const bool fast = !adaptive && !heap && firstPaths <= chunkPaths && !opts->collect_stats;
     F.fast = fast;
+    // single-chunk frames: the traversal launches time themselves on the device clock instead of carrying events (device_util.h)
+    const bool useStamps = fast && !s->launchEvents && !s->noLaunchTiming && s->wallClockKHz > 0;
+    F.stampRows = 0;
+    if (useStamps && (rc = W.stamps.ensure((size_t)3 * (R + 2) * STAMP_STRIDE))) return rc;
     if (!st) {
-        // No stream given.  Single-chunk frames that keep the GPU busy for a while get a stream per context, so that two
-        // frames in flight overlap on the GPU; everything else stays on the scene's one stream (measured on MI355X /
-        // ROCm 7.2: enqueueing on a stream that has gone idle costs ~15 us a launch, on one that still has work ~4 us --
-        // alternating two streams with 60-200 us frames makes the host the bottleneck).
+        // No stream given.  Single-chunk frames get a stream per context, so that two frames in flight overlap on the GPU
+        // (C2: 0.139 -> 0.115 ms per frame, C3 2.7 -> 2.3); everything else, and frames of a few microseconds, stay on the
+        // scene's one stream.  (While every traversal launch carried two events, enqueueing on a stream that had gone idle cost
+        // ~15 us a launch and alternating streams made the host the bottleneck of 0.2 ms frames; the launches time themselves
+        // now, device_util.h.)
         if (fast && s->lastFrameMs >= s->overlapMinMs && !s->oneStream) {
             if (!W.stream) HIPCHECK(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
             st = W.stream;
@@ -614,9 +625,11 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 PA.queue = q + QW * k + 1 + word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv; PA.grabMax = s->packetGrabMax;
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
-                pairs.push_back({ev, ev + 1}); ev += 2;
                 int grid = s->numCUs * s->blocksPerCUPacket;
                 if (nHost >= 0) { const long long want = (nHost + 255) / 256; if (want < grid) grid = (int)(want < 1 ? 1 : want); }
+                if (useStamps && grid * 4 <= STAMP_SLOTS) { PA.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
+                else if (fast && s->noLaunchTiming) a0 = a1 = nullptr;
+                else { pairs.push_back({ev, ev + 1}); ev += 2; }
                 launch_packet(S, PA, grid, st, a0, a1);
                 return XRT_OK;
             };
@@ -629,9 +642,12 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 if (laneC && laneB) { A.rays2 = B.rays; A.hits2 = B.hits; A.nDev2 = B.nDev; A.nMul2 = B.nMul; A.nCap2 = B.nCap; }
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
-                pairs.push_back({ev, ev + 1}); ev += 2;
+                const int grid = persistent_grid(s, k == 0 ? Pc : -1);
+                if (useStamps && grid * 4 <= STAMP_SLOTS) { A.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
+                else if (fast && s->noLaunchTiming) a0 = a1 = nullptr;
+                else { pairs.push_back({ev, ev + 1}); ev += 2; }
                 if (s->waveTimes.p && k < 16) A.debugTimes = s->waveTimes.p + (size_t)k * 3 * 8192;
-                launch_intersect(S, A, s->stackNeeded, persistent_grid(s, k == 0 ? Pc : -1), st, a0, a1);
+                launch_intersect(S, A, s->stackNeeded, grid, st, a0, a1);
             }
             if ((hasClosest || hasShadow) && opts->collect_stats) {   // generation 0: the live list; culled rays are added in frame_finish
                 if (hasClosest) launch_count(S, C, s->counters.p, st);
@@ -660,7 +676,10 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         else {
             ResolveArgs RA;
             RA.fused = fuseResolve ? 1 : 0; RA.g = gp; RA.pixelBase = pathBase; RA.out = d_out; RA.outF32 = d_outF32;
-            if (fast) { RA.cntSrc = cnt; RA.hostCnt = F.pinnedDev; RA.cntWords = cntStride; RA.zeroWords = cntStride + qStride; }
+            if (fast) {
+                RA.cntSrc = cnt; RA.hostCnt = F.pinnedDev; RA.cntWords = cntStride; RA.zeroWords = cntStride + qStride;
+                RA.stampSrc = W.stamps.p; RA.hostStamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(F.pinnedDev) + F.stampOff); RA.stampRows = F.stampRows;
+            }
             launch_compose(W.lvlA.p, W.lvlB.p, Pc, P, R, W.sampleColor.p, (wantF32 && !fuseResolve) ? W.sampleF32.p : nullptr, RA, st,
                            (fast && fuseResolve) ? e1 : nullptr);
         }
@@ -732,7 +751,10 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         const int *cntsBefore = W.cnts.p;
         if ((rc2 = W.cnts.ensure(cntWords + qWords))) return rc2;
         unsigned *queuesBase = reinterpret_cast<unsigned *>(W.cnts.p + cntWords);
-        if (fast && (rc2 = ensure_pinned(cntWords * sizeof(int)))) return rc2;
+        if (fast) {   // counters, then the (start, end) clock pairs of up to 3 traversal launches per step
+            F.stampOff = (cntWords * sizeof(int) + 63) & ~(size_t)63;
+            if ((rc2 = ensure_pinned(F.stampOff + (size_t)3 * (R + 2) * 2 * sizeof(unsigned long long)))) return rc2;
+        }
         if (!fast || !W.cntsClean || W.cnts.p != cntsBefore) HIPCHECK(hipMemsetAsync(W.cnts.p, 0, W.cnts.cap * sizeof(int), st));
         W.cntsClean = false;
         for (int c = 0; c < nChunks; c++) {
@@ -908,8 +930,13 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
             HIPCHECK(hipEventElapsedTime(&t, F.events[pr.first], F.events[pr.second]));
             mi += t;
         }
+        if (F.fast && F.stampRows > 0) {
+            const unsigned long long *sp = reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(F.pinned) + F.stampOff);
+            for (int j = 0; j < F.stampRows; j++)
+                if (sp[2 * j + 1] > sp[2 * j]) mi += (double)(sp[2 * j + 1] - sp[2 * j]) / (double)s->wallClockKHz;
+        }
         stats->ms_intersect = mi;
-        stats->intersect_launches = (uint32_t)F.pairs.size();
+        stats->intersect_launches = (uint32_t)F.pairs.size() + (uint32_t)(F.fast ? F.stampRows : 0);
         stats->pieces = 1;
     }
     return XRT_OK;
@@ -933,6 +960,8 @@ int ensure_replicas(xrt_scene *s, int n) {
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) r->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (hipDeviceGetAttribute(&r->wallClockKHz, hipDeviceAttributeWallClockRate, r->device) != hipSuccess) { r->wallClockKHz = 0; (void)hipGetLastError(); }
+        r->launchEvents = s->launchEvents; r->noLaunchTiming = s->noLaunchTiming;
         HIPCHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
         int rc = scene_upload(r.get());
         if (rc != XRT_OK) return rc;
@@ -1294,6 +1323,8 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_PK_STATIC")) { const int v = atoi(e); if (v >= 0 && v <= 64) s->packetStaticDiv = v; }
     if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 15) s->packetMask = v; }
     if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
+    if (const char *e = getenv("XRT_LAUNCH_EVENTS")) s->launchEvents = atoi(e) != 0;
+    if (const char *e = getenv("XRT_LAUNCH_TIMING")) s->noLaunchTiming = atoi(e) == 0;
     if (const char *e = getenv("XRT_SPLIT_MS")) s->splitMinMs = (float)atof(e);
     if (const char *e = getenv("XRT_SPLIT_PARTS")) { const int v = atoi(e); if (v >= 2 && v <= 4) s->splitParts = v; }
     if (const char *e = getenv("XRT_CULL_SAFETY")) { const double v = atof(e); if (v >= 0.0 && v <= 1e6) s->hs.cullSafety = v; }   // development: factor S of the object pre-cull margin (below 2 the bound is no longer proven)
@@ -1311,6 +1342,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (device >= 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (hipDeviceGetAttribute(&s->wallClockKHz, hipDeviceAttributeWallClockRate, device) != hipSuccess) { s->wallClockKHz = 0; (void)hipGetLastError(); }
         hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete s; return fail(XRT_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     }
