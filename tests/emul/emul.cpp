@@ -32,6 +32,8 @@ int emu_add_object(emu_scene *s, const int *ids, int n, const float *w, const fl
 int emu_build(emu_scene *s, int mt, int st) { return s->hs.build(mt, st, s->err) ? 0 : -1; }
 // factor S of the object pre-cull margin (scene_host.cpp); set before emu_build
 void emu_set_cull_safety(emu_scene *s, double f) { s->hs.cullSafety = f; }
+// factor on the tight-leaf-box margin (xrt_core.h leaf_certainly_missed): 0 = off, 1 = the proven bound; set before emu_build
+void emu_set_leaf_cull(emu_scene *s, double f) { s->hs.leafCullSafety = f; }
 int emu_get_tree(emu_scene *s, int mesh, xrt_node_info *nodes, int64_t *nn, int *refs, int64_t *nr) {
     const FlatTree &t = mesh < 0 ? s->hs.sceneTree : s->hs.meshTrees[mesh];
     if (nodes) std::memcpy(nodes, t.info.data(), t.info.size() * sizeof(xrt_node_info));

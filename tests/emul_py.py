@@ -42,6 +42,7 @@ def lib():
         l.emu_add_object.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int, _F, _F, _F, _F]
         l.emu_build.argtypes = [C.c_void_p, C.c_int, C.c_int]
         l.emu_set_cull_safety.argtypes = [C.c_void_p, C.c_double]
+        l.emu_set_leaf_cull.argtypes = [C.c_void_p, C.c_double]
         l.emu_get_tree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64)]
         l.emu_tree_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         l.emu_intersect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
@@ -55,12 +56,14 @@ def _fp(a):
 
 
 class EmulScene:
-    def __init__(self, spec, cull_safety=None):
+    def __init__(self, spec, cull_safety=None, leaf_cull=None):
         from oracle import oracle_py as orc
         L = lib()
         self.h = C.c_void_p(L.emu_create())
         if cull_safety is not None:
             L.emu_set_cull_safety(self.h, float(cull_safety))
+        if leaf_cull is not None:
+            L.emu_set_leaf_cull(self.h, float(leaf_cull))
         for data, m in spec.meshes:
             a, keep = orc.material_abi(m)
             sn = np.ascontiguousarray(data.surface_normal, dtype=np.float32)

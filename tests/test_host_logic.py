@@ -279,6 +279,32 @@ def test_object_precull_adversarial_transforms(xrt, orc, emul):
     assert hits_equal(ho, e.intersect(rays)) == {}
 
 
+@pytest.mark.parametrize("kind", ["heightfield", "soup", "crate"])
+def test_tight_leaf_boxes_adversarial(xrt, orc, emul, kind):
+    """A leaf is skipped when the ray misses the box of its triangles' vertices grown by rho(ray, leaf) (xrt_core.h
+    leaf_certainly_missed): rays placed on that decision boundary -- grazing the vertex boxes, lying in
+    triangle planes, through vertices and edges, from up to 1e5 leaf sizes away -- answer exactly like the oracle, which tests
+    every reference of every leaf it enters.  With the margin cut to 1e-4 of the proven bound the same rays DO lose hits."""
+    from util import tight_box_adversarial_rays
+    if kind == "heightfield":
+        spec = xrt.configs.heightfield_scene(64, 36, m=48)
+    elif kind == "crate":
+        spec = xrt.configs.config("C1")
+        spec.meshes[0] = (xrt.fixtures.crate(7), spec.meshes[0][1])
+    else:
+        spec = soup_spec(xrt, 900, 5, 12, 0.3)
+    o, e = orc.OracleScene(spec), emul.EmulScene(spec)
+    off, weak = emul.EmulScene(spec, leaf_cull=0.0), emul.EmulScene(spec, leaf_cull=1e-4)
+    nodes, refs = o.tree(0)
+    rays = tight_box_adversarial_rays(xrt, spec.meshes[0][0], nodes, refs, 60, 150, 23)
+    ho = o.mesh_intersect(0, rays)
+    assert 0.05 < (ho["hit"] != 0).mean() < 0.95
+    assert hits_equal(ho, e.intersect(rays, mode=1, mesh=0)) == {}
+    assert hits_equal(ho, off.intersect(rays, mode=1, mesh=0)) == {}
+    if kind == "heightfield":   # (the others' boxes are too loose for 25,000 rays to find the gap)
+        assert len(hits_equal(ho, weak.intersect(rays, mode=1, mesh=0))) > 0
+
+
 REF_CONTENT = "/root/reference/RayTraceProject/RayTraceProjectContent"
 
 

@@ -118,4 +118,5 @@ def test_packet_kernel_resources(isa):
     blocks = re.findall(r"Function Name: (\S*k_packet\S*).*?TotalSGPRs: (\d+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", usage, flags=re.S)
     assert len(blocks) == 2
     for name, sgprs, vgprs, scratch in blocks:
-        assert int(sgprs) <= budget and int(vgprs) <= 72 and int(scratch) == 0, (name, sgprs, vgprs, scratch)
+        # 112 SGPRs allow six waves per SIMD, and so do up to 80 VGPRs
+        assert int(sgprs) <= budget and int(vgprs) <= 80 and int(scratch) == 0, (name, sgprs, vgprs, scratch)

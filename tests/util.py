@@ -136,3 +136,68 @@ def far_origin_rays(xrt, spec, radius, per_corner, seed):
             origins.append(org)
             dirs.append(d / np.linalg.norm(d, axis=1, keepdims=True))
     return xrt.rays_array(np.concatenate(origins).astype(np.float32), np.concatenate(dirs).astype(np.float32))
+
+
+def leaf_tight_boxes(nodes, refs, mesh):
+    """(lo, hi, rows) of the vertex boxes of the non-empty leaves of a mesh tree (xrt_scene_get_tree layout)."""
+    V = mesh.v.reshape(-1, 3, 3).astype(np.float64)
+    rows = np.where((nodes["is_leaf"] != 0) & (nodes["count"] > 0))[0]
+    lo, hi = np.zeros((len(rows), 3)), np.zeros((len(rows), 3))
+    for i, r in enumerate(rows):
+        tr = refs[nodes["first_ref"][r]: nodes["first_ref"][r] + nodes["count"][r]]
+        lo[i] = V[tr].reshape(-1, 3).min(axis=0)
+        hi[i] = V[tr].reshape(-1, 3).max(axis=0)
+    return lo, hi, rows
+
+
+def tight_box_adversarial_rays(xrt, mesh, nodes, refs, n_leaves, per_leaf, seed):
+    """Object-space rays built to sit on the decision boundary of the tight-leaf-box skip (xrt_core.h leaf_certainly_missed):
+    (a) through points within 1e-7 .. 1e-1 of the corners, edges and faces of leaves' vertex boxes, from 1 .. 1e5 box sizes away;
+    (b) in the plane of a triangle of the leaf (normal offset and tilt 1e-8 .. 1e-2), towards it from outside;
+    (c) through the triangles' vertices and edge midpoints, jittered by 1e-7 .. 1e-3."""
+    rng = np.random.default_rng(seed)
+    lo, hi, rows = leaf_tight_boxes(nodes, refs, mesh)
+    V = mesh.v.reshape(-1, 3, 3).astype(np.float64)
+    pick = rng.choice(len(rows), size=min(n_leaves, len(rows)), replace=False)
+    O, D = [], []
+
+    def add(org, tgt):
+        d = tgt - org
+        n = np.linalg.norm(d, axis=-1, keepdims=True)
+        ok = n[..., 0] > 0
+        O.append(org[ok]); D.append((d / np.where(n == 0, 1, n))[ok])
+    for i in pick:
+        size = np.maximum(hi[i] - lo[i], 1e-3)
+        diag = np.linalg.norm(size)
+        # (a) boundary points of the vertex box: each coordinate at lo, hi or anywhere inside
+        sel = rng.integers(0, 3, size=(per_leaf, 3))
+        inside = lo[i] + rng.uniform(size=(per_leaf, 3)) * size
+        pts = np.where(sel == 0, lo[i], np.where(sel == 1, hi[i], inside))
+        pts = pts + rng.normal(size=pts.shape) * (10.0 ** rng.uniform(-7, -1, size=(per_leaf, 1))) * diag
+        dirs = rng.normal(size=pts.shape)
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        dist = diag * 10.0 ** rng.uniform(0, 5, size=(per_leaf, 1))
+        add(pts - dirs * dist, pts)
+        tr = refs[nodes["first_ref"][rows[i]]: nodes["first_ref"][rows[i]] + nodes["count"][rows[i]]]
+        t = V[rng.choice(tr, size=per_leaf)]
+        e1, e2 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]
+        nrm = np.cross(e1, e2)
+        ln = np.linalg.norm(nrm, axis=1, keepdims=True)
+        nrm = nrm / np.where(ln == 0, 1, ln)
+        # (b) in-plane rays: from a point of the plane outside the triangle towards a point inside it
+        w = rng.dirichlet((1, 1, 1), size=per_leaf)
+        inside = (t * w[:, :, None]).sum(axis=1)
+        ang = rng.uniform(0, 2 * np.pi, size=(per_leaf, 1))
+        ex = e1 / np.maximum(np.linalg.norm(e1, axis=1, keepdims=True), 1e-30)
+        ey = np.cross(nrm, ex)
+        away = (np.cos(ang) * ex + np.sin(ang) * ey) * diag * 10.0 ** rng.uniform(0, 3, size=(per_leaf, 1))
+        eps = (10.0 ** rng.uniform(-8, -2, size=(per_leaf, 1))) * rng.choice([-1.0, 1.0], size=(per_leaf, 1)) * diag
+        add(inside + away + eps * nrm, inside - eps * nrm * rng.uniform(-1, 1, size=(per_leaf, 1)))
+        # (c) vertices and edge midpoints
+        k = rng.integers(0, 6, size=per_leaf)
+        feat = np.where((k < 3)[:, None], t[np.arange(per_leaf), k % 3], 0.5 * (t[np.arange(per_leaf), k % 3] + t[np.arange(per_leaf), (k + 1) % 3]))
+        feat = feat + rng.normal(size=feat.shape) * (10.0 ** rng.uniform(-7, -3, size=(per_leaf, 1))) * diag
+        dirs = rng.normal(size=feat.shape)
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        add(feat - dirs * diag * 10.0 ** rng.uniform(0, 4, size=(per_leaf, 1)), feat)
+    return xrt.rays_array(np.concatenate(O).astype(np.float32), np.concatenate(D).astype(np.float32))

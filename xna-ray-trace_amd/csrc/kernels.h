@@ -69,6 +69,7 @@ struct PacketArgs {
     int unmark = 0;               // rays may carry the long-ray mark of their producer (device_util.h)
     int staticDiv = 4;            // 1/staticDiv of the packets are dealt statically (0: none)
     int grabMax = 2;              // most packets a wave takes per queue atomic
+    int cullMin = 4;              // leaves of at least this many references are tested against their tight box first (the test costs about two triangles)
     unsigned long long *stamps = nullptr;   // this launch's row of device-clock stamps (device_util.h), or null
 };
 bool packet_supported(int mode, int meshDepth);
@@ -111,8 +112,15 @@ void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long
 void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase,
                    const HeavyArgs &H, hipStream_t st, hipEvent_t startEvent = nullptr);
 void launch_shade(const SceneView &S, const ShadeView &V, const ShadeArgs &X, hipStream_t st);
+// Frame epilogue of the compose kernels: the clock stamps of traversal launches row0 .. row1-1 are folded into (start, latest
+// end) pairs in host-visible memory (device_util.h)
+struct StampFold {
+    const unsigned long long *src = nullptr;
+    unsigned long long *host = nullptr;
+    int row0 = 0, row1 = 0;
+};
 void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections, uint32_t *sampleColor,
-                         float *sampleF32, hipStream_t st);
+                         float *sampleF32, const StampFold &stamps, hipStream_t st);
 // compose can write the framebuffer itself when there is one sample per pixel
 struct ResolveArgs {
     int fused;
@@ -125,10 +133,7 @@ struct ResolveArgs {
     int *cntSrc = nullptr;
     int *hostCnt = nullptr;
     int cntWords = 0, zeroWords = 0;
-    // ... and the traversal launches' clock stamps are folded into (start, end) pairs for the host (device_util.h)
-    const unsigned long long *stampSrc = nullptr;
-    unsigned long long *hostStamps = nullptr;
-    int stampRows = 0;
+    StampFold stamps;
 };
 void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P /* level stride */, int maxReflections, uint32_t *sampleColor, float *sampleF32,
                     const ResolveArgs &RA, hipStream_t st, hipEvent_t stopEvent = nullptr);

@@ -891,6 +891,33 @@ void launch_shade(const SceneView &S, const ShadeView &V, const ShadeArgs &X, hi
     hipLaunchKernelGGL(k_shade, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, X);
 }
 
+// Frame epilogue: (start, latest wave end) of traversal launches row0 .. row1-1 go to host-visible memory, one block per launch
+// where the grid has them (block 0 is busy with the counters).  All threads of every block call it.
+__device__ __forceinline__ void fold_stamps(const StampFold &F) {
+    const int rows = F.row1 - F.row0;
+    if (rows <= 0) return;
+    __shared__ unsigned long long latest[4];
+    const bool spread = (int)gridDim.x > rows;
+    const int j0 = spread ? (int)blockIdx.x - 1 : (blockIdx.x == 0 ? 0 : rows), j1 = spread ? min(j0 + 1, rows) : rows;
+    for (int jj = j0; jj >= 0 && jj < j1; jj++) {
+        const int j = F.row0 + jj;
+        const unsigned long long *row = F.src + (size_t)j * STAMP_STRIDE;
+        const int nb = min((int)row[1], STAMP_SLOTS);
+        unsigned long long m = 0;
+        for (int b = (int)threadIdx.x; b < nb; b += (int)blockDim.x) { const unsigned long long t = row[STAMP_HEADER + b]; m = t > m ? t : m; }
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
+        if (lane_id() == 0) latest[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < (int)(blockDim.x >> 6) && w < 4; w++) m = latest[w] > m ? latest[w] : m;
+            F.host[2 * j] = row[0];
+            F.host[2 * j + 1] = m;
+            __threadfence_system();
+        }
+        __syncthreads();
+    }
+}
+
 // The return path of the CastRay recursion: deepest generation first, one RGBA8 quantisation per level.
 __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32,
                                                  ResolveArgs RA) {
@@ -902,27 +929,7 @@ __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB,
         }
         __threadfence_system();
     }
-    if (RA.stampRows > 0) {   // (start, latest wave end) of traversal launch j: one block per launch where the grid has them
-        __shared__ unsigned long long latest[4];
-        const bool spread = (int)gridDim.x > RA.stampRows;
-        const int j0 = spread ? (int)blockIdx.x - 1 : (blockIdx.x == 0 ? 0 : RA.stampRows), j1 = spread ? min(j0 + 1, RA.stampRows) : RA.stampRows;
-        for (int j = j0; j >= 0 && j < j1; j++) {
-            const unsigned long long *row = RA.stampSrc + (size_t)j * STAMP_STRIDE;
-            const int nb = min((int)row[1], STAMP_SLOTS);
-            unsigned long long m = 0;
-            for (int b = (int)threadIdx.x; b < nb; b += (int)blockDim.x) { const unsigned long long t = row[STAMP_HEADER + b]; m = t > m ? t : m; }
-            for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
-            if (lane_id() == 0) latest[threadIdx.x >> 6] = m;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                for (int w = 1; w < 4; w++) m = latest[w] > m ? latest[w] : m;
-                RA.hostStamps[2 * j] = row[0];
-                RA.hostStamps[2 * j + 1] = m;
-                __threadfence_system();
-            }
-            __syncthreads();
-        }
-    }
+    fold_stamps(RA.stamps);
     const int sshift = RA.g.samples == 16 ? 4 : (RA.g.samples == 4 ? 2 : 0);
     for (int p = (int)(blockIdx.x * blockDim.x + threadIdx.x); p < count; p += (int)(gridDim.x * blockDim.x)) {
         int kd = 0;
@@ -970,8 +977,9 @@ __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB,
 // The same return path over the binary ray tree of a scene with Transparent materials (RT:586-702): node i has
 // its reflection at 2i+1 and its refraction at 2i+2; evaluated depth first like the recursion itself.
 __global__ __launch_bounds__(256) void k_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections,
-                                                      uint32_t *sampleColor, float *sampleF32) {
+                                                      uint32_t *sampleColor, float *sampleF32, StampFold stamps) {
     constexpr int MAXD = 14;
+    fold_stamps(stamps);
     for (int p = (int)(blockIdx.x * blockDim.x + threadIdx.x); p < count; p += (int)(gridDim.x * blockDim.x)) {
         int stNode[MAXD], stPhase[MAXD];
         uint32_t stRefl[MAXD];
@@ -1021,10 +1029,11 @@ __global__ __launch_bounds__(256) void k_compose_tree(const f4 *lvlA, const f4 *
     }
 }
 void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections, uint32_t *sampleColor,
-                         float *sampleF32, hipStream_t st) {
+                         float *sampleF32, const StampFold &stamps, hipStream_t st) {
     int blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_compose_tree, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, lvlA, lvlB, lvlAlpha, count, P, maxReflections, sampleColor, sampleF32);
+    hipLaunchKernelGGL(k_compose_tree, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, lvlA, lvlB, lvlAlpha, count, P, maxReflections, sampleColor, sampleF32,
+                       stamps);
 }
 void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32,
                     const ResolveArgs &RA, hipStream_t st, hipEvent_t stopEvent) {

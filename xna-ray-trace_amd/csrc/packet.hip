@@ -40,7 +40,8 @@ __device__ __forceinline__ float rflf(float v) { return i2f(__builtin_amdgcn_rea
 
 template <int M>
 __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, const f4 *__restrict__ refN, const g3 *__restrict__ refG,
-                                                const f4 *__restrict__ leafNB, const MeshRec *__restrict__ meshes, SceneView S, PacketArgs A) {
+                                                const f4 *__restrict__ leafNB, const f4 *__restrict__ leafTB, const MeshRec *__restrict__ meshes, SceneView S,
+                                                PacketArgs A) {
     __shared__ unsigned frames[4 * PK_LEVELS * PK_FRAME_WORDS];
     stamp_begin(A.stamps);
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
             if (A.unmark && heavy_marked(it)) it ^= HEAVY_BIT;
             if (im != DEAD_RAY) lane_begin(L, C, S, o, d, im, it, idx, M, A.meshId, false);
         }
+        const RayCull RC = make_ray_cull(L.r.o, L.r.d);   // tight leaf boxes (xrt_core.h): what depends on the ray alone
         const int mesh = (M == MODE_MESH) ? A.meshId : 0;
         const MeshRec &mr = meshes[mesh];
         const bool fastL = L.r.par == 0 && L.weird == 0;
@@ -163,10 +165,15 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
             const int node = U.blk * 8 + c;
             if (!((d2 >> c) & 1)) {   // ---- leaf (non-empty): MO:288-304 for the lanes the bucket rule lets in ----
                 const f4 nlo = leafNB[2 * (size_t)node], nhi = leafNB[2 * (size_t)node + 1];
-                const bool go = inC && !(L.mfound && key > L.mKey) && !all_back_facing(nlo, nhi, L.r.d);
+                bool go = inC && !(L.mfound && key > L.mKey) && !all_back_facing(nlo, nhi, L.r.d);
                 if (!__any(go)) continue;
                 const int r0 = d1 + child_ref_offset(offLo, offHi, c);
                 const int r1 = d1 + ((c == 7) ? d3 : child_ref_offset(offLo, offHi, c + 1));
+                if (r1 - r0 >= A.cullMin) {   // lanes whose ray cannot reach any triangle of the leaf (xrt_core.h leaf_certainly_missed) stay out of it
+                    const f4 *tb = leafTB + 4 * (size_t)node;
+                    go = go && !leaf_certainly_missed(L.r, RC, tb[0], tb[1], tb[2], tb[3]);
+                    if (!__any(go)) continue;
+                }
                 if (go) {   // the lanes of this leaf, selected once for all its triangles
                     L.leafKey = key; L.leafNode = node;
                     // The triangle is the same for every lane: normals and geometry come through the scalar cache.  Two register
@@ -248,8 +255,8 @@ int packet_blocks_per_cu(int mode) {
 
 void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     dim3 g((unsigned)gridBlocks), b(256);
-    if (A.mode == MODE_MESH) hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.blocks, S.refN, S.refG, S.leafNB, S.meshes, S, A);
-    else hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refN, S.refG, S.leafNB, S.meshes, S, A);
+    if (A.mode == MODE_MESH) hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.blocks, S.refN, S.refG, S.leafNB, S.leafTB, S.meshes, S, A);
+    else hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refN, S.refG, S.leafNB, S.leafTB, S.meshes, S, A);
 }
 
 }  // namespace xrt

@@ -8,7 +8,7 @@
 namespace xrt {
 
 size_t SceneArrays::bytes() const {
-    return (blocks.size() + refN.size() + snodes.size() + shade.size() + leafNB.size()) * sizeof(f4) + refG.size() * sizeof(g3) +
+    return (blocks.size() + refN.size() + snodes.size() + shade.size() + leafNB.size() + leafTB.size()) * sizeof(f4) + refG.size() * sizeof(g3) +
            (childDfs.size() + srefs.size() + objMesh.size()) * sizeof(int) + meshes.size() * sizeof(MeshRec) +
            objects.size() * sizeof(ObjRec) + materials.size() * sizeof(MaterialRec) + texels.size() * sizeof(uint32_t);
 }
@@ -192,6 +192,41 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
                     }
                 }
                 A.leafNB.push_back(mn); A.leafNB.push_back(mx);
+                // ... and the tight box of the leaf (xrt_core.h leaf_certainly_missed): vertex box, box of the unit geometric normals,
+                // K = C u0 max |E1||E2|/|E1 x E2| and the longest edge, all rounded outwards
+                f4 rec[4] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
+                if (!((masks >> c) & 1)) {
+                    const int b0 = lref + off(c), b1 = lref + (c == 7 ? total : off(c + 1));
+                    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, nlo[3] = {2, 2, 2}, nhi[3] = {-2, -2, -2};
+                    double aMax = 0, eMax = 0;
+                    bool ok = b1 > b0;
+                    for (int r = b0; r < b1 && ok; r++) {
+                        const float *p = &m.v[(size_t)t.leafRefs[r] * 9];
+                        const float e1f[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]}, e2f[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};   // RE:54-55, as stored in refG
+                        const double e1[3] = {e1f[0], e1f[1], e1f[2]}, e2[3] = {e2f[0], e2f[1], e2f[2]};
+                        const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                        const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+                        const double ln = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                        // magnitudes the error analysis assumes (no overflow, no subnormal products)
+                        if (!(l1 >= 1e-9 && l2 >= 1e-9 && l1 <= 1e12 && l2 <= 1e12 && ln > 0 && l1 * l2 / ln <= 1e6)) { ok = false; break; }
+                        aMax = std::fmax(aMax, l1 * l2 / ln);
+                        eMax = std::fmax(eMax, std::fmax(l1, l2));
+                        for (int k = 0; k < 3; k++) {
+                            const double v[3] = {(double)p[k], (double)p[k] + e1[k], (double)p[k] + e2[k]};
+                            for (double x : v) { if (!(std::fabs(x) <= 1e12)) ok = false; lo[k] = std::fmin(lo[k], x); hi[k] = std::fmax(hi[k], x); }
+                            nlo[k] = std::fmin(nlo[k], n[k] / ln); nhi[k] = std::fmax(nhi[k], n[k] / ln);
+                        }
+                    }
+                    if (ok && leafCullSafety > 0.0) {
+                        auto down = [](double x) { return std::nextafterf((float)x, -INFINITY); };
+                        auto up = [](double x) { return std::nextafterf((float)x, INFINITY); };
+                        rec[0] = f4{down(lo[0]), down(lo[1]), down(lo[2]), up((double)LEAF_CULL_C * std::ldexp(1.0, -24) * aMax * leafCullSafety)};
+                        rec[1] = f4{up(hi[0]), up(hi[1]), up(hi[2]), up(eMax)};
+                        rec[2] = f4{down(nlo[0] - 1e-6), down(nlo[1] - 1e-6), down(nlo[2] - 1e-6), 1.0f};
+                        rec[3] = f4{up(nhi[0] + 1e-6), up(nhi[1] + 1e-6), up(nhi[2] + 1e-6), 0.0f};
+                    }
+                }
+                for (const f4 &q : rec) A.leafTB.push_back(q);
             }
         }
         for (int tri : t.leafRefs) {   // leaf references in leaf order: normal stream + geometry stream
@@ -261,6 +296,7 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
     if (A.materials.empty()) { MaterialRec z; std::memset(&z, 0, sizeof(z)); A.materials.push_back(z); }
     if (A.blocks.empty()) A.blocks.assign(2, f4{0, 0, 0, 0});
     if (A.leafNB.empty()) A.leafNB.assign(16, f4{0, 0, 0, 0});
+    if (A.leafTB.empty()) A.leafTB.assign(32, f4{0, 0, 0, 0});
     if (A.childDfs.empty()) A.childDfs.assign(8, -1);
     built = true;
     return true;
@@ -348,7 +384,7 @@ bool HostScene::load(const char *path, std::string &err) {
 SceneView HostScene::host_view() const {
     SceneView S;
     const SceneArrays &A = arrays;
-    S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data(); S.leafNB = A.leafNB.data();
+    S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data(); S.leafNB = A.leafNB.data(); S.leafTB = A.leafTB.data();
     S.refN = A.refN.data(); S.refG = A.refG.data(); S.meshes = A.meshes.data();
     S.snodes = A.snodes.data(); S.srefs = A.srefs.data(); S.objects = A.objects.data(); S.objMesh = A.objMesh.data();
     S.nMeshes = (int)meshes.size(); S.nObjects = (int)objects.size();

@@ -16,6 +16,7 @@ constexpr int SHADE_F4 = 6;   // f4 per triangle shading record:
 
 struct SceneArrays {
     std::vector<f4> blocks, refN, snodes, shade, leafNB;   // leafNB: 2 per node: component-wise min / max of the leaf's surface normals
+    std::vector<f4> leafTB;                                // 4 per node: the leaf's tight box (xrt_core.h leaf_certainly_missed)
     std::vector<g3> refG;
     std::vector<int> childDfs, srefs, objMesh;
     std::vector<MeshRec> meshes;
@@ -35,6 +36,7 @@ struct HostScene {
     FlatTree sceneTree;
     SceneArrays arrays;
     bool built = false;
+    double leafCullSafety = 1.0;   // factor on the tight-leaf-box margin (xrt_core.h LEAF_CULL_C): 0 switches the skip off, below 1 the bound is no longer proven (tests)
     double cullSafety = 2.0;   // factor S of the object pre-cull margin (scene_host.cpp); tests lower it to see the bound bite
 
     int add_mesh(const float *v, const float *n, const float *uv, const float *sn, const float *color, int ntri,

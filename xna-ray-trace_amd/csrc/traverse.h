@@ -21,6 +21,7 @@ struct SceneView {
     const f4 *blocks;       // mesh octrees: 2 per block descriptor (implicit boxes, xrt_core.h)
     const int *childDfs;    // 8 per block: DFS pre-order index of child c
     const f4 *leafNB;       // 2 per node: component-wise min / max of the leaf's surface normals
+    const f4 *leafTB;       // 4 per node: the leaf's tight box (xrt_core.h leaf_certainly_missed)
     const f4 *refN;         // per leaf reference: (surfaceNormal.xyz, global triangle id)
     const g3 *refG;         // 3 per leaf reference: v1, E1, E2
     const MeshRec *meshes;
@@ -451,6 +452,10 @@ XRT_HD void advance_node(Lane &L, const SceneView &S, Stack &stk, int mode, bool
         if (!L.spec) {   // the lane has lately met back faces only: can this whole leaf be rejected by RE:48-51 without reading it?
             const f4 nlo = S.leafNB[2 * (size_t)(L.blk * 8 + c)], nhi = S.leafNB[2 * (size_t)(L.blk * 8 + c) + 1];
             if (all_back_facing(nlo, nhi, L.r.d)) return;
+        }
+        {   // can the ray reach any triangle of the leaf at all (xrt_core.h leaf_certainly_missed)?
+            const f4 *tb = S.leafTB + 4 * (size_t)(L.blk * 8 + c);
+            if (leaf_certainly_missed(L.r, make_ray_cull(L.r.o, L.r.d), tb[0], tb[1], tb[2], tb[3])) return;
         }
         // offs[] is a running total over all eight children, so the list ends where the next child's starts
         const unsigned long long offLo = L.offLo, offHi = L.offHi;

@@ -112,7 +112,7 @@ struct xrt_scene {
     HostScene hs;
     const HostScene *host = &hs;   // what the frame code reads; a replica on another device points at its primary's
     // HBM-resident scene
-    DevBuf<f4> blocks, refN, snodes, shade, leafNB;
+    DevBuf<f4> blocks, refN, snodes, shade, leafNB, leafTB;
     DevBuf<g3> refG;
     DevBuf<int> childDfs, srefs, objMesh;
     DevBuf<MeshRec> meshes;
@@ -135,6 +135,7 @@ struct xrt_scene {
     // tail growing with the frame size -- waves stuck with eight expensive rays per lane while the queue was empty.  64: C3 3.9 ->
     // 3.4 ms, C4 11.4 -> 9.4 ms per blocking frame; 32 and 16 lose to contention on the queue word.
     int batchMax = 64;
+    int packetCullMin = 4;     // XRT_PK_CULL_MIN (development): leaves with fewer references skip the tight-box test
     int packetGrabMax = 2;     // XRT_PK_GRAB (development): 8 -> 2 shortened the tail of a launch (C5 blocking 9.0 -> 7.8 ms); 1 loses to contention on the queue word
     int packetStaticDiv = 4;   // XRT_PK_STATIC (development): 1/2 .. 1/8 measured within 2 % of each other on C5
     int sceneMode = MODE_SCENE;   // MODE_SINGLE when the scene is one SceneObject with one Mesh
@@ -196,8 +197,8 @@ struct xrt_scene {
         bool pending = false;
         bool fast = false;           // no copy / fill / event-record commands: k_compose hands the counters over, events ride on kernels
         int *pinnedDev = nullptr;    // device view of `pinned`
-        int stampRows = 0;           // traversal launches that timed themselves (device_util.h); (start, end) pairs at pinned + stampOff
-        size_t stampOff = 0;
+        int stampRows = 0;           // traversal launches of the frame that timed themselves (device_util.h)
+        unsigned long long *stampHost = nullptr, *stampHostDev = nullptr;   // their (start, end) clock pairs: mapped pinned memory and its device view
         // deferred accounting
         int tallyChunks = 0, cntStride = 0, R = 0, nL = 0;
         bool collect = false;
@@ -256,10 +257,11 @@ struct xrt_scene {
                 for (auto e : f.events) (void)hipEventDestroy(e);
                 if (f.done) (void)hipEventDestroy(f.done);
                 if (f.pinned) (void)hipHostFree(f.pinned);
+                if (f.stampHost) (void)hipHostFree(f.stampHost);
                 f.w.release();
             }
             if (stream) (void)hipStreamDestroy(stream);
-            blocks.release(); leafNB.release(); refN.release(); refG.release(); snodes.release(); shade.release();
+            blocks.release(); leafNB.release(); leafTB.release(); refN.release(); refG.release(); snodes.release(); shade.release();
             childDfs.release(); srefs.release(); objMesh.release(); meshes.release();
             objects.release(); materials.release(); texels.release();
             apiRays.release(); apiHits.release();
@@ -295,6 +297,7 @@ int need_device(xrt_scene *s, const char *fn) {
     return XRT_OK;
 }
 
+constexpr int MAX_STAMP_ROWS = 256;   // traversal launches of one frame that can time themselves (kernels.h STAMP_*)
 hipEvent_t get_event(std::vector<hipEvent_t> &pool, size_t i) {
     while (pool.size() <= i) {
         hipEvent_t e = nullptr;
@@ -497,10 +500,17 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // on the stream: counters come back through k_compose's epilogue and the frame's events ride on raygen / compose.
     const bool fast = !adaptive && !heap && firstPaths <= chunkPaths && !opts->collect_stats;
     F.fast = fast;
-    // single-chunk frames: the traversal launches time themselves on the device clock instead of carrying events (device_util.h)
-    const bool useStamps = fast && !s->launchEvents && !s->noLaunchTiming && s->wallClockKHz > 0;
+    // the traversal launches time themselves on the device clock instead of carrying events (device_util.h); a frame of more
+    // than MAX_STAMP_ROWS launches (many chunks or supersampling levels) goes on with events
+    const bool useStamps = !s->launchEvents && !s->noLaunchTiming && s->wallClockKHz > 0;
     F.stampRows = 0;
-    if (useStamps && (rc = W.stamps.ensure((size_t)3 * (R + 2) * STAMP_STRIDE))) return rc;
+    if (useStamps) {
+        if ((rc = W.stamps.ensure((size_t)MAX_STAMP_ROWS * STAMP_STRIDE))) return rc;
+        if (!F.stampHost) {
+            HIPCHECK(hipHostMalloc((void **)&F.stampHost, (size_t)MAX_STAMP_ROWS * 2 * sizeof(unsigned long long), hipHostMallocMapped));
+            HIPCHECK(hipHostGetDevicePointer((void **)&F.stampHostDev, F.stampHost, 0));
+        }
+    }
     if (!st) {
         // No stream given.  Single-chunk frames get a stream per context, so that two frames in flight overlap on the GPU
         // (C2: 0.139 -> 0.115 ms per frame, C3 2.7 -> 2.3); everything else, and frames of a few microseconds, stay on the
@@ -585,6 +595,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // shadow answers and turns the hits of generation k into shadow rays and the rays of generation k+1.
     auto enqueue_chunk = [&](const RayGenParams &gp, int *cnt, unsigned *q, int Pc, long long pathBase) -> int {
         int *scnt = cnt + (R + 2), *hcnt = cnt + 2 * (R + 2);
+        const int chunkRow0 = F.stampRows;
         // "long ray first" (kernels.hip): the producer of generation k lists its long rays, launch #k takes them first
         const bool feedback = fast && s->deepMeshes && s->costMap.p != nullptr;
         const bool listLong = s->heavyPath > 0.0f || feedback;
@@ -622,13 +633,13 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             auto launch_pk = [&](const IntersectArgs &I, int word, long long nHost) -> int {
                 PacketArgs PA;
                 PA.rays = I.rays; PA.hits = I.hits; PA.index = I.index; PA.nDev = I.nDev; PA.nMul = I.nMul; PA.n = I.n; PA.nCap = I.nCap;
-                PA.queue = q + QW * k + 1 + word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv; PA.grabMax = s->packetGrabMax;
+                PA.queue = q + QW * k + 1 + word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv; PA.grabMax = s->packetGrabMax; PA.cullMin = s->packetCullMin;
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 int grid = s->numCUs * s->blocksPerCUPacket;
                 if (nHost >= 0) { const long long want = (nHost + 255) / 256; if (want < grid) grid = (int)(want < 1 ? 1 : want); }
-                if (useStamps && grid * 4 <= STAMP_SLOTS) { PA.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
-                else if (fast && s->noLaunchTiming) a0 = a1 = nullptr;
+                if (useStamps && grid * 4 <= STAMP_SLOTS && F.stampRows < MAX_STAMP_ROWS) { PA.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
+                else if (s->noLaunchTiming) a0 = a1 = nullptr;
                 else { pairs.push_back({ev, ev + 1}); ev += 2; }
                 launch_packet(S, PA, grid, st, a0, a1);
                 return XRT_OK;
@@ -643,8 +654,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 const int grid = persistent_grid(s, k == 0 ? Pc : -1);
-                if (useStamps && grid * 4 <= STAMP_SLOTS) { A.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
-                else if (fast && s->noLaunchTiming) a0 = a1 = nullptr;
+                if (useStamps && grid * 4 <= STAMP_SLOTS && F.stampRows < MAX_STAMP_ROWS) { A.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
+                else if (s->noLaunchTiming) a0 = a1 = nullptr;
                 else { pairs.push_back({ev, ev + 1}); ev += 2; }
                 if (s->waveTimes.p && k < 16) A.debugTimes = s->waveTimes.p + (size_t)k * 3 * 8192;
                 launch_intersect(S, A, s->stackNeeded, grid, st, a0, a1);
@@ -672,14 +683,14 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             launch_shade(S, V, X, st);
         }
         Range rc_("xrt compose");
-        if (heap) launch_compose_tree(W.lvlA.p, W.lvlB.p, s->lvlAlpha.p, Pc, P, R, W.sampleColor.p, wantF32 ? W.sampleF32.p : nullptr, st);
+        StampFold fold;
+        fold.src = W.stamps.p; fold.host = F.stampHostDev; fold.row0 = chunkRow0; fold.row1 = F.stampRows;
+        if (heap) launch_compose_tree(W.lvlA.p, W.lvlB.p, s->lvlAlpha.p, Pc, P, R, W.sampleColor.p, wantF32 ? W.sampleF32.p : nullptr, fold, st);
         else {
             ResolveArgs RA;
             RA.fused = fuseResolve ? 1 : 0; RA.g = gp; RA.pixelBase = pathBase; RA.out = d_out; RA.outF32 = d_outF32;
-            if (fast) {
-                RA.cntSrc = cnt; RA.hostCnt = F.pinnedDev; RA.cntWords = cntStride; RA.zeroWords = cntStride + qStride;
-                RA.stampSrc = W.stamps.p; RA.hostStamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(F.pinnedDev) + F.stampOff); RA.stampRows = F.stampRows;
-            }
+            RA.stamps = fold;
+            if (fast) { RA.cntSrc = cnt; RA.hostCnt = F.pinnedDev; RA.cntWords = cntStride; RA.zeroWords = cntStride + qStride; }
             launch_compose(W.lvlA.p, W.lvlB.p, Pc, P, R, W.sampleColor.p, (wantF32 && !fuseResolve) ? W.sampleF32.p : nullptr, RA, st,
                            (fast && fuseResolve) ? e1 : nullptr);
         }
@@ -712,20 +723,23 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         if (heap) {
             // ray-tree mode: one chunk at a time, checked for overflow, retried with fewer paths when a generation did not fit
             const size_t words = (size_t)cntStride + (size_t)qStride;
-            if ((rc2 = W.cnts.ensure(words)) || (rc2 = ensure_pinned(words * sizeof(int) + nb2 + 64))) return rc2;
+            if ((rc2 = W.cnts.ensure(words)) || (rc2 = ensure_pinned(words * sizeof(int) + nb2 + 64 + 8))) return rc2;
             unsigned *q = reinterpret_cast<unsigned *>(W.cnts.p + cntStride);
             long long pathBase = 0, curChunk = chunkPaths;   // (ray-tree frames are never split: partStart == 0)
             while (pathBase < total) {
                 const int Pc = (int)((total - pathBase) < curChunk ? (total - pathBase) : curChunk);
                 HIPCHECK(hipMemsetAsync(W.cnts.p, 0, words * sizeof(int), st));
                 const size_t pairsMark = pairs.size(), evMark = ev;
+                const int rowsMark = F.stampRows;
                 if ((rc2 = enqueue_chunk(gp, W.cnts.p, q, Pc, pathBase))) return rc2;
+                // the chunk's samples are consumed before the host has looked at the overflow flag: a retry overwrites them
+                if ((rc2 = post(Pc, pathBase))) return rc2;
                 char *pin = (char *)F.pinned;
+                const size_t cAt = ((size_t)cntStride * sizeof(int) + 7) & ~(size_t)7;   // counters + spare words (overflow flag) in one copy
                 HIPCHECK(hipMemcpyAsync(pin, W.cnts.p, (size_t)cntStride * sizeof(int), hipMemcpyDeviceToHost, st));
-                HIPCHECK(hipMemcpyAsync(pin + (size_t)cntStride * sizeof(int), overflowFlag, sizeof(int), hipMemcpyDeviceToHost, st));
-                HIPCHECK(hipMemcpyAsync(pin + (size_t)cntStride * sizeof(int) + 64, s->counters.p, nb2, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipMemcpyAsync(pin + cAt, s->counters.p, nb2 + 64, hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipStreamSynchronize(st));
-                const int over = *(const int *)(pin + (size_t)cntStride * sizeof(int));
+                const int over = *(const int *)(pin + cAt + nb2 + 12 * sizeof(int));
                 if (over) {
                     if (curChunk <= 64) return fail(XRT_E_UNSUPPORTED, "the ray tree of 64 paths does not fit the ray buffers (MaxReflections too high for this scene)");
                     curChunk = (curChunk / 4) & ~63LL;
@@ -733,12 +747,11 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                     HIPCHECK(hipMemsetAsync(overflowFlag, 0, sizeof(int), st));
                     HIPCHECK(hipMemcpyAsync(s->counters.p, hcntHost, nb2, hipMemcpyHostToDevice, st));   // undo this attempt's counting
                     HIPCHECK(hipStreamSynchronize(st));
-                    pairs.resize(pairsMark); ev = evMark;   // its launches are not part of the frame's timing
+                    pairs.resize(pairsMark); ev = evMark; F.stampRows = rowsMark;   // its launches are not part of the frame's timing
                     continue;
                 }
                 tally((const int *)pin);
-                std::memcpy(hcntHost, pin + (size_t)cntStride * sizeof(int) + 64, nb2);
-                if ((rc2 = post(Pc, pathBase))) return rc2;
+                std::memcpy(hcntHost, pin + cAt, nb2);
                 pathBase += Pc;
                 s->progress.store(progress0 + (progress1 - progress0) * (float)pathBase / (float)total);
             }
@@ -751,10 +764,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         const int *cntsBefore = W.cnts.p;
         if ((rc2 = W.cnts.ensure(cntWords + qWords))) return rc2;
         unsigned *queuesBase = reinterpret_cast<unsigned *>(W.cnts.p + cntWords);
-        if (fast) {   // counters, then the (start, end) clock pairs of up to 3 traversal launches per step
-            F.stampOff = (cntWords * sizeof(int) + 63) & ~(size_t)63;
-            if ((rc2 = ensure_pinned(F.stampOff + (size_t)3 * (R + 2) * 2 * sizeof(unsigned long long)))) return rc2;
-        }
+        if (fast && (rc2 = ensure_pinned(cntWords * sizeof(int)))) return rc2;
         if (!fast || !W.cntsClean || W.cnts.p != cntsBefore) HIPCHECK(hipMemsetAsync(W.cnts.p, 0, W.cnts.cap * sizeof(int), st));
         W.cntsClean = false;
         for (int c = 0; c < nChunks; c++) {
@@ -930,13 +940,12 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
             HIPCHECK(hipEventElapsedTime(&t, F.events[pr.first], F.events[pr.second]));
             mi += t;
         }
-        if (F.fast && F.stampRows > 0) {
-            const unsigned long long *sp = reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(F.pinned) + F.stampOff);
-            for (int j = 0; j < F.stampRows; j++)
-                if (sp[2 * j + 1] > sp[2 * j]) mi += (double)(sp[2 * j + 1] - sp[2 * j]) / (double)s->wallClockKHz;
+        for (int j = 0; j < F.stampRows; j++) {
+            const unsigned long long *sp = F.stampHost;
+            if (sp[2 * j + 1] > sp[2 * j]) mi += (double)(sp[2 * j + 1] - sp[2 * j]) / (double)s->wallClockKHz;
         }
         stats->ms_intersect = mi;
-        stats->intersect_launches = (uint32_t)F.pairs.size() + (uint32_t)(F.fast ? F.stampRows : 0);
+        stats->intersect_launches = (uint32_t)F.pairs.size() + (uint32_t)F.stampRows;
         stats->pieces = 1;
     }
     return XRT_OK;
@@ -955,7 +964,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->batchMax = s->batchMax; r->tuneGiven = s->tuneGiven;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->packetCullMin = s->packetCullMin; r->batchMax = s->batchMax; r->tuneGiven = s->tuneGiven;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1241,14 +1250,14 @@ int scene_upload(xrt_scene *scene) {
     if (scene->device < 0) return XRT_OK;   // host-only scene: trees can be inspected, nothing can be traced
     HIPCHECK(hipSetDevice(scene->device));
     int rc;
-    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->leafNB, A.leafNB)) || (rc = upload(scene->refN, A.refN)) || (rc = upload(scene->refG, A.refG)) ||
+    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->leafNB, A.leafNB)) || (rc = upload(scene->leafTB, A.leafTB)) || (rc = upload(scene->refN, A.refN)) || (rc = upload(scene->refG, A.refG)) ||
         (rc = upload(scene->snodes, A.snodes)) || (rc = upload(scene->shade, A.shade)) || (rc = upload(scene->childDfs, A.childDfs)) ||
         (rc = upload(scene->srefs, A.srefs)) || (rc = upload(scene->objMesh, A.objMesh)) ||
         (rc = upload(scene->meshes, A.meshes)) || (rc = upload(scene->objects, A.objects)) || (rc = upload(scene->materials, A.materials)) ||
         (rc = upload(scene->texels, A.texels)))
         return rc;
     SceneView &S = scene->view;
-    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.leafNB = scene->leafNB.p; S.refN = scene->refN.p; S.refG = scene->refG.p;
+    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.leafNB = scene->leafNB.p; S.leafTB = scene->leafTB.p; S.refN = scene->refN.p; S.refG = scene->refG.p;
     S.meshes = scene->meshes.p; S.snodes = scene->snodes.p; S.srefs = scene->srefs.p;
     S.objects = scene->objects.p; S.objMesh = scene->objMesh.p;
     S.nMeshes = (int)scene->host->meshes.size(); S.nObjects = (int)scene->host->objects.size();
@@ -1327,6 +1336,8 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_LAUNCH_TIMING")) s->noLaunchTiming = atoi(e) == 0;
     if (const char *e = getenv("XRT_SPLIT_MS")) s->splitMinMs = (float)atof(e);
     if (const char *e = getenv("XRT_SPLIT_PARTS")) { const int v = atoi(e); if (v >= 2 && v <= 4) s->splitParts = v; }
+    if (const char *e = getenv("XRT_PK_CULL_MIN")) s->packetCullMin = atoi(e);
+    if (const char *e = getenv("XRT_LEAF_CULL")) { const double v = atof(e); if (v >= 0.0 && v <= 1e6) s->hs.leafCullSafety = v; }   // development: 0 = no tight leaf boxes, 1 = the proven margin
     if (const char *e = getenv("XRT_CULL_SAFETY")) { const double v = atof(e); if (v >= 0.0 && v <= 1e6) s->hs.cullSafety = v; }   // development: factor S of the object pre-cull margin (below 2 the bound is no longer proven)
     s->noRectCull = getenv("XRT_NO_RECT_CULL") != nullptr; s->oneStream = getenv("XRT_ONE_STREAM") != nullptr; s->noFeedback = getenv("XRT_NO_FEEDBACK") != nullptr;
     if (const char *e = getenv("XRT_OVERLAP_MS")) s->overlapMinMs = (float)atof(e);   // 0: every single-chunk frame gets its context's stream

@@ -249,6 +249,58 @@ XRT_HD bool tri_test_front(v3 O, v3 D, v3 v1, v3 E1, v3 E2, float &u, float &v, 
     return tri_stage_b(D, E1, E2, T, det, row2, u, v, dist);
 }
 
+// ---- tight leaf boxes (DESIGN.md §3 "Leaves whose triangles a ray cannot reach") -----------------------------------------
+// A leaf's octree cell is a cube, its triangles usually fill a thin slab of it: a ray can cross the cell far from all of them,
+// and MO:288-304 then runs RE:42-75 on every reference for nothing.  Per leaf the host stores the box of the triangles' vertices
+// (v1, v1 + E1, v1 + E2 -- the very numbers RE:54-58 uses), the box of their unit geometric normals and two constants; a ray
+// skips the leaf when it misses the vertex box grown by rho, where rho bounds how far from a triangle the exact ray can pass
+// while the binary32 test RE:42-75 still answers "hit":
+//     rho = LEAF_CULL_C u0 kappa (Tmax + Emax),  kappa <= max_t |E1||E2|/|E1 x E2| * |D| / min_t |D . n_t|,  u0 = 2^-24,
+// Tmax >= |O - v1| (distance to the farthest corner of the vertex box), Emax = the leaf's longest edge E1 / E2.  The
+// derivation (forward error of RE:42-75, no FMA: |X* - X_f| <= 84 u0 kappa (|T| + Emax), 42 u0 kappa |T| more for a hit reported
+// slightly behind the origin, 3 u0 (Tmax + rho) for the slab test below) needs 130; 192 leaves room for the roundings of
+// this evaluation itself.  kappa = inf (a ray in a triangle's plane, a degenerate triangle) grows the box over everything.
+// Record: [0] = (lo.xyz, K = C u0 max_t |E1||E2|/|N|), [1] = (hi.xyz, Emax), [2] = (nlo.xyz, ok), [3] = (nhi.xyz, -).
+constexpr float LEAF_CULL_C = 192.0f;
+struct RayCull {
+    float d2;    // |D|_2, or 0 when the ray takes no part (a component of D below 2^-40 |D| or non-finite, |O| above 2^40)
+    float slack; // 2^-21 |D|_1: rounding of the three products of D . n below
+};
+XRT_HD RayCull make_ray_cull(v3 o, v3 d) {
+    RayCull c;
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    const float d1 = (ax + ay) + az;
+    const float q = (d.x * d.x + d.y * d.y) + d.z * d.z;
+    const float lo = fminf(fminf(ax, ay), az), om = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+    const bool ok = d1 >= 9.5367432e-7f /* 2^-20 */ && d1 <= 1048576.0f && lo >= d1 * 9.094947e-13f /* 2^-40 */ && om <= 1.0995116e12f /* 2^40 */;
+    c.d2 = ok ? sqrtf(q) * 1.000001f : 0.0f;   // (comparisons with a NaN are false: not ok)
+    c.slack = d1 * 4.7683716e-7f;              // 2^-21
+    return c;
+}
+XRT_HD bool leaf_certainly_missed(const RayPre &r, const RayCull &rc, const f4 &a, const f4 &b, const f4 &nl, const f4 &nh) {
+    // the farthest corner of the vertex box from the origin: >= |O - v1| for every triangle of the leaf
+    const float fx = fmaxf(fabsf(r.o.x - a.x), fabsf(r.o.x - b.x)), fy = fmaxf(fabsf(r.o.y - a.y), fabsf(r.o.y - b.y)),
+                fz = fmaxf(fabsf(r.o.z - a.z), fabsf(r.o.z - b.z));
+    const float tmax = sqrtf((fx * fx + fy * fy) + fz * fz) * 1.000001f;
+    // a lower bound of |D . n| over the box of the leaf's unit normals
+    const float px = r.d.x * nl.x, qx = r.d.x * nh.x, py = r.d.y * nl.y, qy = r.d.y * nh.y, pz = r.d.z * nl.z, qz = r.d.z * nh.z;
+    const float lo = (fminf(px, qx) + fminf(py, qy)) + fminf(pz, qz), hi = (fmaxf(px, qx) + fmaxf(py, qy)) + fmaxf(pz, qz);
+    const float cmin = fmaxf(lo, -hi) - rc.slack;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float rho = ((a.w * (b.w + tmax)) * rc.d2) * (__builtin_amdgcn_rcpf(cmin) * 1.000001f);   // (v_rcp_f32: 1 ulp)
+#else
+    const float rho = ((a.w * (b.w + tmax)) * rc.d2) * ((1.0f / cmin) * 1.000001f);
+#endif
+    // (every comparison below is false when something is not a finite positive number: no skip)
+    if (!(nl.w > 0.0f && rc.d2 > 0.0f && cmin > 0.0f && rho < 1.0e15f)) return false;
+    const float t1x = ((a.x - rho) - r.o.x) * r.inv.x, t2x = ((b.x + rho) - r.o.x) * r.inv.x;
+    const float t1y = ((a.y - rho) - r.o.y) * r.inv.y, t2y = ((b.y + rho) - r.o.y) * r.inv.y;
+    const float t1z = ((a.z - rho) - r.o.z) * r.inv.z, t2z = ((b.z + rho) - r.o.z) * r.inv.z;
+    const float tn = fmaxf(fmaxf(fmaxf(fminf(t1x, t2x), 0.0f), fminf(t1y, t2y)), fminf(t1z, t2z));
+    const float tf = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+    return tn > tf;
+}
+
 // ---- Color (RT:584,705,726,732) ---------------------------------------------------------------------------
 XRT_HD uint32_t pack_unorm255(float v) {
     v = v * 255.0f;
