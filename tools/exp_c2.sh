@@ -1,9 +1,6 @@
 set -e -o pipefail
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/exp6_pytest.log 2>&1 || { tail -30 gpurun_out/exp6_pytest.log; exit 1; }
-tail -3 gpurun_out/exp6_pytest.log
-for c in C3 C4 C5_1spp C2 G1; do
-for v in 1 0; do
-echo $c leafcull=$v; XRT_LEAF_CULL=$v timeout -k 10 300 python tools/hosttime.py $c 60
-done
-done
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/exp9_pytest.log 2>&1 || { tail -30 gpurun_out/exp9_pytest.log; exit 1; }
+tail -3 gpurun_out/exp9_pytest.log
+for i in 1 2 3; do timeout -k 10 300 python tools/hosttime.py C5 40; done
+bash tools/frame_trace.sh C5 | tail -16

@@ -35,11 +35,12 @@ struct PkUniform {   // wave-uniform cursor
     v3 bmin, half;
 };
 
+struct alignas(4) TriWords { float w[16]; };   // a 13-word record of refT and the first three words of the next one
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float rflf(float v) { return i2f(__builtin_amdgcn_readfirstlane(f2i(v))); }
 
 template <int M>
-__global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, const f4 *__restrict__ refN, const g3 *__restrict__ refG,
+__global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, const float *__restrict__ refT,
                                                 const f4 *__restrict__ leafNB, const f4 *__restrict__ leafTB, const MeshRec *__restrict__ meshes, SceneView S,
                                                 PacketArgs A) {
     __shared__ unsigned frames[4 * PK_LEVELS * PK_FRAME_WORDS];
@@ -179,31 +180,30 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
                     // The triangle is the same for every lane: normals and geometry come through the scalar cache.  Two register
                     // sets take turns, and a triangle's 52 bytes are requested before the previous one's arithmetic starts (the
                     // records of a leaf are back to back; the arrays end in two dummy records, so asking one past the leaf is safe).
-                    const f4 *pn = refN + r0;
-                    const g3 *pg = refG + 3 * (size_t)r0;
-                    auto test = [&](const f4 &nn, const g3 &ga, const g3 &gb, const g3 &gc, int r) {
-                        const bool f = !(facing(mk(nn.x, nn.y, nn.z), L.r.d) > 0.0f) & (f2i(nn.w) != L.ignoreId);   // RE:48-51, MO:290
+                    // One record of 13 words (refT: normal, id, v1, E1, E2) = one s_load_dwordx16 (the three words past it belong to
+                    // the next record; the array ends in padding): the scalar unit is this kernel's scarce resource, and a
+                    // triangle used to cost three loads from two streams.
+                    const char *pt = reinterpret_cast<const char *>(refT) + (size_t)r0 * TRI_REC_BYTES;
+                    auto test = [&](const TriWords &q, int r) {
+                        const bool f = !(facing(mk(q.w[0], q.w[1], q.w[2]), L.r.d) > 0.0f) & (f2i(q.w[3]) != L.ignoreId);   // RE:48-51, MO:290
                         v3 T; float det, row2;
-                        const bool sA = tri_stage_a(L.r.o, L.r.d, mk(ga.x, ga.y, ga.z), mk(gb.x, gb.y, gb.z), mk(gc.x, gc.y, gc.z), T, det, row2) & f;
-                        if (__any(sA)) {   // one wave-level branch per triangle: most are rejected by the sign of u for every lane
-                            if (sA) {
-                                float u, v, t;
-                                if (tri_stage_b(L.r.d, mk(gb.x, gb.y, gb.z), mk(gc.x, gc.y, gc.z), T, det, row2, u, v, t))
-                                    leaf_candidate(L, S, r, -2, true, u, v, t);   // (the ignored triangle was filtered above: -2 matches no id)
-                            }
+                        const v3 gb = mk(q.w[7], q.w[8], q.w[9]), gc = mk(q.w[10], q.w[11], q.w[12]);
+                        const bool sA = tri_stage_a(L.r.o, L.r.d, mk(q.w[4], q.w[5], q.w[6]), gb, gc, T, det, row2) & f;
+                        if (sA) {   // one wave-level branch per triangle (s_cbranch_execz): most are rejected by the sign of u for every lane
+                            float u, v, t;
+                            if (tri_stage_b(L.r.d, gb, gc, T, det, row2, u, v, t))
+                                leaf_candidate(L, S, r, -2, true, u, v, t);   // (the ignored triangle was filtered above: -2 matches no id)
                         }
                     };
-                    f4 nA = pn[0];
-                    g3 a0 = pg[0], a1 = pg[1], a2 = pg[2];
+                    TriWords qA = *reinterpret_cast<const TriWords *>(pt);
                     int r = r0;
                     for (;;) {
-                        const f4 nB = pn[1];
-                        const g3 b0 = pg[3], b1 = pg[4], b2 = pg[5];
-                        test(nA, a0, a1, a2, r);
+                        const TriWords qB = *reinterpret_cast<const TriWords *>(pt + TRI_REC_BYTES);
+                        test(qA, r);
                         if (r + 1 >= r1) break;
-                        nA = pn[2]; a0 = pg[6]; a1 = pg[7]; a2 = pg[8];
-                        test(nB, b0, b1, b2, r + 1);
-                        r += 2; pn += 2; pg += 6;
+                        qA = *reinterpret_cast<const TriWords *>(pt + 2 * TRI_REC_BYTES);
+                        test(qB, r + 1);
+                        r += 2; pt += 2 * TRI_REC_BYTES;
                         if (r >= r1) break;
                     }
                 }
@@ -255,8 +255,8 @@ int packet_blocks_per_cu(int mode) {
 
 void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     dim3 g((unsigned)gridBlocks), b(256);
-    if (A.mode == MODE_MESH) hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.blocks, S.refN, S.refG, S.leafNB, S.leafTB, S.meshes, S, A);
-    else hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refN, S.refG, S.leafNB, S.leafTB, S.meshes, S, A);
+    if (A.mode == MODE_MESH) hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S, A);
+    else hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S, A);
 }
 
 }  // namespace xrt

@@ -8,7 +8,7 @@
 namespace xrt {
 
 size_t SceneArrays::bytes() const {
-    return (blocks.size() + refN.size() + snodes.size() + shade.size() + leafNB.size() + leafTB.size()) * sizeof(f4) + refG.size() * sizeof(g3) +
+    return (blocks.size() + refN.size() + snodes.size() + shade.size() + leafNB.size() + leafTB.size()) * sizeof(f4) + refT.size() * sizeof(float) + refG.size() * sizeof(g3) +
            (childDfs.size() + srefs.size() + objMesh.size()) * sizeof(int) + meshes.size() * sizeof(MeshRec) +
            objects.size() * sizeof(ObjRec) + materials.size() * sizeof(MaterialRec) + texels.size() * sizeof(uint32_t);
 }
@@ -287,6 +287,12 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
     // never hand out empty arrays (a zero-size allocation has no address)
     // two dummy references at the end: the wave-packet kernel requests the next triangle's record before it knows the leaf has ended
     for (int k = 0; k < 2; k++) { A.refN.push_back(f4{0, 0, 0, i2f(-1)}); for (int j = 0; j < 3; j++) A.refG.push_back(g3{0, 0, 0}); }
+    A.refT.resize(A.refN.size() * TRI_REC_WORDS + 16, 0.0f);
+    for (size_t r = 0; r < A.refN.size(); r++) {
+        float *q = &A.refT[r * TRI_REC_WORDS];
+        q[0] = A.refN[r].x; q[1] = A.refN[r].y; q[2] = A.refN[r].z; q[3] = A.refN[r].w;
+        for (int j = 0; j < 3; j++) { q[4 + 3 * j] = A.refG[3 * r + j].x; q[5 + 3 * j] = A.refG[3 * r + j].y; q[6 + 3 * j] = A.refG[3 * r + j].z; }
+    }
     if (A.srefs.empty()) A.srefs.assign(1, -1);
     if (A.objMesh.empty()) A.objMesh.assign(1, -1);
     if (A.shade.empty()) A.shade.assign(SHADE_F4, f4{0, 0, 0, 0});
@@ -384,7 +390,7 @@ bool HostScene::load(const char *path, std::string &err) {
 SceneView HostScene::host_view() const {
     SceneView S;
     const SceneArrays &A = arrays;
-    S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data(); S.leafNB = A.leafNB.data(); S.leafTB = A.leafTB.data();
+    S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data(); S.leafNB = A.leafNB.data(); S.leafTB = A.leafTB.data(); S.refT = A.refT.data();
     S.refN = A.refN.data(); S.refG = A.refG.data(); S.meshes = A.meshes.data();
     S.snodes = A.snodes.data(); S.srefs = A.srefs.data(); S.objects = A.objects.data(); S.objMesh = A.objMesh.data();
     S.nMeshes = (int)meshes.size(); S.nObjects = (int)objects.size();

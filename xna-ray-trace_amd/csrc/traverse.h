@@ -24,6 +24,7 @@ struct SceneView {
     const f4 *leafTB;       // 4 per node: the leaf's tight box (xrt_core.h leaf_certainly_missed)
     const f4 *refN;         // per leaf reference: (surfaceNormal.xyz, global triangle id)
     const g3 *refG;         // 3 per leaf reference: v1, E1, E2
+    const float *refT;      // the same two streams as one record of TRI_REC_WORDS words per reference (k_packet's scalar loads)
     const MeshRec *meshes;
     const f4 *snodes;       // scene octree, 2 per record
     const int *srefs;       // object id per scene leaf reference

@@ -113,6 +113,7 @@ struct xrt_scene {
     const HostScene *host = &hs;   // what the frame code reads; a replica on another device points at its primary's
     // HBM-resident scene
     DevBuf<f4> blocks, refN, snodes, shade, leafNB, leafTB;
+    DevBuf<float> refT;
     DevBuf<g3> refG;
     DevBuf<int> childDfs, srefs, objMesh;
     DevBuf<MeshRec> meshes;
@@ -261,7 +262,7 @@ struct xrt_scene {
                 f.w.release();
             }
             if (stream) (void)hipStreamDestroy(stream);
-            blocks.release(); leafNB.release(); leafTB.release(); refN.release(); refG.release(); snodes.release(); shade.release();
+            blocks.release(); leafNB.release(); leafTB.release(); refT.release(); refN.release(); refG.release(); snodes.release(); shade.release();
             childDfs.release(); srefs.release(); objMesh.release(); meshes.release();
             objects.release(); materials.release(); texels.release();
             apiRays.release(); apiHits.release();
@@ -679,7 +680,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             X.hitsPrev = hitsOf[prv]; X.slotPrev = slotOf[prv]; X.scntPrev = k >= 1 ? scnt + (k - 1) : nullptr; X.shadowHits = W.shadowHits.p;
             X.lvlA = W.lvlA.p; X.lvlB = W.lvlB.p; X.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
             if (k < R) X.heavy = heavy_for(k + 1);
-            if (feedback && hasClosest) { X.costOut = s->costMap.p + (size_t)k * (size_t)framePaths + (size_t)partStart; X.epoch = s->epoch & 0xffffu; }
+            if (feedback && hasClosest && !packet_closest(k)) { X.costOut = s->costMap.p + (size_t)k * (size_t)framePaths + (size_t)partStart; X.epoch = s->epoch & 0xffffu; }
             launch_shade(S, V, X, st);
         }
         Range rc_("xrt compose");
@@ -1250,14 +1251,14 @@ int scene_upload(xrt_scene *scene) {
     if (scene->device < 0) return XRT_OK;   // host-only scene: trees can be inspected, nothing can be traced
     HIPCHECK(hipSetDevice(scene->device));
     int rc;
-    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->leafNB, A.leafNB)) || (rc = upload(scene->leafTB, A.leafTB)) || (rc = upload(scene->refN, A.refN)) || (rc = upload(scene->refG, A.refG)) ||
+    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->leafNB, A.leafNB)) || (rc = upload(scene->leafTB, A.leafTB)) || (rc = upload(scene->refT, A.refT)) || (rc = upload(scene->refN, A.refN)) || (rc = upload(scene->refG, A.refG)) ||
         (rc = upload(scene->snodes, A.snodes)) || (rc = upload(scene->shade, A.shade)) || (rc = upload(scene->childDfs, A.childDfs)) ||
         (rc = upload(scene->srefs, A.srefs)) || (rc = upload(scene->objMesh, A.objMesh)) ||
         (rc = upload(scene->meshes, A.meshes)) || (rc = upload(scene->objects, A.objects)) || (rc = upload(scene->materials, A.materials)) ||
         (rc = upload(scene->texels, A.texels)))
         return rc;
     SceneView &S = scene->view;
-    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.leafNB = scene->leafNB.p; S.leafTB = scene->leafTB.p; S.refN = scene->refN.p; S.refG = scene->refG.p;
+    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.leafNB = scene->leafNB.p; S.leafTB = scene->leafTB.p; S.refT = scene->refT.p; S.refN = scene->refN.p; S.refG = scene->refG.p;
     S.meshes = scene->meshes.p; S.snodes = scene->snodes.p; S.srefs = scene->srefs.p;
     S.objects = scene->objects.p; S.objMesh = scene->objMesh.p;
     S.nMeshes = (int)scene->host->meshes.size(); S.nObjects = (int)scene->host->objects.size();
