@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
         // per lane: for every level of the shared stack, which children of that level's block the lane's own box tests accepted
         unsigned long long cbLo = 0, cbMid = 0, cbHi = 0;
         int sp = 0;
-        bool entering = true;
+        bool entering = true, anyFound = false;   // anyFound: some lane of the wave has a candidate
         int d0 = 0, d1 = 0, d2 = 0, d3 = 0;
         unsigned long long offLo = 0, offHi = 0;
         int cb = 0;
@@ -158,11 +158,18 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
             const bool inC = in && ((cb >> c) & 1);
             v3 cmin, cmax;
             child_box(U.bmin, U.half, c, cmin, cmax);
+            // The child's own test gives the entry key (its outcome is known: hit).  The bucket rule compares keys only once a lane
+            // has a candidate; until some lane of the wave has one (most of a packet's walk) the key of a leaf is computed by the
+            // lanes that find a candidate in it, and nobody computes the key of an interior child.
+            auto entry_key = [&]() {
+                float k = 0.0f;
+                if (fastL) (void)slab_fast(L.r, L.dmask, cmin, cmax, k);
+                else (void)slab(L.r, cmin.x, cmin.y, cmin.z, cmax.x, cmax.y, cmax.z, k);
+                return k;
+            };
+            const bool keyed = anyFound;   // wave-uniform
             float key = 0.0f;
-            if (inC) {   // the child's own test gives the entry key (its outcome is known: hit)
-                if (fastL) (void)slab_fast(L.r, L.dmask, cmin, cmax, key);
-                else (void)slab(L.r, cmin.x, cmin.y, cmin.z, cmax.x, cmax.y, cmax.z, key);
-            }
+            if (keyed && inC) key = entry_key();
             const int node = U.blk * 8 + c;
             if (!((d2 >> c) & 1)) {   // ---- leaf (non-empty): MO:288-304 for the lanes the bucket rule lets in ----
                 const f4 nlo = leafNB[2 * (size_t)node], nhi = leafNB[2 * (size_t)node + 1];
@@ -191,8 +198,10 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
                         const bool sA = tri_stage_a(L.r.o, L.r.d, mk(q.w[4], q.w[5], q.w[6]), gb, gc, T, det, row2) & f;
                         if (sA) {   // one wave-level branch per triangle (s_cbranch_execz): most are rejected by the sign of u for every lane
                             float u, v, t;
-                            if (tri_stage_b(L.r.d, gb, gc, T, det, row2, u, v, t))
+                            if (tri_stage_b(L.r.d, gb, gc, T, det, row2, u, v, t)) {
+                                if (!keyed) L.leafKey = entry_key();
                                 leaf_candidate(L, S, r, -2, true, u, v, t);   // (the ignored triangle was filtered above: -2 matches no id)
+                            }
                         }
                     };
                     TriWords qA = *reinterpret_cast<const TriWords *>(pt);
@@ -207,6 +216,7 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
                         if (r >= r1) break;
                     }
                 }
+                if (!keyed) anyFound = __any(L.mfound != 0);
                 continue;
             }
             // ---- interior child: a lane prunes it by key only where that is a proven lower bound (safe bit) ----
