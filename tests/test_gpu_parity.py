@@ -954,12 +954,12 @@ def test_frames_split_in_two_halves_on_two_streams(xrt, monkeypatch, split):
 
 
 def test_wave_packet_kernel_against_the_oracle(xrt, orc, monkeypatch):
-    """k_packet (packet.hip): one wavefront walks the mesh octree once for 64 rays.  XRT_PACKET=15 routes every ray population
+    """k_packet (packet.hip): one wavefront walks the mesh octree once for 64 rays.  XRT_PACKET=31 routes every ray population
     of a one-body scene through it -- seam-1 batches included, i.e. incoherent random rays, rays leaving surfaces with an
     ignored triangle, axis-parallel, zero and non-finite rays: the worst case for a packet, and it must still give the
     reference's answers bit for bit (hit triangle, leaf id, u/v/d, world position), for the scene query and the per-mesh query;
     frames with 1 and 16 sub-rays equal the oracle's too."""
-    monkeypatch.setenv("XRT_PACKET", "15")
+    monkeypatch.setenv("XRT_PACKET", "31")
     specs = {"h64": xrt.configs.heightfield_scene(160, 90, m=64), "h224": xrt.configs.heightfield_scene(160, 90, m=224),
              "soup": soup_spec(xrt, 2000, 7, 20, 0.15), "soup_deep": soup_spec(xrt, 300, 5, 4, 0.5)}
     t = xrt.configs.SceneSpec("crate5_rot")

@@ -129,7 +129,8 @@ struct xrt_scene {
     // Which ray populations take the wave-packet kernel.  -1 (default): all three of a frame with 16 sub-rays per pixel -- a wave
     // then holds 4 pixels x 16 samples, rays that visit the same leaves (measured on the 1M-triangle frame: 7.3 against 11.1 ms);
     // none otherwise (64 pixels of a 1-sample frame fan out over too many leaves: 5 x slower than the per-lane kernel).
-    // XRT_PACKET=<mask> forces it: bit 0 primary rays, 1 shadow rays, 2 closest-hit rays of later generations, 3 seam-1 batches.
+    // XRT_PACKET=<mask> forces it: bit 0 primary rays, 1 shadow rays, 2 closest-hit rays of later generations, 3 seam-1 batches,
+    // 4 bits 1 and 2 also apply beyond generation 1 (default: the first two generations and the first shadow rays only).
     int packetMask = -1;
     // Largest guided batch of k_intersect (XRT_BATCH_MAX).  Round 1 let a wave reserve up to 512 rays per atomic; per-wave clocks
     // (make WAVE_TIMES=1, tools/wave_times.py) showed the median wave of a C3 / C4 launch leaving at 57 % of the launch and the
@@ -184,6 +185,7 @@ struct xrt_scene {
     bool deepMeshes = false;  // some mesh has a real octree: rays can be long
     float heavyPath = 0.0f;   // rays longer than this inside the root box are traced first (0: off); XRT_HEAVY=<fraction of the box diagonal>
     std::string waveTimesPath;
+    std::string stampDumpPath;   // XRT_STAMP_DUMP=<file>: the stamp rows of the last frame (start, waves, every wave's end) -- how long a launch's waves lived
     DevBuf<unsigned long long> waveTimes;   // XRT_WAVE_TIMES=<file>: per-wave clocks of the last frame's launches (development aid)
     // Per-frame host state.  Two contexts so that the next frame can be enqueued while the previous one's counters
     // and timings are still on their way back (xrt_render_device_begin / _end).
@@ -600,8 +602,10 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         // "long ray first" (kernels.hip): the producer of generation k lists its long rays, launch #k takes them first
         const bool feedback = fast && s->deepMeshes && s->costMap.p != nullptr;
         const bool listLong = s->heavyPath > 0.0f || feedback;
-        auto packet_closest = [&](int k) { return (k == 0 ? (pkMask & 1) : (pkMask & 4)) != 0; };
-        const bool packetShadow = (pkMask & 2) != 0;
+        // (generation 0 and 1 and the shadow rays of generation 0 are the big coherent populations; after two bounces the 64 rays
+        // of a packet have little in common and a few packets take three times as long as the rest of their launch: bit 4)
+        auto packet_closest = [&](int k) { return (k == 0 ? (pkMask & 1) : (k == 1 ? (pkMask & 4) : ((pkMask & 4) && (pkMask & 16)))) != 0; };
+        auto packet_shadow = [&](int k) { return (pkMask & 2) != 0 && (k <= 1 || (pkMask & 16) != 0); };   // shadow rays of generation k-1
         auto heavy_for = [&](int k) {
             HeavyArgs H;
             if (listLong && (k == 0 || !heap) && !packet_closest(k)) {   // (packets are not scheduled ray by ray)
@@ -630,7 +634,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 a->refillMin = s->tune[0]; a->nodeBurst = s->tune[1]; a->leafBurst = s->tune[2]; a->coopMax = s->tune[3]; a->batchMax = s->batchMax; a->firstBatch = s->firstBatch;
             }
             // segments of coherent rays go to the wave-packet kernel, the others (together, one launch) to the per-lane kernel
-            const bool pkC = hasClosest && packet_closest(k), pkB = hasShadow && packetShadow;
+            const bool pkC = hasClosest && packet_closest(k), pkB = hasShadow && packet_shadow(k);
             auto launch_pk = [&](const IntersectArgs &I, int word, long long nHost) -> int {
                 PacketArgs PA;
                 PA.rays = I.rays; PA.hits = I.hits; PA.index = I.index; PA.nDev = I.nDev; PA.nMul = I.nMul; PA.n = I.n; PA.nCap = I.nCap;
@@ -884,6 +888,11 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
         std::vector<unsigned long long> h((size_t)16 * 3 * 8192);
         HIPCHECK(hipMemcpy(h.data(), s->waveTimes.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         if (FILE *f = fopen(s->waveTimesPath.c_str(), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+    }
+    if (!s->stampDumpPath.empty() && F.stampRows > 0) {   // development aid (tools/stamp_lives.py)
+        std::vector<unsigned long long> h((size_t)F.stampRows * STAMP_STRIDE);
+        HIPCHECK(hipMemcpy(h.data(), F.w.stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(s->stampDumpPath.c_str(), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
     }
     const int R = F.R;
     if (F.tallyChunks > 0) {   // single-pass frame: the read-back was left in flight
@@ -1327,11 +1336,12 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     xrt_scene *s = new xrt_scene();
     s->device = device;
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
+    s->stampDumpPath = getenv("XRT_STAMP_DUMP") ? getenv("XRT_STAMP_DUMP") : "";
     s->fakeGpus = getenv("XRT_FAKE_GPUS") != nullptr;
     if (const char *e = getenv("XRT_BATCH_MAX")) { const int v = atoi(e); if (v >= 16 && v <= 4096 && v % 16 == 0) s->batchMax = v; }
     if (const char *e = getenv("XRT_PK_GRAB")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->packetGrabMax = v; }
     if (const char *e = getenv("XRT_PK_STATIC")) { const int v = atoi(e); if (v >= 0 && v <= 64) s->packetStaticDiv = v; }
-    if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 15) s->packetMask = v; }
+    if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 31) s->packetMask = v; }
     if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
     if (const char *e = getenv("XRT_LAUNCH_EVENTS")) s->launchEvents = atoi(e) != 0;
     if (const char *e = getenv("XRT_LAUNCH_TIMING")) s->noLaunchTiming = atoi(e) == 0;
