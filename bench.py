@@ -49,11 +49,12 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 # (= the 157.3 TFLOP/s vector peak, which counts a fused multiply-add as two; this path is built with contraction off)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 SCALAR_PEAK_TINST = 256 * 2.4e9 / 1e12   # one scalar-unit instruction per cycle per CU (empirical)
-KERNEL_SOURCES = ("kernels.hip", "packet.hip", "kernels.h", "device_util.h", "traverse.h", "xrt_core.h")
+KERNEL_SOURCES = ("kernels.hip", "packet.hip", "kernels.h", "device_util.h", "traverse.h", "xrt_core.h", "xrt_api.cpp")
 
 
 def build_id():
-    """Hash of the sources the traversal kernel is compiled from: PMC figures are only quoted for the build they were taken on."""
+    """Hash of the sources the traversal kernels are compiled from and of the host code that decides which launches a frame makes:
+    PMC figures (per-launch averages) are only quoted for the build they were taken on."""
     import hashlib
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 def build_id():
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip", "packet.hip", "kernels.h", "device_util.h", "traverse.h", "xrt_core.h"):
+    for f in ("kernels.hip", "packet.hip", "kernels.h", "device_util.h", "traverse.h", "xrt_core.h", "xrt_api.cpp"):
         h.update(open(os.path.join(ROOT, "xna-ray-trace_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
