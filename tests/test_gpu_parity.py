@@ -569,6 +569,29 @@ def test_launch_timing_device_clock_vs_events(xrt, monkeypatch):
     assert e * 0.85 - 0.012 * n <= c <= e * 1.15, (ms_c, ms_e)
 
 
+def test_launch_timing_mixed_stamps_and_events(xrt, monkeypatch):
+    """A frame with more traversal launches than stamp rows (XRT_STAMP_ROWS lowers the 256 of a build to 3) times the rest with
+    events: same frames, same launch count, a sum of the same order -- for a plain frame, a ray-tree frame (whose chunks fold
+    their rows in k_compose_tree) and an adaptive frame (several passes)."""
+    import copy
+    specs = [xrt.configs.config("C3", 0.25), xrt.configs.config("G1", 0.25)]
+    ad = copy.deepcopy(xrt.configs.config("C3", 0.25))
+    ad.multisampling, ad.multisample_quality = xrt.abi.MS_ADAPTIVE, 2
+    specs.append(ad)
+    for spec in specs:
+        scene, tracer = xrt.configs.build_product(spec)
+        monkeypatch.setenv("XRT_STAMP_ROWS", "3")
+        scene_m, tracer_m = xrt.configs.build_product(spec)
+        monkeypatch.delenv("XRT_STAMP_ROWS")
+        for i in range(3):
+            a = tracer.Render().copy(); sa = dict(tracer.last_stats)
+            b = tracer_m.Render().copy(); sb = dict(tracer_m.last_stats)
+        assert np.array_equal(a, b)
+        assert sa["intersect_launches"] == sb["intersect_launches"] > 3
+        assert 0 < sa["ms_intersect"] <= sa["ms_total"] and 0 < sb["ms_intersect"] <= sb["ms_total"] * 1.05
+        assert 0.5 * sb["ms_intersect"] < sa["ms_intersect"] < 1.5 * sb["ms_intersect"] + 0.1
+
+
 def test_overlapping_frames_on_two_streams(xrt, monkeypatch):
     """Frames that run long enough get one stream per frame context and overlap on the GPU (XRT_OVERLAP_MS=0 forces it
     for a test-sized frame): two different cameras in flight at once give the frames of the blocking renders, over

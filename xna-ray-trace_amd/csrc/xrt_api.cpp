@@ -107,6 +107,7 @@ int upload(DevBuf<T> &b, const std::vector<T> &v) {
 
 }  // namespace
 
+constexpr int MAX_STAMP_ROWS = 256;   // traversal launches of one frame that can time themselves (kernels.h STAMP_*)
 struct xrt_scene {
     int device = -1;   // -1: host-only scene (inspection of the built trees; every compute call fails)
     HostScene hs;
@@ -222,6 +223,7 @@ struct xrt_scene {
     // 75-95 % and the second set of launches costs what the overlap gains (C3 2.74 vs 2.91 ms, C4 7.1 vs 6.9, C5 7.9 vs 8.0).
     int splitMode = 0, splitParts = 2;
     bool launchEvents = false;   // XRT_LAUNCH_EVENTS=1: single-chunk frames time their traversal launches with events on the dispatch packets, too
+    int maxStampRows = MAX_STAMP_ROWS;   // XRT_STAMP_ROWS=<n> (tests): launches of a frame beyond the n-th carry events instead
     bool noLaunchTiming = false; // XRT_LAUNCH_TIMING=0: single-chunk frames do not time their traversal launches (xrt_stats.ms_intersect = 0)
     int wallClockKHz = 0;        // rate of the device clock the launches stamp (hipDeviceAttributeWallClockRate)
     float splitMinMs = 1.0f;
@@ -300,7 +302,6 @@ int need_device(xrt_scene *s, const char *fn) {
     return XRT_OK;
 }
 
-constexpr int MAX_STAMP_ROWS = 256;   // traversal launches of one frame that can time themselves (kernels.h STAMP_*)
 hipEvent_t get_event(std::vector<hipEvent_t> &pool, size_t i) {
     while (pool.size() <= i) {
         hipEvent_t e = nullptr;
@@ -643,7 +644,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 int grid = s->numCUs * s->blocksPerCUPacket;
                 if (nHost >= 0) { const long long want = (nHost + 255) / 256; if (want < grid) grid = (int)(want < 1 ? 1 : want); }
-                if (useStamps && grid * 4 <= STAMP_SLOTS && F.stampRows < MAX_STAMP_ROWS) { PA.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
+                if (useStamps && grid * 4 <= STAMP_SLOTS && F.stampRows < s->maxStampRows) { PA.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
                 else if (s->noLaunchTiming) a0 = a1 = nullptr;
                 else { pairs.push_back({ev, ev + 1}); ev += 2; }
                 launch_packet(S, PA, grid, st, a0, a1);
@@ -659,7 +660,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 const int grid = persistent_grid(s, k == 0 ? Pc : -1);
-                if (useStamps && grid * 4 <= STAMP_SLOTS && F.stampRows < MAX_STAMP_ROWS) { A.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
+                if (useStamps && grid * 4 <= STAMP_SLOTS && F.stampRows < s->maxStampRows) { A.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
                 else if (s->noLaunchTiming) a0 = a1 = nullptr;
                 else { pairs.push_back({ev, ev + 1}); ev += 2; }
                 if (s->waveTimes.p && k < 16) A.debugTimes = s->waveTimes.p + (size_t)k * 3 * 8192;
@@ -980,7 +981,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) r->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (hipDeviceGetAttribute(&r->wallClockKHz, hipDeviceAttributeWallClockRate, r->device) != hipSuccess) { r->wallClockKHz = 0; (void)hipGetLastError(); }
-        r->launchEvents = s->launchEvents; r->noLaunchTiming = s->noLaunchTiming;
+        r->launchEvents = s->launchEvents; r->noLaunchTiming = s->noLaunchTiming; r->maxStampRows = s->maxStampRows;
         HIPCHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
         int rc = scene_upload(r.get());
         if (rc != XRT_OK) return rc;
@@ -1344,6 +1345,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 31) s->packetMask = v; }
     if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
     if (const char *e = getenv("XRT_LAUNCH_EVENTS")) s->launchEvents = atoi(e) != 0;
+    if (const char *e = getenv("XRT_STAMP_ROWS")) { const int v = atoi(e); if (v >= 0 && v <= MAX_STAMP_ROWS) s->maxStampRows = v; }
     if (const char *e = getenv("XRT_LAUNCH_TIMING")) s->noLaunchTiming = atoi(e) == 0;
     if (const char *e = getenv("XRT_SPLIT_MS")) s->splitMinMs = (float)atof(e);
     if (const char *e = getenv("XRT_SPLIT_PARTS")) { const int v = atoi(e); if (v >= 2 && v <= 4) s->splitParts = v; }
