@@ -2,5 +2,7 @@
 # Scratch pad for one-off measurements on the GPU box (gpurun -- 'bash tools/scratch_experiment.sh'); rewritten per experiment.
 set -e -o pipefail
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/exp12_pytest.log 2>&1 || { tail -40 gpurun_out/exp12_pytest.log; exit 1; }
-tail -3 gpurun_out/exp12_pytest.log
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/exp13_pytest.log 2>&1 || { tail -40 gpurun_out/exp13_pytest.log; exit 1; }
+tail -3 gpurun_out/exp13_pytest.log
+for c in C5 C3 C2 C4; do timeout -k 10 300 python tools/hosttime.py $c 40; done
+bash tools/frame_trace.sh C5 | tail -15

@@ -51,6 +51,10 @@ struct IntersectArgs {
     xrt_hit *hits2 = nullptr;
     const int *nDev2 = nullptr;
     int nMul2 = 0, nCap2 = 0;
+    // Inside a frame: one word per ray says hit / miss (dense, what k_shade reads first) and a miss writes no 48-byte record
+    // unless its scheduling-feedback word is wanted (missRecords); null: every ray gets its full record (seam 1)
+    int *flags = nullptr, *flags2 = nullptr;
+    int missRecords = 0;
 };
 
 // Row of device-clock stamps of one traversal launch (device_util.h stamp_begin / stamp_end): [start, waves, end[waves]]
@@ -69,6 +73,7 @@ struct PacketArgs {
     int unmark = 0;               // rays may carry the long-ray mark of their producer (device_util.h)
     int staticDiv = 4;            // 1/staticDiv of the packets are dealt statically (0: none)
     int grabMax = 2;              // most packets a wave takes per queue atomic
+    int *flags = nullptr;         // inside a frame: hit / miss word per ray, no record for a miss (IntersectArgs::flags)
     int cullMin = 4;              // leaves of at least this many references are tested against their tight box first (the test costs about two triangles)
     unsigned long long *stamps = nullptr;   // this launch's row of device-clock stamps (device_util.h), or null
 };
@@ -102,6 +107,8 @@ struct ShadeArgs {
     HeavyArgs heavy;   // for the rays of generation level+1
     unsigned *costOut = nullptr;   // cost map of generation `level` (part A writes what its rays cost), tagged with `epoch`
     unsigned epoch = 0;
+    // hit / miss words of `hits` and `shadowHits` (IntersectArgs::flags): the 48-byte record of a miss does not exist
+    const int *hitFlags = nullptr, *shadowFlags = nullptr;
 };
 
 int  intersect_stack_capacity(int needed);   // smallest compiled capacity >= needed, or -1

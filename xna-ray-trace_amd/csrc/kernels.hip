@@ -361,7 +361,12 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? 4 : 5) void k_intersect(Sc
             else coop_leaf_step(L, S, &coopOwn[wave * 64 * COOP_ROUNDS]);
         }
         if (L.state == ST_FINISH) {
-            store_hit(L.rayIndex < 0 ? A.hits2 + ~L.rayIndex : A.hits + L.rayIndex, lane_result(L, C, S, M));
+            const HitOut h = lane_result(L, C, S, M);
+            const bool seg2 = L.rayIndex < 0;
+            const int at = seg2 ? ~L.rayIndex : L.rayIndex;
+            int *const fl = seg2 ? A.flags2 : A.flags;
+            if (fl) fl[at] = h.hit;
+            if (!fl || h.hit || A.missRecords) store_hit((seg2 ? A.hits2 : A.hits) + at, h);
             L.state = ST_IDLE;
         }
     }
@@ -672,9 +677,12 @@ struct ShadePoint {
     v3 normal, world;
     int gtri, mat;
 };
-__device__ __forceinline__ void load_hit(const xrt_hit *src, int &hit, int &object, int &mesh, int &tri, float &u, float &v, float &d, v3 &w) {
+// (`flag`: the ray's hit / miss word where the launch wrote one -- a miss has no record then, IntersectArgs::flags)
+__device__ __forceinline__ void load_hit(const xrt_hit *src, int &hit, int &object, int &mesh, int &tri, float &u, float &v, float &d, v3 &w,
+                                         const int *flag = nullptr) {
     const Hit16 *p = reinterpret_cast<const Hit16 *>(src);
-    Hit16 a = p[0], b = p[1], c = p[2];
+    Hit16 a = Hit16{0, -1, -1, -1}, b = Hit16{0, 0, 0, 0}, c = b;
+    if (!flag || *flag != 0) { a = p[0]; b = p[1]; c = p[2]; }
     hit = a.i0; object = a.i1; mesh = a.i2; tri = a.i3;
     u = i2f(b.i1); v = i2f(b.i2); d = i2f(b.i3);
     w = mk(i2f(c.i0), i2f(c.i1), i2f(c.i2));
@@ -779,7 +787,8 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
                 v3 dir; float dist;
                 light_dir(Lt, w, dir, dist);
                 int sh, sobj, smesh, stri; float su, sv, sd; v3 sw;
-                load_hit(X.shadowHits + (size_t)s * V.nLights + l, sh, sobj, smesh, stri, su, sv, sd, sw);
+                load_hit(X.shadowHits + (size_t)s * V.nLights + l, sh, sobj, smesh, stri, su, sv, sd, sw,
+                         X.shadowFlags ? X.shadowFlags + (size_t)s * V.nLights + l : nullptr);
                 float lightAmount = 0.0f;   // RT:485-501
                 if (sh && sd < dist) {
                     const MaterialRec SM = V.materials[V.meshes[smesh].material];
@@ -820,9 +829,9 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
         bool refracts = false;
         if (j < n) {
             if (X.index) i = X.index[j];   // generation 0: only the rays that reached the scene's root box were traced
-            load_hit(X.hits + i, hit, object, mesh, tri, u, v, d, w);
+            load_hit(X.hits + i, hit, object, mesh, tri, u, v, d, w, X.hitFlags ? X.hitFlags + i : nullptr);
             p = X.rayPath ? X.rayPath[i] : i;
-            if (X.costOut) {
+            if (X.costOut) {   // (launches whose cost words are read write a record for every ray: IntersectArgs::missRecords)
                 const int c = reinterpret_cast<const Hit16 *>(X.hits + i)[2].i3;
                 X.costOut[p] = (X.epoch << 16) | (unsigned)(c > 0xffff ? 0xffff : (c < 0 ? 0 : c));
             }

@@ -244,7 +244,9 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
         }
         if (valid) {
             L.mesh = mesh;
-            store_hit(A.hits + idx, lane_result(L, C, S, M));
+            const HitOut h = lane_result(L, C, S, M);
+            if (A.flags) A.flags[idx] = h.hit;
+            if (!A.flags || h.hit) store_hit(A.hits + idx, h);
         }
     }
     stamp_end(A.stamps);

@@ -158,6 +158,7 @@ struct xrt_scene {
         DevBuf<xrt_ray> rays0, rays1, shadowRays;
         DevBuf<xrt_hit> hits, hits1, shadowHits;
         DevBuf<int> path0, path1, index0, heavyList, cnts;
+        DevBuf<int> hitFlags0, hitFlags1, shadowFlags;   // hit / miss word per ray of hits, hits1, shadowHits (a miss has no record)
         DevBuf<unsigned long long> stamps;      // device-clock stamps of the traversal launches (device_util.h), STAMP_STRIDE per launch
         DevBuf<SlotRec> slot0, slot1;
         DevBuf<f4> lvlA, lvlB;
@@ -171,7 +172,7 @@ struct xrt_scene {
         hipStream_t lastStream = nullptr;       // the stream the context's last frame ran on
         void release() {
             rays0.release(); rays1.release(); shadowRays.release(); hits.release(); hits1.release(); shadowHits.release();
-            path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); stamps.release(); slot0.release(); slot1.release();
+            path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); stamps.release(); hitFlags0.release(); hitFlags1.release(); shadowFlags.release(); slot0.release(); slot1.release();
             lvlA.release(); lvlB.release(); sampleColor.release(); sampleF32.release(); lights.release();
             if (stream) (void)hipStreamDestroy(stream);
             stream = nullptr;
@@ -483,7 +484,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const bool fuseResolve = !adaptive && !heap && g.samples == 1;   // k_compose writes the framebuffer itself
     // buffers
     if ((rc = W.rays0.ensure(rayCap)) || (rc = W.rays1.ensure(rayCap)) || (rc = W.hits.ensure(rayCap)) || (rc = W.path0.ensure(rayCap)) ||
-        (rc = W.path1.ensure(rayCap)) || (rc = W.hits1.ensure(rayCap)) || (rc = W.slot0.ensure(rayCap)) ||
+        (rc = W.path1.ensure(rayCap)) || (rc = W.hits1.ensure(rayCap)) || (rc = W.hitFlags0.ensure(rayCap)) || (rc = W.hitFlags1.ensure(rayCap)) ||
+        (rc = W.shadowFlags.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = W.slot0.ensure(rayCap)) ||
         (rc = W.slot1.ensure(rayCap)) || (rc = W.index0.ensure(P)) || (rc = W.heavyList.ensure(rayCap)) || (rc = W.shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
         (rc = W.shadowHits.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = W.lvlA.ensure((size_t)P * nodes)) ||
         (rc = W.lvlB.ensure((size_t)P * nodes)) || (rc = W.sampleColor.ensure(P)) || (rc = W.lights.ensure(nL > 0 ? nL : 1)) ||
@@ -618,6 +620,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         // cnt[0] counts the primary rays that reach the scene's root box; index0 lists them
         { Range r("xrt raygen"); launch_raygen(gp, S, rays[0], W.lvlB.p, W.index0.p, cnt, Pc, pathBase, heavy_for(0), st, fast ? e0 : nullptr); }
         xrt_hit *hitsOf[2] = {W.hits.p, W.hits1.p};
+        int *flagsOf[2] = {W.hitFlags0.p, W.hitFlags1.p};
         SlotRec *slotOf[2] = {W.slot0.p, W.slot1.p};
         for (int k = 0; k <= R + 1; k++) {
             const int cur = k & 1, prv = cur ^ 1;
@@ -627,6 +630,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             IntersectArgs C, B;   // closest-hit segment, shadow segment
             C.rays = rays[cur]; C.hits = hitsOf[cur]; C.index = k == 0 ? W.index0.p : nullptr; C.nDev = nClosest; C.nMul = 1; C.n = Pc;
             C.nCap = (int)rayCap;
+            C.flags = flagsOf[cur]; B.flags = W.shadowFlags.p;
+            C.missRecords = (feedback && !packet_closest(k)) ? 1 : 0;   // k_shade #k reads the cost word of every ray of the generation
             { const HeavyArgs H = heavy_for(k); C.heavyIdx = H.list; C.nHeavy = H.count; }
             B.rays = W.shadowRays.p; B.hits = W.shadowHits.p; B.index = nullptr; B.nDev = hasShadow ? scnt + (k - 1) : nullptr; B.nMul = nL; B.n = 0;
             B.nCap = (int)((long long)shadowCap * nL);
@@ -638,7 +643,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             const bool pkC = hasClosest && packet_closest(k), pkB = hasShadow && packet_shadow(k);
             auto launch_pk = [&](const IntersectArgs &I, int word, long long nHost) -> int {
                 PacketArgs PA;
-                PA.rays = I.rays; PA.hits = I.hits; PA.index = I.index; PA.nDev = I.nDev; PA.nMul = I.nMul; PA.n = I.n; PA.nCap = I.nCap;
+                PA.rays = I.rays; PA.hits = I.hits; PA.flags = I.flags; PA.index = I.index; PA.nDev = I.nDev; PA.nMul = I.nMul; PA.n = I.n; PA.nCap = I.nCap;
                 PA.queue = q + QW * k + 1 + word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv; PA.grabMax = s->packetGrabMax; PA.cullMin = s->packetCullMin;
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
@@ -656,7 +661,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             const bool laneC = hasClosest && !pkC, laneB = hasShadow && !pkB;
             if (laneC || laneB) {
                 IntersectArgs A = laneC ? C : B;
-                if (laneC && laneB) { A.rays2 = B.rays; A.hits2 = B.hits; A.nDev2 = B.nDev; A.nMul2 = B.nMul; A.nCap2 = B.nCap; }
+                if (laneC && laneB) { A.rays2 = B.rays; A.hits2 = B.hits; A.flags2 = B.flags; A.nDev2 = B.nDev; A.nMul2 = B.nMul; A.nCap2 = B.nCap; }
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 const int grid = persistent_grid(s, k == 0 ? Pc : -1);
@@ -676,7 +681,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             std::memset(&X, 0, sizeof(X));
             X.level = k; X.doA = hasClosest ? 1 : 0; X.doB = k >= 1 ? 1 : 0;
             X.maxReflections = R; X.P = P; X.heap = heap ? 1 : 0; X.overflow = overflowFlag;
-            X.rays = rays[cur]; X.hits = hitsOf[cur]; X.nDev = nClosest; X.nHost = Pc; X.cap = (int)rayCap;
+            X.rays = rays[cur]; X.hits = hitsOf[cur]; X.hitFlags = flagsOf[cur]; X.shadowFlags = W.shadowFlags.p; X.nDev = nClosest; X.nHost = Pc; X.cap = (int)rayCap;
             X.index = k == 0 ? W.index0.p : nullptr; X.rayPath = k == 0 ? nullptr : paths[cur];
             X.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; X.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
             X.slotOut = slotOf[cur]; X.scnt = scnt + k; X.shadowCap = (int)shadowCap; X.shadowRays = W.shadowRays.p;
