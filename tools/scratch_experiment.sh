@@ -2,5 +2,6 @@
 # Scratch pad for one-off measurements on the GPU box (gpurun -- 'bash tools/scratch_experiment.sh'); rewritten per experiment.
 set -e -o pipefail
 cd $GRAFT_REPO_ROOT
-XRT_FUZZ_EXTRA=400 timeout -k 10 1100 python -m pytest tests -m gpu -q -k "random_scenes_against_the_oracle" > gpurun_out/fuzz400.log 2>&1 || { tail -30 gpurun_out/fuzz400.log; exit 1; }
-tail -3 gpurun_out/fuzz400.log
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/exp15_pytest.log 2>&1 || { tail -40 gpurun_out/exp15_pytest.log; exit 1; }
+tail -3 gpurun_out/exp15_pytest.log
+for c in C5 C5_1spp C3 C2 G1; do timeout -k 10 300 python tools/hosttime.py $c 40; done

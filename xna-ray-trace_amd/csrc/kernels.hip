@@ -258,10 +258,16 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? 4 : 5) void k_intersect(Sc
     // closest-hit rays): ray g >= n1 is rays2[g - n1]
     int n2 = A.nDev2 ? (*A.nDev2) * A.nMul2 : 0;
     if (n2 > A.nCap2) n2 = A.nCap2;
-    // rays of segment 1 that their producer listed as long are taken first (work items 0 .. nH-1)
+    // Rays of segment 1 that their producer listed as long are taken first -- but not 64 to a wave: long rays come in clusters
+    // (neighbouring pixels), a wave full of them takes five times as long as one of them alone (C3: 64 rays 320-450 us, one ray
+    // 80 us) and ends the launch long after the other waves have left.  So every 2^heavyShift-th of the first work items is a
+    // listed ray, the others are rays in array order: item w < nH << hs is listed ray w >> hs when w % 2^hs == 0.
     int nH = A.nHeavy ? *A.nHeavy : 0;
     if (nH > n1) nH = n1;
     const int n = nH + n1 + n2;
+    int hs = A.heavyShift;
+    while (hs > 0 && ((long long)nH << hs) > (long long)n) hs--;
+    const int hRegion = nH << hs, hMask = (1 << hs) - 1;
     Lane L;
     L.state = ST_IDLE;
     // Work distribution.  The first 64 rays of every wave are static (no atomic: a grid-wide burst on one word
@@ -272,8 +278,11 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? 4 : 5) void k_intersect(Sc
     const int nWaves = (int)gridDim.x * 4;
     // static share: at most A.firstBatch rays (64 for deep octrees where dynamic balance matters, 256 for trivial
     // scenes where queue traffic matters), but no more than an even split of the launch over the resident waves
-    const int even = ((n + nWaves - 1) / nWaves + 63) & ~63;
-    const int first = even < 64 ? 64 : (even < A.firstBatch ? even : A.firstBatch);
+    // (a small launch is spread over all waves in batches of batchMin rays rather than packed 64 to a wave: a batch takes as
+    // long as its slowest ray, slow rays come in clusters, and idle waves cost nothing)
+    const int bmin = A.batchMin < 16 ? 16 : (A.batchMin > 64 ? 64 : (A.batchMin & ~15));
+    const int even = ((n + nWaves - 1) / nWaves + bmin - 1) & ~(bmin - 1);
+    const int first = even < bmin ? bmin : (even < A.firstBatch ? even : A.firstBatch);
     const unsigned qOffset = (unsigned)(nWaves * first);
     int batchNext = (wave * (int)gridDim.x + (int)blockIdx.x) * first;
     int batchEnd = min(batchNext + first, n);
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? 4 : 5) void k_intersect(Sc
     unsigned long long tStart = 0, tDry = 0;
     if (A.debugTimes) tStart = wall_clock64();
 #endif
-    auto guided = [&](int done) { int c = (n - done) / (nWaves * 2); c &= ~15; const int lo = A.batchMax < 64 ? A.batchMax : 64; return c < lo ? lo : (c > A.batchMax ? A.batchMax : c); };
+    auto guided = [&](int done) { int c = (n - done) / (nWaves * 2); c &= ~15; const int lo = A.batchMax < bmin ? A.batchMax : bmin; return c < lo ? lo : (c > A.batchMax ? A.batchMax : c); };
     unsigned pfBase = 0;
     int pfChunk = 0;
     if (!exhausted && (int)qOffset < n) {   // there is dynamic work beyond the static batches
@@ -314,16 +323,18 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? 4 : 5) void k_intersect(Sc
                     const int take = min(nIdle, batchEnd - batchNext);
                     const int rank = lanes_below(idle);
                     if (L.state == ST_IDLE && rank < take) {
-                        const int w = batchNext + rank, g = w - nH;
+                        const int w = batchNext + rank;
+                        const bool listed = w < hRegion && (w & hMask) == 0;
+                        const int g = w < hRegion ? w - (w >> hs) - 1 : w - nH;   // (unlisted items only)
                         int idx;
                         const xrt_ray *src;
-                        if (w < nH) { idx = A.heavyIdx[w]; src = A.rays + idx; }
+                        if (listed) { idx = A.heavyIdx[w >> hs]; src = A.rays + idx; }
                         else if (g < n1) { idx = A.index ? A.index[g] : g; src = A.rays + idx; }
                         else { src = A.rays2 + (g - n1); idx = ~(g - n1); }   // answers of segment 2 go to hits2
                         v3 o, d; int im, it;
                         load_ray(src, o, d, im, it);
                         bool skip = false;
-                        if (A.nHeavy && idx >= 0 && heavy_marked(it)) { it ^= HEAVY_BIT; skip = w >= nH; }   // listed: traced as work item < nH
+                        if (A.nHeavy && idx >= 0 && heavy_marked(it)) { it ^= HEAVY_BIT; skip = !listed; }   // listed: traced as one of the first work items
                         if (skip) {}
                         else if (im == DEAD_RAY) { L.rayIndex = idx; L.cost = 0; C.sfound = 0; L.mfound = 0; L.state = ST_FINISH; }
                         else lane_begin(L, C, S, o, d, im, it, idx, M, A.meshId);

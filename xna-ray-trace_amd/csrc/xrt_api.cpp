@@ -138,6 +138,9 @@ struct xrt_scene {
     // tail growing with the frame size -- waves stuck with eight expensive rays per lane while the queue was empty.  64: C3 3.9 ->
     // 3.4 ms, C4 11.4 -> 9.4 ms per blocking frame; 32 and 16 lose to contention on the queue word.
     int batchMax = 64;
+    int batchMin = 64;         // XRT_BATCH_MIN (development)
+    int heavyShift = 3;        // listed long rays are dealt one in 2^n work items (0: 64 to a wave); scene_upload: 0 for two-level scenes; XRT_HEAVY_SHIFT
+    bool heavyShiftGiven = false;
     int packetCullMin = 4;     // XRT_PK_CULL_MIN (development): leaves with fewer references skip the tight-box test
     int packetGrabMax = 2;     // XRT_PK_GRAB (development): 8 -> 2 shortened the tail of a launch (C5 blocking 9.0 -> 7.8 ms); 1 loses to contention on the queue word
     int packetStaticDiv = 4;   // XRT_PK_STATIC (development): 1/2 .. 1/8 measured within 2 % of each other on C5
@@ -637,7 +640,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             B.nCap = (int)((long long)shadowCap * nL);
             for (IntersectArgs *a : {&C, &B}) {
                 a->queue = q + QW * k; a->mode = s->sceneMode; a->meshId = 0;
-                a->refillMin = s->tune[0]; a->nodeBurst = s->tune[1]; a->leafBurst = s->tune[2]; a->coopMax = s->tune[3]; a->batchMax = s->batchMax; a->firstBatch = s->firstBatch;
+                a->refillMin = s->tune[0]; a->nodeBurst = s->tune[1]; a->leafBurst = s->tune[2]; a->coopMax = s->tune[3]; a->batchMax = s->batchMax; a->heavyShift = s->heavyShift; a->batchMin = s->batchMin; a->firstBatch = s->firstBatch;
             }
             // segments of coherent rays go to the wave-packet kernel, the others (together, one launch) to the per-lane kernel
             const bool pkC = hasClosest && packet_closest(k), pkB = hasShadow && packet_shadow(k);
@@ -980,7 +983,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->packetCullMin = s->packetCullMin; r->batchMax = s->batchMax; r->tuneGiven = s->tuneGiven;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->packetCullMin = s->packetCullMin; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->tuneGiven = s->tuneGiven;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1224,7 +1227,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
     HIPCHECK(hipMemsetAsync(queue, 0, 2 * sizeof(unsigned), st));
     IntersectArgs A;
     A.rays = d_rays; A.hits = d_hits; A.index = nullptr; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.nCap = 0; A.queue = queue; A.mode = mode; A.meshId = meshId;
-    A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.coopMax = s->tune[3]; A.batchMax = s->batchMax; A.firstBatch = s->firstBatch;
+    A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.coopMax = s->tune[3]; A.batchMax = s->batchMax; A.heavyShift = s->heavyShift; A.batchMin = s->batchMin; A.firstBatch = s->firstBatch;
     hipEvent_t a0 = nullptr, a1 = nullptr;
     if (stats) {
         a0 = get_event(s, 0); a1 = get_event(s, 1);
@@ -1289,6 +1292,10 @@ int scene_upload(xrt_scene *scene) {
     // (measured with 8x8-pixel waves, whose rays take about equally long: C3 3.1 -> 2.45 ms, C4 8.9 -> 6.2 ms of traversal per frame).
     // One-body scenes have no such phase and keep refilling at 24 idle lanes (64 costs them 6 %).
     if (!scene->tuneGiven) scene->tune[0] = scene->sceneMode == MODE_SCENE ? 64 : 24;
+    // Listed long rays: mixed one in eight into the first batches where waves refill lane by lane (a wave full of them takes five
+    // times as long as one of them: C5 at one sample per pixel 1.58 -> 1.42 ms); 64 to a wave where waves refill as a whole -- there
+    // a mixed wave idles 56 lanes until its long rays are done (C3 2.71 -> 2.97 ms when mixed).
+    if (!scene->heavyShiftGiven) scene->heavyShift = scene->sceneMode == MODE_SCENE ? 0 : 3;
     scene->blocksPerCUPacket = packet_blocks_per_cu(scene->sceneMode);
     scene->firstBatch = (A.meshDepth == 0) ? 256 : 64;   // every mesh is a single leaf: rays are cheap, avoid queue traffic
     if (const char *e = getenv("XRT_FIRST_BATCH")) { int v = atoi(e); if (v >= 64 && v <= 4096 && v % 64 == 0) scene->firstBatch = v; }
@@ -1344,6 +1351,8 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
     s->stampDumpPath = getenv("XRT_STAMP_DUMP") ? getenv("XRT_STAMP_DUMP") : "";
     s->fakeGpus = getenv("XRT_FAKE_GPUS") != nullptr;
+    if (const char *e = getenv("XRT_BATCH_MIN")) { const int v = atoi(e); if (v >= 16 && v <= 64 && v % 16 == 0) s->batchMin = v; }
+    if (const char *e = getenv("XRT_HEAVY_SHIFT")) { const int v = atoi(e); if (v >= 0 && v <= 6) { s->heavyShift = v; s->heavyShiftGiven = true; } }
     if (const char *e = getenv("XRT_BATCH_MAX")) { const int v = atoi(e); if (v >= 16 && v <= 4096 && v % 16 == 0) s->batchMax = v; }
     if (const char *e = getenv("XRT_PK_GRAB")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->packetGrabMax = v; }
     if (const char *e = getenv("XRT_PK_STATIC")) { const int v = atoi(e); if (v >= 0 && v <= 64) s->packetStaticDiv = v; }
