@@ -185,6 +185,32 @@ def test_render_parity(xrt, orc, name):
     assert st["ms_intersect"] > 0 and st["intersect_launches"] >= 2
 
 
+def test_no_light_many_lights_and_deep_chains(xrt, orc):
+    """Corners of the frame schedule: a scene without lights (no shadow segment at all), one with three lights (three shadow rays
+    and hit / miss words per hit), and reflection chains of depth 12 on a mirror-like crate grid (fourteen traversal steps, the
+    later ones nearly empty) -- plain frames (no counting pass: the launches time themselves) and counted ones."""
+    import copy
+    base = xrt.configs.crate_grid_scene(96, 54)
+    none = copy.deepcopy(base); none.lights = []
+    three = copy.deepcopy(base)
+    three.lights = [xrt.configs.spot((0, 300, 300)), xrt.configs.spot((200, 150, -100)), xrt.configs.directional((0.3, -1.0, 0.2))]
+    deep = copy.deepcopy(base); deep.max_reflections = 12
+    for m in deep.meshes:
+        m[1]["reflectiveness"] = 0.9
+    deep16 = copy.deepcopy(xrt.configs.heightfield_scene(48, 27, m=64, multisampling=xrt.abi.MS_FIXED16)); deep16.max_reflections = 6
+    for spec in (none, three, deep, deep16):
+        o_rgba, o_rgbf, o_st = orc.OracleScene(spec).render(nthreads=8)
+        for collect in (False, True):
+            scene, tracer = xrt.configs.build_product(spec)
+            tracer.collect_stats = collect
+            rgba, rgbf = tracer.Render(want_float=True)
+            assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+            st = tracer.last_stats
+            for k in ("rays_closest", "rays_shadow", "shaded_hits", "pixels"):
+                assert st[k] == o_st[k], (k, st[k], o_st[k])
+            assert st["intersect_launches"] >= 1 and st["ms_intersect"] > 0
+
+
 def test_golden_frames_on_gpu(xrt):
     for fname, spec in (("c1_rgba.npy", xrt.configs.config("C1")), ("c3_96x54_rgba.npy", xrt.configs.crate_grid_scene(96, 54)),
                         ("h224_48x27_ms16_rgba.npy", xrt.configs.heightfield_scene(48, 27, m=224, multisampling=xrt.abi.MS_FIXED16))):
