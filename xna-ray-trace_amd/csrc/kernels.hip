@@ -907,8 +907,8 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
         }
     }
 }
-void launch_shade(const SceneView &S, const ShadeView &V, const ShadeArgs &X, hipStream_t st) {
-    hipLaunchKernelGGL(k_shade, dim3(1024), dim3(APPEND_BLOCK), 0, st, S, V, X);
+void launch_shade(const SceneView &S, const ShadeView &V, const ShadeArgs &X, hipStream_t st, int blocks) {
+    hipLaunchKernelGGL(k_shade, dim3(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks)), dim3(APPEND_BLOCK), 0, st, S, V, X);
 }
 
 // Frame epilogue: (start, latest wave end) of traversal launches row0 .. row1-1 go to host-visible memory, one block per launch

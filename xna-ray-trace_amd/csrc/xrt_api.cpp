@@ -138,6 +138,10 @@ struct xrt_scene {
     // tail growing with the frame size -- waves stuck with eight expensive rays per lane while the queue was empty.  64: C3 3.9 ->
     // 3.4 ms, C4 11.4 -> 9.4 ms per blocking frame; 32 and 16 lose to contention on the queue word.
     int batchMax = 64;
+    // Sizes of the last finished single-chunk frame's generations (rays of traversal step k, work items of shade step k): the
+    // launches of the next frame of the same geometry are sized for four times that instead of for the whole chip -- a generation
+    // of a few thousand rays costs its kernels' launch floor (5-6 us each with full grids, C2: 0.119 -> 0.11 ms).  Sizing only.
+    long long genKey = -1, genRays[68], genShade[68];
     int batchMin = 64;         // XRT_BATCH_MIN (development)
     int heavyShift = 3;        // listed long rays are dealt one in 2^n work items (0: 64 to a wave); scene_upload: 0 for two-level scenes; XRT_HEAVY_SHIFT
     bool heavyShiftGiven = false;
@@ -205,6 +209,7 @@ struct xrt_scene {
         bool pending = false;
         bool fast = false;           // no copy / fill / event-record commands: k_compose hands the counters over, events ride on kernels
         int *pinnedDev = nullptr;    // device view of `pinned`
+        long long framePaths = 0;    // paths of the frame (part) this context holds: key of the grid hints
         int stampRows = 0;           // traversal launches of the frame that timed themselves (device_util.h)
         unsigned long long *stampHost = nullptr, *stampHostDev = nullptr;   // their (start, end) clock pairs: mapped pinned memory and its device view
         // deferred accounting
@@ -228,6 +233,7 @@ struct xrt_scene {
     int splitMode = 0, splitParts = 2;
     bool launchEvents = false;   // XRT_LAUNCH_EVENTS=1: single-chunk frames time their traversal launches with events on the dispatch packets, too
     int maxStampRows = MAX_STAMP_ROWS;   // XRT_STAMP_ROWS=<n> (tests): launches of a frame beyond the n-th carry events instead
+    bool noGridHints = false;    // XRT_GRID_HINTS=0: every launch is sized for the whole chip
     bool noLaunchTiming = false; // XRT_LAUNCH_TIMING=0: single-chunk frames do not time their traversal launches (xrt_stats.ms_intersect = 0)
     int wallClockKHz = 0;        // rate of the device clock the launches stamp (hipDeviceAttributeWallClockRate)
     float splitMinMs = 1.0f;
@@ -509,6 +515,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // on the stream: counters come back through k_compose's epilogue and the frame's events ride on raygen / compose.
     const bool fast = !adaptive && !heap && firstPaths <= chunkPaths && !opts->collect_stats;
     F.fast = fast;
+    F.framePaths = nParts == 1 ? firstPaths : -1;
     // the traversal launches time themselves on the device clock instead of carrying events (device_util.h); a frame of more
     // than MAX_STAMP_ROWS launches (many chunks or supersampling levels) goes on with events
     const bool useStamps = !s->launchEvents && !s->noLaunchTiming && s->wallClockKHz > 0;
@@ -611,6 +618,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         // (generation 0 and 1 and the shadow rays of generation 0 are the big coherent populations; after two bounces the 64 rays
         // of a packet have little in common and a few packets take three times as long as the rest of their launch: bit 4)
         auto packet_closest = [&](int k) { return (k == 0 ? (pkMask & 1) : (k == 1 ? (pkMask & 4) : ((pkMask & 4) && (pkMask & 16)))) != 0; };
+        const bool hinted = fast && nParts == 1 && s->genKey == firstPaths * 64 + nL && !s->noGridHints;
+        auto hint = [&](const long long *v, int k) -> long long { return (hinted && k < 68 && v[k] >= 0) ? 4 * v[k] + 4096 : -1; };
         auto packet_shadow = [&](int k) { return (pkMask & 2) != 0 && (k <= 1 || (pkMask & 16) != 0); };   // shadow rays of generation k-1
         auto heavy_for = [&](int k) {
             HeavyArgs H;
@@ -659,15 +668,15 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 return XRT_OK;
             };
             Range ri("xrt intersect #%d", k);
-            if (pkC && (rc = launch_pk(C, 0, k == 0 ? Pc : -1))) return rc;
-            if (pkB && (rc = launch_pk(B, 1, -1))) return rc;
+            if (pkC && (rc = launch_pk(C, 0, k == 0 ? Pc : hint(s->genRays, k)))) return rc;
+            if (pkB && (rc = launch_pk(B, 1, hint(s->genRays, k)))) return rc;
             const bool laneC = hasClosest && !pkC, laneB = hasShadow && !pkB;
             if (laneC || laneB) {
                 IntersectArgs A = laneC ? C : B;
                 if (laneC && laneB) { A.rays2 = B.rays; A.hits2 = B.hits; A.flags2 = B.flags; A.nDev2 = B.nDev; A.nMul2 = B.nMul; A.nCap2 = B.nCap; }
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
-                const int grid = persistent_grid(s, k == 0 ? Pc : -1);
+                const int grid = persistent_grid(s, k == 0 ? Pc : hint(s->genRays, k));
                 if (useStamps && grid * 4 <= STAMP_SLOTS && F.stampRows < s->maxStampRows) { A.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
                 else if (s->noLaunchTiming) a0 = a1 = nullptr;
                 else { pairs.push_back({ev, ev + 1}); ev += 2; }
@@ -694,7 +703,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             X.lvlA = W.lvlA.p; X.lvlB = W.lvlB.p; X.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
             if (k < R) X.heavy = heavy_for(k + 1);
             if (feedback && hasClosest && !packet_closest(k)) { X.costOut = s->costMap.p + (size_t)k * (size_t)framePaths + (size_t)partStart; X.epoch = s->epoch & 0xffffu; }
-            launch_shade(S, V, X, st);
+            { const long long h = hint(s->genShade, k); launch_shade(S, V, X, st, h < 0 ? 1024 : (int)((h + 1023) / 1024 < 1024 ? (h + 1023) / 1024 : 1024)); }
         }
         Range rc_("xrt compose");
         StampFold fold;
@@ -915,6 +924,16 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
             }
         }
         if (!F.fast) std::memcpy(F.hcnt, (char *)F.pinned + nb, sizeof(F.hcnt));
+        if (F.fast && F.tallyChunks == 1) {   // sizes of this frame's generations: grid hints for the next one (sizing only)
+            const int *hc = (const int *)F.pinned;
+            for (int k = 0; k <= R + 1 && k < 68; k++) {
+                const long long closest = k == 0 ? hc[0] : (k <= R ? hc[(R + 2) + k - 1] : 0), shaded = k >= 1 ? hc[(R + 2) + k - 1] : 0;
+                s->genRays[k] = closest + shaded * F.nL;
+                s->genShade[k] = closest > shaded ? closest : shaded;
+            }
+            for (int k = R + 2; k < 68; k++) s->genRays[k] = s->genShade[k] = -1;
+            s->genKey = F.framePaths * 64 + F.nL;
+        }
         if (F.fast && s->costMap.p) {   // steer the "long ray" thresholds towards 2-6 % of each generation's rays
             const int *hc = (const int *)F.pinned;
             for (int k = 0; k <= R && k < 66; k++) {
@@ -989,7 +1008,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) r->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (hipDeviceGetAttribute(&r->wallClockKHz, hipDeviceAttributeWallClockRate, r->device) != hipSuccess) { r->wallClockKHz = 0; (void)hipGetLastError(); }
-        r->launchEvents = s->launchEvents; r->noLaunchTiming = s->noLaunchTiming; r->maxStampRows = s->maxStampRows;
+        r->launchEvents = s->launchEvents; r->noLaunchTiming = s->noLaunchTiming; r->noGridHints = s->noGridHints; r->maxStampRows = s->maxStampRows;
         HIPCHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
         int rc = scene_upload(r.get());
         if (rc != XRT_OK) return rc;
@@ -1359,6 +1378,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 31) s->packetMask = v; }
     if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
     if (const char *e = getenv("XRT_LAUNCH_EVENTS")) s->launchEvents = atoi(e) != 0;
+    if (const char *e = getenv("XRT_GRID_HINTS")) s->noGridHints = atoi(e) == 0;
     if (const char *e = getenv("XRT_STAMP_ROWS")) { const int v = atoi(e); if (v >= 0 && v <= MAX_STAMP_ROWS) s->maxStampRows = v; }
     if (const char *e = getenv("XRT_LAUNCH_TIMING")) s->noLaunchTiming = atoi(e) == 0;
     if (const char *e = getenv("XRT_SPLIT_MS")) s->splitMinMs = (float)atof(e);
