@@ -48,7 +48,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 # 2 cycles on a SIMD-32 with >= 2 waves resident, chip table "Max clock 2400 MHz") = 78.6 T lane-operations per second
 # (= the 157.3 TFLOP/s vector peak, which counts a fused multiply-add as two; this path is built with contraction off)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-SCALAR_PEAK_TINST = 256 * 2.4e9 / 1e12   # one scalar-unit instruction per cycle per CU (empirical)
+SCALAR_PEAK_TINST = 256 * 2.4e9 / 1e12   # one scalar-unit instruction per cycle per CU
+# what micro-benchmarks of nothing but independent instructions reach (tools/microbench/, profiles/r02_j/*_peak.txt): 0.94 scalar
+# instructions per cycle and CU, 0.44 wave64 VALU instructions per cycle and SIMD, both with eight waves per SIMD
+SCALAR_MEASURED_TINST = 256 * 2.238e9 / 1e12
+VALU_MEASURED_TLANEOPS = 70.0
 KERNEL_SOURCES = ("kernels.hip", "packet.hip", "kernels.h", "device_util.h", "traverse.h", "xrt_core.h", "xrt_api.cpp")
 
 
@@ -326,16 +330,19 @@ def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_fra
         fr["hbm"] = {"achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4), "bytes_per_launch": traffic}
         fr["valu"] = {"achieved": round(useful, 2), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "Tlane-op/s", "frac": round(useful / VALU_PEAK_TLANEOPS, 4),
                       "issue_frac": round(issue / VALU_PEAK_TLANEOPS, 4), "lane_utilisation": round(pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_INSTS_VALU"] * 64.0), 3),
-                      "valu_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]),
+                      "valu_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]), "measured_peak": VALU_MEASURED_TLANEOPS,
+                      "issue_frac_of_measured_peak": round(issue / VALU_MEASURED_TLANEOPS, 4),
                       "waves_waiting_frac": round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 3) if pmc.get("SQ_WAVE_CYCLES") else None}
         cands = {"valu": fr["valu"]["issue_frac"], "hbm": fr["hbm"]["frac"]}
         if pmc.get("SQ_INSTS_SALU") is not None:
             # the scalar unit (SALU, branches, scalar loads) is shared by a CU's four SIMDs: one instruction per cycle per CU
-            # (empirical ceiling: the first k_packet saturated at 0.89 per cycle per CU; MI355X_MICROARCH.md gives no figure)
+            # (MI355X_MICROARCH.md gives no figure; measured with independent s_add_u32: 0.94 per cycle per CU at best)
             sc = (pmc["SQ_INSTS_SALU"] + pmc.get("SQ_INSTS_BRANCH", 0.0) + pmc.get("SQ_INSTS_SMEM", 0.0)) / t / 1e12
             fr["scalar"] = {"achieved": round(sc, 3), "peak": round(SCALAR_PEAK_TINST, 3), "unit": "Tinst/s", "frac": round(sc / SCALAR_PEAK_TINST, 4),
                             "scalar_instructions_per_launch": int(pmc["SQ_INSTS_SALU"] + pmc.get("SQ_INSTS_BRANCH", 0.0) + pmc.get("SQ_INSTS_SMEM", 0.0))}
             fr["scalar"]["issue_frac"] = fr["scalar"]["frac"]
+            fr["scalar"]["measured_peak"] = round(SCALAR_MEASURED_TINST, 3)
+            fr["scalar"]["frac_of_measured_peak"] = round(sc / SCALAR_MEASURED_TINST, 4)
             cands["scalar"] = fr["scalar"]["frac"]
         bound = max(cands, key=cands.get)
         top = fr[bound]
