@@ -618,6 +618,48 @@ def test_launch_timing_mixed_stamps_and_events(xrt, monkeypatch):
         assert 0.5 * sb["ms_intersect"] < sa["ms_intersect"] < 1.5 * sb["ms_intersect"] + 0.1
 
 
+def test_grid_hints_follow_a_camera_that_looks_away(xrt):
+    """The launches of a frame's later generations are sized for four times the generation sizes of the last finished frame
+    (xrt_api.cpp genRays / genShade).  A camera that looks away from the scene (every generation empty) and back again makes those
+    hints as wrong as they can be; sizing never touches a result: the frames equal the ones rendered without hints."""
+    import torch
+    spec = xrt.configs.config("C3", 0.25)
+    scene, tracer = xrt.configs.build_product(spec)
+    full = tracer.CurrentCamera
+    away = xrt.api.Camera((0, 200, 400), (0, 800, 1200), (0.0, 1.0, 0.0), 0.7853981852531433, xrt.xna.aspect_ratio(spec.width, spec.height), 1.0, 1000.0)
+    want = {}
+    os.environ["XRT_GRID_HINTS"] = "0"
+    try:
+        scene0, tracer0 = xrt.configs.build_product(spec)
+    finally:
+        del os.environ["XRT_GRID_HINTS"]
+    for name, cam in (("full", full), ("away", away)):
+        tracer0.CurrentCamera = cam
+        want[name] = tracer0.Render().copy()
+    assert want["away"].max() == want["away"].min() and not np.array_equal(want["full"], want["away"])
+    seq = ["full", "full", "away", "away", "full", "away", "full", "full"]
+    for name in seq:   # blocking frames
+        tracer.CurrentCamera = full if name == "full" else away
+        assert np.array_equal(tracer.Render(), want[name]), name
+    n = spec.width * spec.height
+    outs = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(2)]
+    frs = {}
+    for name, cam in (("full", full), ("away", away)):
+        tracer.CurrentCamera = cam
+        frs[name] = [tracer.PrepareDevice(o.data_ptr()) for o in outs]
+    open_t = None
+    for i, name in enumerate(seq * 3):   # two frames in flight
+        t = frs[name][i % 2].begin()
+        if open_t is not None:
+            pn, pi, pt = open_t
+            frs[pn][pi % 2].end(pt)
+            assert np.array_equal(outs[pi % 2].cpu().numpy().view(np.uint32), want[pn]), (pi, pn)
+        open_t = (name, i, t)
+    pn, pi, pt = open_t
+    frs[pn][pi % 2].end(pt)
+    assert np.array_equal(outs[pi % 2].cpu().numpy().view(np.uint32), want[pn])
+
+
 def test_overlapping_frames_on_two_streams(xrt, monkeypatch):
     """Frames that run long enough get one stream per frame context and overlap on the GPU (XRT_OVERLAP_MS=0 forces it
     for a test-sized frame): two different cameras in flight at once give the frames of the blocking renders, over

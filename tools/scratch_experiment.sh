@@ -2,5 +2,5 @@
 # Scratch pad for one-off measurements on the GPU box (gpurun -- 'bash tools/scratch_experiment.sh'); rewritten per experiment.
 set -e -o pipefail
 cd $GRAFT_REPO_ROOT
-bash tools/frame_trace.sh C2 | tail -12
-timeout -k 10 200 python tools/stamp_lives.py C2
+timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "grid_hints" > gpurun_out/exp18_pytest.log 2>&1 || { tail -40 gpurun_out/exp18_pytest.log; exit 1; }
+tail -3 gpurun_out/exp18_pytest.log
