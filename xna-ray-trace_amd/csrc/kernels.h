@@ -46,7 +46,8 @@ struct IntersectArgs {
     int coopMax = 32;   // at most this many lanes in a leaf: their triangle lists are dealt to the whole wave
     int batchMax = 64;  // largest guided batch a wave takes per queue atomic (multiple of 16)
     int heavyShift = 3; // one in 2^heavyShift of the first work items is a listed (long) ray
-    int batchMin = 64;  // smallest batch (multiple of 16, 16 .. 64): below 64 the tail of a launch is dealt in part-filled waves
+    int batchMin = 64;  // smallest guided batch (multiple of 16, 16 .. 64): below 64 the tail of a launch is dealt in part-filled waves
+    int spreadMin = 4;  // a launch of fewer than 64 rays per wave is split evenly over all waves in multiples of this (4 .. 64)
     unsigned long long *stamps = nullptr;   // this launch's row of device-clock stamps (device_util.h), or null
     // optional second segment traced by the same launch: rays2[0 .. (*nDev2) * nMul2) -> hits2 (no index list)
     const xrt_ray *rays2 = nullptr;

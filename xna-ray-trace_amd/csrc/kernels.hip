@@ -278,11 +278,12 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? 4 : 5) void k_intersect(Sc
     const int nWaves = (int)gridDim.x * 4;
     // static share: at most A.firstBatch rays (64 for deep octrees where dynamic balance matters, 256 for trivial
     // scenes where queue traffic matters), but no more than an even split of the launch over the resident waves
-    // (a small launch is spread over all waves in batches of batchMin rays rather than packed 64 to a wave: a batch takes as
+    // (a small launch is spread over all waves, spreadMin rays at least, rather than packed 64 to a wave: a batch takes as
     // long as its slowest ray, slow rays come in clusters, and idle waves cost nothing)
-    const int bmin = A.batchMin < 16 ? 16 : (A.batchMin > 64 ? 64 : (A.batchMin & ~15));
-    const int even = ((n + nWaves - 1) / nWaves + bmin - 1) & ~(bmin - 1);
-    const int first = even < bmin ? bmin : (even < A.firstBatch ? even : A.firstBatch);
+    const int bmin = A.batchMin < 16 ? 16 : (A.batchMin > 64 ? 64 : (A.batchMin & ~15));   // smallest guided batch
+    const int smin = A.spreadMin < 4 ? 4 : (A.spreadMin > 64 ? 64 : (A.spreadMin & ~3));    // granule of the static share
+    const int even = ((n + nWaves - 1) / nWaves + smin - 1) & ~(smin - 1);
+    const int first = even < smin ? smin : (even < A.firstBatch ? even : A.firstBatch);
     const unsigned qOffset = (unsigned)(nWaves * first);
     int batchNext = (wave * (int)gridDim.x + (int)blockIdx.x) * first;
     int batchEnd = min(batchNext + first, n);

@@ -143,6 +143,10 @@ struct xrt_scene {
     // of a few thousand rays costs its kernels' launch floor (5-6 us each with full grids, C2: 0.119 -> 0.11 ms).  Sizing only.
     long long genKey = -1, genRays[68], genShade[68];
     int batchMin = 64;         // XRT_BATCH_MIN (development)
+    // A launch of fewer rays than 64 per resident wave is dealt evenly over all waves in multiples of spreadMin instead of 64 to a
+    // wave: a batch takes as long as its slowest ray and longer the more rays diverge in it, and idle waves cost nothing -- the ten
+    // launches of a ray-tree frame of the reference's default scene: 1.05 -> 0.65 ms (XRT_SPREAD_MIN=64: as before).
+    int spreadMin = 4;
     int heavyShift = 3;        // listed long rays are dealt one in 2^n work items (0: 64 to a wave); scene_upload: 0 for two-level scenes; XRT_HEAVY_SHIFT
     bool heavyShiftGiven = false;
     int packetCullMin = 4;     // XRT_PK_CULL_MIN (development): leaves with fewer references skip the tight-box test
@@ -649,7 +653,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             B.nCap = (int)((long long)shadowCap * nL);
             for (IntersectArgs *a : {&C, &B}) {
                 a->queue = q + QW * k; a->mode = s->sceneMode; a->meshId = 0;
-                a->refillMin = s->tune[0]; a->nodeBurst = s->tune[1]; a->leafBurst = s->tune[2]; a->coopMax = s->tune[3]; a->batchMax = s->batchMax; a->heavyShift = s->heavyShift; a->batchMin = s->batchMin; a->firstBatch = s->firstBatch;
+                a->refillMin = s->tune[0]; a->nodeBurst = s->tune[1]; a->leafBurst = s->tune[2]; a->coopMax = s->tune[3]; a->batchMax = s->batchMax; a->heavyShift = s->heavyShift; a->batchMin = s->batchMin; a->spreadMin = s->spreadMin; a->firstBatch = s->firstBatch;
             }
             // segments of coherent rays go to the wave-packet kernel, the others (together, one launch) to the per-lane kernel
             const bool pkC = hasClosest && packet_closest(k), pkB = hasShadow && packet_shadow(k);
@@ -1002,7 +1006,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->packetCullMin = s->packetCullMin; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->tuneGiven = s->tuneGiven;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->packetCullMin = s->packetCullMin; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1246,7 +1250,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
     HIPCHECK(hipMemsetAsync(queue, 0, 2 * sizeof(unsigned), st));
     IntersectArgs A;
     A.rays = d_rays; A.hits = d_hits; A.index = nullptr; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.nCap = 0; A.queue = queue; A.mode = mode; A.meshId = meshId;
-    A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.coopMax = s->tune[3]; A.batchMax = s->batchMax; A.heavyShift = s->heavyShift; A.batchMin = s->batchMin; A.firstBatch = s->firstBatch;
+    A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.coopMax = s->tune[3]; A.batchMax = s->batchMax; A.heavyShift = s->heavyShift; A.batchMin = s->batchMin; A.spreadMin = s->spreadMin; A.firstBatch = s->firstBatch;
     hipEvent_t a0 = nullptr, a1 = nullptr;
     if (stats) {
         a0 = get_event(s, 0); a1 = get_event(s, 1);
@@ -1370,6 +1374,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
     s->stampDumpPath = getenv("XRT_STAMP_DUMP") ? getenv("XRT_STAMP_DUMP") : "";
     s->fakeGpus = getenv("XRT_FAKE_GPUS") != nullptr;
+    if (const char *e = getenv("XRT_SPREAD_MIN")) { const int v = atoi(e); if (v >= 4 && v <= 64 && v % 4 == 0) s->spreadMin = v; }
     if (const char *e = getenv("XRT_BATCH_MIN")) { const int v = atoi(e); if (v >= 16 && v <= 64 && v % 16 == 0) s->batchMin = v; }
     if (const char *e = getenv("XRT_HEAVY_SHIFT")) { const int v = atoi(e); if (v >= 0 && v <= 6) { s->heavyShift = v; s->heavyShiftGiven = true; } }
     if (const char *e = getenv("XRT_BATCH_MAX")) { const int v = atoi(e); if (v >= 16 && v <= 4096 && v % 16 == 0) s->batchMax = v; }
