@@ -1222,3 +1222,33 @@ def test_ray_tree_overflow_retries_with_fewer_paths(xrt, monkeypatch):
     for k in ("rays_closest", "rays_shadow", "shaded_hits", "pixels"):
         assert tracer2.last_stats[k] == st_want[k], (k, tracer2.last_stats[k], st_want[k])
     assert tracer2.last_stats["intersect_launches"] > st_want["intersect_launches"], "no chunk was split"
+    assert np.array_equal(tracer2.Render(), want)   # (the scene's later ray-tree frames go the careful way from the start)
+    # A ray-tree frame of one chunk is enqueued optimistically, without a host round trip, so that two can be in flight; one that
+    # overflows is rendered again when it is waited for.  Two such frames in flight, HBM and host output:
+    import torch
+    monkeypatch.setenv("XRT_HEAP_RAY_CAP", "1024")
+    scene3, tracer3 = xrt.configs.build_product(spec)
+    scene4, tracer4 = xrt.configs.build_product(spec)
+    monkeypatch.delenv("XRT_HEAP_RAY_CAP")
+    n = spec.width * spec.height
+    outs = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(2)]
+    frs = [tracer3.PrepareDevice(o.data_ptr()) for o in outs]
+    t0, t1 = frs[0].begin(), frs[1].begin()
+    st0 = frs[0].end(t0)
+    st1 = frs[1].end(t1)
+    for o, st in zip(outs, (st0, st1)):
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), want)
+        assert st["rays_closest"] == st_want["rays_closest"] and st["shaded_hits"] == st_want["shaded_hits"]
+    bufs = [np.zeros(n, dtype=np.uint32) for _ in range(2)]
+    hfr = [tracer4.PrepareHost(b) for b in bufs]
+    t0, t1 = hfr[0].begin(), hfr[1].begin()
+    hfr[0].end(t0); hfr[1].end(t1)
+    assert np.array_equal(bufs[0], want) and np.array_equal(bufs[1], want)
+    # and with room to spare two optimistic frames in flight are simply the frame, twice
+    frs = [tracer.PrepareDevice(o.data_ptr()) for o in outs]
+    for o in outs:
+        o.zero_()
+    torch.cuda.synchronize()
+    t0, t1 = frs[0].begin(), frs[1].begin()
+    frs[0].end(t0); frs[1].end(t1)
+    assert np.array_equal(outs[0].cpu().numpy().view(np.uint32), want) and np.array_equal(outs[1].cpu().numpy().view(np.uint32), want)

@@ -129,8 +129,17 @@ struct StampFold {
     unsigned long long *host = nullptr;
     int row0 = 0, row1 = 0;
 };
+// Frame epilogue of a single-chunk frame (block 0 of the compose kernel): the first cntWords ray counters -- and, for a ray-tree
+// frame, the word that says a generation overflowed its buffers, as hostCnt[cntWords] -- go to host-visible memory, and zeroWords
+// counter / queue words and that flag are cleared for the next frame: no copy or fill commands on the stream
+struct FrameEpilogue {
+    int *cntSrc = nullptr;
+    int *hostCnt = nullptr;
+    int cntWords = 0, zeroWords = 0;
+    int *flagSrc = nullptr;
+};
 void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections, uint32_t *sampleColor,
-                         float *sampleF32, const StampFold &stamps, hipStream_t st);
+                         float *sampleF32, const StampFold &stamps, const FrameEpilogue &epilogue, hipStream_t st);
 // compose can write the framebuffer itself when there is one sample per pixel
 struct ResolveArgs {
     int fused;

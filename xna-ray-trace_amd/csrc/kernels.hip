@@ -912,6 +912,18 @@ void launch_shade(const SceneView &S, const ShadeView &V, const ShadeArgs &X, hi
     hipLaunchKernelGGL(k_shade, dim3(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks)), dim3(APPEND_BLOCK), 0, st, S, V, X);
 }
 
+// Frame epilogue (kernels.h FrameEpilogue): every kernel that counts rays has finished -- hand the counters to the host, clear them
+__device__ __forceinline__ void frame_epilogue(const FrameEpilogue &E) {
+    if (E.cntSrc && blockIdx.x == 0) {
+        for (int i = (int)threadIdx.x; i < E.zeroWords; i += (int)blockDim.x) {
+            const int v = E.cntSrc[i];
+            if (i < E.cntWords) E.hostCnt[i] = v;
+            E.cntSrc[i] = 0;
+        }
+        if (E.flagSrc && threadIdx.x == 0) { E.hostCnt[E.cntWords] = *E.flagSrc; *E.flagSrc = 0; }
+        __threadfence_system();
+    }
+}
 // Frame epilogue: (start, latest wave end) of traversal launches row0 .. row1-1 go to host-visible memory, one block per launch
 // where the grid has them (block 0 is busy with the counters).  All threads of every block call it.
 __device__ __forceinline__ void fold_stamps(const StampFold &F) {
@@ -942,13 +954,10 @@ __device__ __forceinline__ void fold_stamps(const StampFold &F) {
 // The return path of the CastRay recursion: deepest generation first, one RGBA8 quantisation per level.
 __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32,
                                                  ResolveArgs RA) {
-    if (RA.cntSrc && blockIdx.x == 0) {   // every kernel that counts rays has finished: hand the counters to the host, clear them
-        for (int i = (int)threadIdx.x; i < RA.zeroWords; i += (int)blockDim.x) {
-            const int v = RA.cntSrc[i];
-            if (i < RA.cntWords) RA.hostCnt[i] = v;
-            RA.cntSrc[i] = 0;
-        }
-        __threadfence_system();
+    {
+        FrameEpilogue E;
+        E.cntSrc = RA.cntSrc; E.hostCnt = RA.hostCnt; E.cntWords = RA.cntWords; E.zeroWords = RA.zeroWords;
+        frame_epilogue(E);
     }
     fold_stamps(RA.stamps);
     const int sshift = RA.g.samples == 16 ? 4 : (RA.g.samples == 4 ? 2 : 0);
@@ -998,8 +1007,9 @@ __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB,
 // The same return path over the binary ray tree of a scene with Transparent materials (RT:586-702): node i has
 // its reflection at 2i+1 and its refraction at 2i+2; evaluated depth first like the recursion itself.
 __global__ __launch_bounds__(256) void k_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections,
-                                                      uint32_t *sampleColor, float *sampleF32, StampFold stamps) {
+                                                      uint32_t *sampleColor, float *sampleF32, StampFold stamps, FrameEpilogue epilogue) {
     constexpr int MAXD = 14;
+    frame_epilogue(epilogue);
     fold_stamps(stamps);
     for (int p = (int)(blockIdx.x * blockDim.x + threadIdx.x); p < count; p += (int)(gridDim.x * blockDim.x)) {
         int stNode[MAXD], stPhase[MAXD];
@@ -1050,11 +1060,11 @@ __global__ __launch_bounds__(256) void k_compose_tree(const f4 *lvlA, const f4 *
     }
 }
 void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections, uint32_t *sampleColor,
-                         float *sampleF32, const StampFold &stamps, hipStream_t st) {
+                         float *sampleF32, const StampFold &stamps, const FrameEpilogue &epilogue, hipStream_t st) {
     int blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_compose_tree, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, lvlA, lvlB, lvlAlpha, count, P, maxReflections, sampleColor, sampleF32,
-                       stamps);
+                       stamps, epilogue);
 }
 void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32,
                     const ResolveArgs &RA, hipStream_t st, hipEvent_t stopEvent) {

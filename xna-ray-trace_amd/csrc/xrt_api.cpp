@@ -157,8 +157,6 @@ struct xrt_scene {
     // per-frame work buffers
     DevBuf<xrt_ray> apiRays;
     DevBuf<xrt_hit> apiHits;
-    DevBuf<int> node0, node1;           // ray-tree frames only (they run alone)
-    DevBuf<float> ref0, ref1, lvlAlpha;
     DevBuf<unsigned> queues;
     DevBuf<uint32_t> outRGBA;
     DevBuf<float> outF32;
@@ -169,6 +167,8 @@ struct xrt_scene {
         DevBuf<xrt_ray> rays0, rays1, shadowRays;
         DevBuf<xrt_hit> hits, hits1, shadowHits;
         DevBuf<int> path0, path1, index0, heavyList, cnts;
+        DevBuf<int> node0, node1, heapFlag;     // ray-tree frames: heap node of every ray; heapFlag[0]: a generation overflowed its buffers
+        DevBuf<float> ref0, ref1, lvlAlpha;     // ... refraction index of the medium a ray travels in; alpha per level record
         DevBuf<int> hitFlags0, hitFlags1, shadowFlags;   // hit / miss word per ray of hits, hits1, shadowHits (a miss has no record)
         DevBuf<unsigned long long> stamps;      // device-clock stamps of the traversal launches (device_util.h), STAMP_STRIDE per launch
         DevBuf<SlotRec> slot0, slot1;
@@ -176,6 +176,7 @@ struct xrt_scene {
         DevBuf<uint32_t> sampleColor;
         DevBuf<float> sampleF32;
         DevBuf<LightRec> lights;
+        bool heapFlagClean = false;
         bool cntsClean = false;                 // cnts is all zero (the previous frame's epilogue cleared what it counted)
         std::vector<LightRec> lightsOnDevice;   // what `lights` holds
         const void *lightsDevPtr = nullptr;
@@ -183,7 +184,8 @@ struct xrt_scene {
         hipStream_t lastStream = nullptr;       // the stream the context's last frame ran on
         void release() {
             rays0.release(); rays1.release(); shadowRays.release(); hits.release(); hits1.release(); shadowHits.release();
-            path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); stamps.release(); hitFlags0.release(); hitFlags1.release(); shadowFlags.release(); slot0.release(); slot1.release();
+            path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); stamps.release(); hitFlags0.release(); hitFlags1.release(); shadowFlags.release();
+            node0.release(); node1.release(); heapFlag.release(); ref0.release(); ref1.release(); lvlAlpha.release(); slot0.release(); slot1.release();
             lvlA.release(); lvlB.release(); sampleColor.release(); sampleF32.release(); lights.release();
             if (stream) (void)hipStreamDestroy(stream);
             stream = nullptr;
@@ -214,6 +216,9 @@ struct xrt_scene {
         bool fast = false;           // no copy / fill / event-record commands: k_compose hands the counters over, events ride on kernels
         int *pinnedDev = nullptr;    // device view of `pinned`
         long long framePaths = 0;    // paths of the frame (part) this context holds: key of the grid hints
+        bool heap = false, redone = false;   // a ray-tree frame; ... that overflowed on the optimistic way and was rendered again
+        xrt_camera redoCam; xrt_render_opts redoOpts; std::vector<xrt_light> redoLights;
+        uint32_t *redoOut = nullptr; float *redoOutF32 = nullptr; hipStream_t redoSt = nullptr;
         int stampRows = 0;           // traversal launches of the frame that timed themselves (device_util.h)
         unsigned long long *stampHost = nullptr, *stampHostDev = nullptr;   // their (start, end) clock pairs: mapped pinned memory and its device view
         // deferred accounting
@@ -237,6 +242,7 @@ struct xrt_scene {
     int splitMode = 0, splitParts = 2;
     bool launchEvents = false;   // XRT_LAUNCH_EVENTS=1: single-chunk frames time their traversal launches with events on the dispatch packets, too
     int maxStampRows = MAX_STAMP_ROWS;   // XRT_STAMP_ROWS=<n> (tests): launches of a frame beyond the n-th carry events instead
+    bool heapFastOk = true;      // single-chunk ray-tree frames go the optimistic way (no host round trip) until one overflows; XRT_HEAP_FAST=0
     bool noGridHints = false;    // XRT_GRID_HINTS=0: every launch is sized for the whole chip
     bool noLaunchTiming = false; // XRT_LAUNCH_TIMING=0: single-chunk frames do not time their traversal launches (xrt_stats.ms_intersect = 0)
     int wallClockKHz = 0;        // rate of the device clock the launches stamp (hipDeviceAttributeWallClockRate)
@@ -259,7 +265,7 @@ struct xrt_scene {
     DevBuf<uint32_t> frameOut[2];    // W*H frame of a host-output ticket
     hipEvent_t tilesReady[2] = {nullptr, nullptr};   // replica (fake mode): its tiles are rendered
     hipEvent_t tailDone[2] = {nullptr, nullptr};     // primary: gather + de-tile + host copy of the ticket are done
-    struct OpenFrame { int nGpus = 0, nParts = 1; bool tail = false; } open[2];
+    struct OpenFrame { int nGpus = 0, nParts = 1; bool tail = false; uint32_t *hostOut = nullptr, *devOut = nullptr; size_t px = 0; hipStream_t st0 = nullptr; } open[2];
     std::mutex apiMutex;
     std::unordered_map<hipStream_t, int> queueOfStream;
     // development switches, read once at xrt_scene_create (never per frame)
@@ -284,7 +290,7 @@ struct xrt_scene {
             childDfs.release(); srefs.release(); objMesh.release(); meshes.release();
             objects.release(); materials.release(); texels.release();
             apiRays.release(); apiHits.release();
-            node0.release(); node1.release(); ref0.release(); ref1.release(); lvlAlpha.release();
+
             queues.release(); outRGBA.release(); outF32.release(); counters.release(); costMap.release(); waveTimes.release();
         }
     }
@@ -432,7 +438,7 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats);
 // frame_finish waits for them.  Adaptive supersampling and ray-tree frames need host decisions between their passes and
 // are complete when this returns.
 int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts,
-                uint32_t *d_out, float *d_outF32, hipStream_t st, int part = 0, int nParts = 1) {
+                uint32_t *d_out, float *d_outF32, hipStream_t st, int part = 0, int nParts = 1, bool heapFastAllowed = true) {
     const bool stats = true;   // the read-back is two small pinned copies; always taken
     xrt_scene::WorkBufs &W = F.w;
     if (!cam || !opts || (!lights && nLights > 0) || nLights < 0) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
@@ -508,8 +514,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         if ((rc = s->waveTimes.ensure((size_t)16 * 3 * 8192))) return rc;
         HIPCHECK(hipMemset(s->waveTimes.p, 0, (size_t)16 * 3 * 8192 * sizeof(unsigned long long)));
     }
-    if (heap && ((rc = s->node0.ensure(rayCap)) || (rc = s->node1.ensure(rayCap)) || (rc = s->ref0.ensure(rayCap)) || (rc = s->ref1.ensure(rayCap)) ||
-                 (rc = s->lvlAlpha.ensure((size_t)P * nodes))))
+    if (heap && ((rc = W.node0.ensure(rayCap)) || (rc = W.node1.ensure(rayCap)) || (rc = W.ref0.ensure(rayCap)) || (rc = W.ref1.ensure(rayCap)) ||
+                 (rc = W.lvlAlpha.ensure((size_t)P * nodes))))
         return rc;
     if (wantF32 && (rc = W.sampleF32.ensure((size_t)P * 3))) return rc;
     const int cntStride = 3 * (R + 2);          // per chunk: cnt[R+2], scnt[R+2], then the long-ray list lengths [R+2]
@@ -517,8 +523,19 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const int qStride = QW * (R + 2);
     // The common frame (one chunk, no supersampling levels, no ray tree, no counting pass) puts nothing but its kernels
     // on the stream: counters come back through k_compose's epilogue and the frame's events ride on raygen / compose.
-    const bool fast = !adaptive && !heap && firstPaths <= chunkPaths && !opts->collect_stats;
+    // ... and so does a ray-tree frame of one chunk: its buffers are sized optimistically, so the frame carries a word that says
+    // "a generation did not fit"; frame_finish then renders it again the careful way (chunks, checks, retries) and the scene's later
+    // ray-tree frames take that way from the start.  Not where something is enqueued behind the frame that a redo cannot recall
+    // (the in-library gather of n_gpus > 1).
+    const bool heapFast = heap && heapFastAllowed && s->heapFastOk && nParts == 1;
+    const bool fast = !adaptive && (!heap || heapFast) && firstPaths <= chunkPaths && !opts->collect_stats;
     F.fast = fast;
+    F.heap = heap;
+    F.redone = false;
+    if (heapFast && fast) {   // what a redo needs
+        F.redoCam = *cam; F.redoOpts = *opts; F.redoLights.assign(lights, lights + nLights);
+        F.redoOut = d_out; F.redoOutF32 = d_outF32; F.redoSt = st;
+    }
     F.framePaths = nParts == 1 ? firstPaths : -1;
     // the traversal launches time themselves on the device clock instead of carrying events (device_util.h); a frame of more
     // than MAX_STAMP_ROWS launches (many chunks or supersampling levels) goes on with events
@@ -546,7 +563,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // rays of later generations
     const int pkMask = (s->packetOk && !heap) ? (s->packetMask >= 0 ? s->packetMask : (g.samples >= 16 ? 7 : 0)) : 0;
     const bool laneClosest = (pkMask & 5) != 5;   // some closest-hit generation is traced ray by ray: the long-ray feedback has a reader
-    const bool wantFeedback = fast && s->deepMeshes && !s->noFeedback && laneClosest;
+    const bool wantFeedback = fast && !heap && s->deepMeshes && !s->noFeedback && laneClosest;
     {   // The other context's frame may still be running on another stream.  Two single-chunk frames share nothing they
         // write except scheduling hints; anything else (counting pass, supersampling levels, ray tree, a cost map
         // about to be reallocated or released) runs alone.
@@ -589,8 +606,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const SceneView &S = s->view;
     xrt_ray *rays[2] = {W.rays0.p, W.rays1.p};
     int *paths[2] = {W.path0.p, W.path1.p};
-    int *nodesOf[2] = {s->node0.p, s->node1.p};
-    float *refOf[2] = {s->ref0.p, s->ref1.p};
+    int *nodesOf[2] = {W.node0.p, W.node1.p};
+    float *refOf[2] = {W.ref0.p, W.ref1.p};
     size_t &ev = F.ev;
     ev = 0;
     std::vector<std::pair<size_t, size_t>> &pairs = F.pairs;
@@ -607,7 +624,14 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     F.tallyChunks = 0; F.cntStride = cntStride; F.R = R; F.nL = nL; F.collect = opts->collect_stats != 0;
 
     // One pass = trace `total` paths produced by generator `gp`; after every chunk `post(Pc, pathBase)` consumes sampleColor.
-    int *overflowFlag = reinterpret_cast<int *>(s->counters.p + 2 * C_COUNT) + 12;   // spare counter words (zeroed above)
+    // "a generation did not fit its buffers": ray-tree frames have the word to themselves (two of them may be in flight)
+    if (heap) {
+        const bool fresh = W.heapFlag.p == nullptr;
+        if ((rc = W.heapFlag.ensure(16))) return rc;
+        if (fresh || !fast || !W.heapFlagClean) HIPCHECK(hipMemsetAsync(W.heapFlag.p, 0, 16 * sizeof(int), st));
+        W.heapFlagClean = fast;   // (the frame epilogue clears it again)
+    }
+    int *overflowFlag = heap ? W.heapFlag.p : reinterpret_cast<int *>(s->counters.p + 2 * C_COUNT) + 12;   // (else: a spare counter word, never set)
 
     // Enqueue one chunk of `Pc` paths starting at `pathBase`: raygen, R+2 rounds of (intersect, shade), compose.
     // Intersect launch #k traces the closest-hit rays of generation k together with the shadow rays of generation k-1
@@ -704,7 +728,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             X.nextRays = rays[prv]; X.nextPath = paths[prv]; X.nextNode = heap ? nodesOf[prv] : nullptr; X.nextRef = heap ? refOf[prv] : nullptr;
             X.nextCnt = cnt + k + 1; X.nextCap = (int)rayCap;
             X.hitsPrev = hitsOf[prv]; X.slotPrev = slotOf[prv]; X.scntPrev = k >= 1 ? scnt + (k - 1) : nullptr; X.shadowHits = W.shadowHits.p;
-            X.lvlA = W.lvlA.p; X.lvlB = W.lvlB.p; X.lvlAlpha = heap ? s->lvlAlpha.p : nullptr;
+            X.lvlA = W.lvlA.p; X.lvlB = W.lvlB.p; X.lvlAlpha = heap ? W.lvlAlpha.p : nullptr;
             if (k < R) X.heavy = heavy_for(k + 1);
             if (feedback && hasClosest && !packet_closest(k)) { X.costOut = s->costMap.p + (size_t)k * (size_t)framePaths + (size_t)partStart; X.epoch = s->epoch & 0xffffu; }
             { const long long h = hint(s->genShade, k); launch_shade(S, V, X, st, h < 0 ? 1024 : (int)((h + 1023) / 1024 < 1024 ? (h + 1023) / 1024 : 1024)); }
@@ -712,7 +736,11 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         Range rc_("xrt compose");
         StampFold fold;
         fold.src = W.stamps.p; fold.host = F.stampHostDev; fold.row0 = chunkRow0; fold.row1 = F.stampRows;
-        if (heap) launch_compose_tree(W.lvlA.p, W.lvlB.p, s->lvlAlpha.p, Pc, P, R, W.sampleColor.p, wantF32 ? W.sampleF32.p : nullptr, fold, st);
+        if (heap) {
+            FrameEpilogue E;
+            if (fast) { E.cntSrc = cnt; E.hostCnt = F.pinnedDev; E.cntWords = cntStride; E.zeroWords = cntStride + qStride; E.flagSrc = overflowFlag; }
+            launch_compose_tree(W.lvlA.p, W.lvlB.p, W.lvlAlpha.p, Pc, P, R, W.sampleColor.p, wantF32 ? W.sampleF32.p : nullptr, fold, E, st);
+        }
         else {
             ResolveArgs RA;
             RA.fused = fuseResolve ? 1 : 0; RA.g = gp; RA.pixelBase = pathBase; RA.out = d_out; RA.outF32 = d_outF32;
@@ -747,10 +775,11 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     auto run_pass = [&](const RayGenParams &gp, long long total, auto &&post, float progress0, float progress1, bool finalPass) -> int {
         int rc2;
         const size_t nb2 = 2 * C_COUNT * sizeof(unsigned long long);
-        if (heap) {
-            // ray-tree mode: one chunk at a time, checked for overflow, retried with fewer paths when a generation did not fit
+        if (heap && !fast) {
+            // ray-tree mode, the careful way: one chunk at a time, checked for overflow, retried with fewer paths when a generation did not fit
             const size_t words = (size_t)cntStride + (size_t)qStride;
-            if ((rc2 = W.cnts.ensure(words)) || (rc2 = ensure_pinned(words * sizeof(int) + nb2 + 64 + 8))) return rc2;
+            if ((rc2 = W.cnts.ensure(words)) || (rc2 = ensure_pinned(words * sizeof(int) + nb2 + 64 + 8 + 64))) return rc2;
+            W.cntsClean = false;
             unsigned *q = reinterpret_cast<unsigned *>(W.cnts.p + cntStride);
             long long pathBase = 0, curChunk = chunkPaths;   // (ray-tree frames are never split: partStart == 0)
             while (pathBase < total) {
@@ -764,9 +793,10 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 char *pin = (char *)F.pinned;
                 const size_t cAt = ((size_t)cntStride * sizeof(int) + 7) & ~(size_t)7;   // counters + spare words (overflow flag) in one copy
                 HIPCHECK(hipMemcpyAsync(pin, W.cnts.p, (size_t)cntStride * sizeof(int), hipMemcpyDeviceToHost, st));
-                HIPCHECK(hipMemcpyAsync(pin + cAt, s->counters.p, nb2 + 64, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipMemcpyAsync(pin + cAt, s->counters.p, nb2, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipMemcpyAsync(pin + cAt + nb2 + 64, overflowFlag, sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCHECK(hipStreamSynchronize(st));
-                const int over = *(const int *)(pin + cAt + nb2 + 12 * sizeof(int));
+                const int over = *(const int *)(pin + cAt + nb2 + 64);
                 if (over) {
                     if (curChunk <= 64) return fail(XRT_E_UNSUPPORTED, "the ray tree of 64 paths does not fit the ray buffers (MaxReflections too high for this scene)");
                     curChunk = (curChunk / 4) & ~63LL;
@@ -791,7 +821,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         const int *cntsBefore = W.cnts.p;
         if ((rc2 = W.cnts.ensure(cntWords + qWords))) return rc2;
         unsigned *queuesBase = reinterpret_cast<unsigned *>(W.cnts.p + cntWords);
-        if (fast && (rc2 = ensure_pinned(cntWords * sizeof(int)))) return rc2;
+        if (fast && (rc2 = ensure_pinned(cntWords * sizeof(int) + 64))) return rc2;   // (+ the overflow word of a ray-tree frame)
         if (!fast || !W.cntsClean || W.cnts.p != cntsBefore) HIPCHECK(hipMemsetAsync(W.cnts.p, 0, W.cnts.cap * sizeof(int), st));
         W.cntsClean = false;
         for (int c = 0; c < nChunks; c++) {
@@ -917,13 +947,27 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
         if (FILE *f = fopen(s->stampDumpPath.c_str(), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
     }
     const int R = F.R;
+    if (F.fast && F.heap && F.tallyChunks == 1 && ((const int *)F.pinned)[F.cntStride] != 0) {
+        // A generation of the ray tree did not fit the optimistically sized buffers: the frame is rendered again the careful way
+        // (chunks, overflow checks, retries with fewer paths), and so are this scene's later ray-tree frames from the start.
+        s->heapFastOk = false;
+        F.tallyChunks = 0;
+        const std::vector<xrt_light> lights = F.redoLights;
+        const xrt_camera cam = F.redoCam;
+        const xrt_render_opts opts = F.redoOpts;
+        int rc = frame_begin(s, F, &cam, lights.data(), (int)lights.size(), &opts, F.redoOut, F.redoOutF32, F.redoSt);
+        if (rc != XRT_OK) return rc;
+        rc = frame_finish(s, F, stats);
+        F.redone = true;
+        return rc;
+    }
     if (F.tallyChunks > 0) {   // single-pass frame: the read-back was left in flight
         const size_t nb = (size_t)F.tallyChunks * F.cntStride * sizeof(int);
         for (int c = 0; c < F.tallyChunks; c++) {
             const int *hc = (const int *)F.pinned + (size_t)c * F.cntStride;
             for (int k = 0; k <= R; k++) {
                 F.shaded += (unsigned long long)hc[(R + 2) + k];
-                if (k > 0) F.closestDeep += (unsigned long long)hc[(R + 2) + k - 1];   // single-pass frames have no ray tree
+                if (k > 0) F.closestDeep += (unsigned long long)(F.heap ? hc[k] : hc[(R + 2) + k - 1]);   // reflection chain: one ray per parent hit
                 else F.live0 += (unsigned long long)hc[0];
             }
         }
@@ -931,7 +975,7 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
         if (F.fast && F.tallyChunks == 1) {   // sizes of this frame's generations: grid hints for the next one (sizing only)
             const int *hc = (const int *)F.pinned;
             for (int k = 0; k <= R + 1 && k < 68; k++) {
-                const long long closest = k == 0 ? hc[0] : (k <= R ? hc[(R + 2) + k - 1] : 0), shaded = k >= 1 ? hc[(R + 2) + k - 1] : 0;
+                const long long closest = (k == 0 || (F.heap && k <= R)) ? hc[k] : (k <= R ? hc[(R + 2) + k - 1] : 0), shaded = k >= 1 ? hc[(R + 2) + k - 1] : 0;
                 s->genRays[k] = closest + shaded * F.nL;
                 s->genShade[k] = closest > shaded ? closest : shaded;
             }
@@ -1012,7 +1056,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) r->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (hipDeviceGetAttribute(&r->wallClockKHz, hipDeviceAttributeWallClockRate, r->device) != hipSuccess) { r->wallClockKHz = 0; (void)hipGetLastError(); }
-        r->launchEvents = s->launchEvents; r->noLaunchTiming = s->noLaunchTiming; r->noGridHints = s->noGridHints; r->maxStampRows = s->maxStampRows;
+        r->launchEvents = s->launchEvents; r->noLaunchTiming = s->noLaunchTiming; r->noGridHints = s->noGridHints; r->heapFastOk = s->heapFastOk; r->maxStampRows = s->maxStampRows;
         HIPCHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
         int rc = scene_upload(r.get());
         if (rc != XRT_OK) return rc;
@@ -1068,7 +1112,7 @@ int multi_begin(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *
         xrt_render_opts o = *opts;
         o.n_gpus = 0; o.shard_rank = i; o.shard_count = n;
         uint32_t *dst = i == 0 ? s->gathered[slot].p : r->tileOut[slot].p;
-        rcs[(size_t)i] = frame_begin(r, r->frames[slot], cam, lights, nLights, &o, dst, nullptr, nullptr);
+        rcs[(size_t)i] = frame_begin(r, r->frames[slot], cam, lights, nLights, &o, dst, nullptr, nullptr, 0, 1, false);   // (the gather is enqueued behind the frame: no redo)
         if (rcs[(size_t)i] != XRT_OK) errs[(size_t)i] = g_err;
     };
     {
@@ -1186,6 +1230,7 @@ int open_frame(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *l
     O.nGpus = n;
     O.nParts = nParts;
     O.tail = n > 1 || host_out != nullptr;
+    O.hostOut = host_out; O.devOut = d_out; O.px = px; O.st0 = st0;
     if (O.tail) {   // work enqueued behind the frame's own kernels: its end is an event of its own
         for (int j = 1; j < nParts; j++) {   // (the other half ends with an event on its last kernel)
             xrt_scene::FrameCtx &Fj = s->frames[slot + 2 * j];
@@ -1202,7 +1247,15 @@ int close_frame(xrt_scene *s, int slot, xrt_stats *stats) {
     xrt_scene::OpenFrame &O = s->open[slot];
     int rc = XRT_OK;
     if (O.nGpus > 1) rc = multi_end(s, slot, O.nGpus, stats);
-    else if (O.nParts <= 1) rc = frame_finish(s, s->frames[slot], stats);
+    else if (O.nParts <= 1) {
+        rc = frame_finish(s, s->frames[slot], stats);
+        if (rc == XRT_OK && s->frames[slot].redone && O.tail && O.hostOut && O.px) {   // the copy enqueued behind the first attempt took the wrong pixels
+            hipError_t e = hipEventSynchronize(s->tailDone[slot]);
+            if (e == hipSuccess) e = hipMemcpyAsync(O.hostOut, O.devOut, O.px * sizeof(uint32_t), hipMemcpyDeviceToHost, s->frames[slot].w.lastStream);
+            if (e == hipSuccess) e = hipEventRecord(s->tailDone[slot], s->frames[slot].w.lastStream);
+            if (e != hipSuccess) rc = fail(XRT_E_HIP, "redo of a ray-tree frame: %s", hipGetErrorString(e));
+        }
+    }
     else {
         xrt_stats acc;
         std::memset(&acc, 0, sizeof(acc));
@@ -1383,6 +1436,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 31) s->packetMask = v; }
     if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
     if (const char *e = getenv("XRT_LAUNCH_EVENTS")) s->launchEvents = atoi(e) != 0;
+    if (const char *e = getenv("XRT_HEAP_FAST")) s->heapFastOk = atoi(e) != 0;
     if (const char *e = getenv("XRT_GRID_HINTS")) s->noGridHints = atoi(e) == 0;
     if (const char *e = getenv("XRT_STAMP_ROWS")) { const int v = atoi(e); if (v >= 0 && v <= MAX_STAMP_ROWS) s->maxStampRows = v; }
     if (const char *e = getenv("XRT_LAUNCH_TIMING")) s->noLaunchTiming = atoi(e) == 0;
