@@ -285,8 +285,9 @@ int xrt_render_device(xrt_scene *scene, const xrt_camera *camera, const xrt_ligh
  * on a stream of its own and the two frames also overlap ON the GPU: a launch of persistent waves leaves the machine
  * half empty while its last rays finish, and the other frame's kernels fill it (a given stream serialises them
  * instead).  d_rgba_out of a frame is complete when its _end returns; give the two frames in flight different output
- * buffers.  Frames that need host decisions between passes (adaptive supersampling, Transparent materials, more than
- * one chunk) finish inside _begin and never overlap another frame.  While a ticket is open every other call that renders
+ * buffers.  Frames that need host decisions between passes (adaptive supersampling, more than one chunk) finish inside
+ * _begin and never overlap another frame; a frame with Transparent materials (a ray tree per pixel) of one chunk is enqueued
+ * like a plain frame with optimistically sized ray buffers and, should a generation not fit, rendered again inside _end.  While a ticket is open every other call that renders
  * or mutates the scene returns XRT_E_BUSY. */
 int xrt_render_device_begin(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights,
                             int32_t n_lights, const xrt_render_opts *opts, void *d_rgba_out, void *stream,
