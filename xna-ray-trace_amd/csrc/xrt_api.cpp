@@ -435,8 +435,8 @@ int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g
 int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats);
 
 // Enqueues one frame on `st`.  On return the frame's kernels and its counter read-back are in flight (F.pending);
-// frame_finish waits for them.  Adaptive supersampling and ray-tree frames of several chunks need host decisions between their
-// passes and are complete when this returns; a ray-tree frame of one chunk is enqueued optimistically (F.heap && F.fast).
+// frame_finish waits for them.  Adaptive supersampling and ray-tree frames need host decisions between their passes and
+// are complete when this returns.
 int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts,
                 uint32_t *d_out, float *d_outF32, hipStream_t st, int part = 0, int nParts = 1, bool heapFastAllowed = true) {
     const bool stats = true;   // the read-back is two small pinned copies; always taken
