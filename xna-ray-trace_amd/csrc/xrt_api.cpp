@@ -332,10 +332,10 @@ hipEvent_t get_event(std::vector<hipEvent_t> &pool, size_t i) {
 }
 hipEvent_t get_event(xrt_scene *s, size_t i) { return get_event(s->events, i); }
 
-int persistent_grid(xrt_scene *s, long long nHost) {
+int persistent_grid(xrt_scene *s, long long nHost, int raysPerBlock = 256) {
     int full = s->numCUs * s->blocksPerCU;
     if (nHost >= 0) {
-        long long want = (nHost + 255) / 256;   // one block covers >= 256 rays
+        long long want = (nHost + raysPerBlock - 1) / raysPerBlock;   // one block covers >= 256 rays (16 for a guessed size: small launches are spread thin)
         if (want < 1) want = 1;
         if (want < full) return (int)want;
     }
@@ -704,7 +704,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 if (laneC && laneB) { A.rays2 = B.rays; A.hits2 = B.hits; A.flags2 = B.flags; A.nDev2 = B.nDev; A.nMul2 = B.nMul; A.nCap2 = B.nCap; }
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
-                const int grid = persistent_grid(s, k == 0 ? Pc : hint(s->genRays, k));
+                const int grid = k == 0 ? persistent_grid(s, Pc) : persistent_grid(s, hint(s->genRays, k), 16);
                 if (useStamps && grid * 4 <= STAMP_SLOTS && F.stampRows < s->maxStampRows) { A.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
                 else if (s->noLaunchTiming) a0 = a1 = nullptr;
                 else { pairs.push_back({ev, ev + 1}); ev += 2; }
@@ -976,8 +976,13 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
             const int *hc = (const int *)F.pinned;
             for (int k = 0; k <= R + 1 && k < 68; k++) {
                 const long long closest = (k == 0 || (F.heap && k <= R)) ? hc[k] : (k <= R ? hc[(R + 2) + k - 1] : 0), shaded = k >= 1 ? hc[(R + 2) + k - 1] : 0;
-                s->genRays[k] = closest + shaded * F.nL;
-                s->genShade[k] = closest > shaded ? closest : shaded;
+                // (a hint shrinks by an eighth per frame at most: a camera that looks away for a frame, or alternates between two views,
+                // must not leave the next full view with a grid of sixteen blocks)
+                const bool same = s->genKey == F.framePaths * 64 + F.nL;
+                const long long rays = closest + shaded * F.nL, work = closest > shaded ? closest : shaded;
+                const long long keepR = same && s->genRays[k] > 0 ? s->genRays[k] - s->genRays[k] / 8 : 0, keepS = same && s->genShade[k] > 0 ? s->genShade[k] - s->genShade[k] / 8 : 0;
+                s->genRays[k] = rays > keepR ? rays : keepR;
+                s->genShade[k] = work > keepS ? work : keepS;
             }
             for (int k = R + 2; k < 68; k++) s->genRays[k] = s->genShade[k] = -1;
             s->genKey = F.framePaths * 64 + F.nL;
