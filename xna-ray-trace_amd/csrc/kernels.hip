@@ -908,8 +908,10 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
         }
     }
 }
-void launch_shade(const SceneView &S, const ShadeView &V, const ShadeArgs &X, hipStream_t st, int blocks) {
-    hipLaunchKernelGGL(k_shade, dim3(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks)), dim3(APPEND_BLOCK), 0, st, S, V, X);
+void launch_shade(const SceneView &S, const ShadeView &V, const ShadeArgs &X, hipStream_t st, int blocks, int threads) {
+    if (threads != 256) threads = APPEND_BLOCK;   // 256-thread blocks spread a small generation over the CUs (block_append takes any block of whole waves)
+    const int cap = threads == 256 ? 4096 : 1024;
+    hipLaunchKernelGGL(k_shade, dim3(blocks < 1 ? 1 : (blocks > cap ? cap : blocks)), dim3(threads), 0, st, S, V, X);
 }
 
 // Frame epilogue (kernels.h FrameEpilogue): every kernel that counts rays has finished -- hand the counters to the host, clear them

@@ -731,7 +731,11 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             X.lvlA = W.lvlA.p; X.lvlB = W.lvlB.p; X.lvlAlpha = heap ? W.lvlAlpha.p : nullptr;
             if (k < R) X.heavy = heavy_for(k + 1);
             if (feedback && hasClosest && !packet_closest(k)) { X.costOut = s->costMap.p + (size_t)k * (size_t)framePaths + (size_t)partStart; X.epoch = s->epoch & 0xffffu; }
-            { const long long h = hint(s->genShade, k); launch_shade(S, V, X, st, h < 0 ? 1024 : (int)((h + 1023) / 1024 < 1024 ? (h + 1023) / 1024 : 1024)); }
+            {   // (a small generation: 256-thread blocks, so that its work items land on many CUs instead of on the first few)
+                const long long h = hint(s->genShade, k);
+                if (h >= 0 && h < 4 * 131072 + 4096) launch_shade(S, V, X, st, (int)((h + 255) / 256), 256);
+                else launch_shade(S, V, X, st, h < 0 ? 1024 : (int)((h + 1023) / 1024 < 1024 ? (h + 1023) / 1024 : 1024));
+            }
         }
         Range rc_("xrt compose");
         StampFold fold;
