@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 # (= the 157.3 TFLOP/s vector peak, which counts a fused multiply-add as two; this path is built with contraction off)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 SCALAR_PEAK_TINST = 256 * 2.4e9 / 1e12   # one scalar-unit instruction per cycle per CU
-# what micro-benchmarks of nothing but independent instructions reach (tools/microbench/, profiles/r02_l/*_peak.txt): 0.94 scalar
+# what micro-benchmarks of nothing but independent instructions reach (tools/microbench/, profiles/r02_m/*_peak.txt): 0.94 scalar
 # instructions per cycle and CU, 0.44 wave64 VALU instructions per cycle and SIMD, both with eight waves per SIMD
 SCALAR_MEASURED_TINST = 256 * 2.238e9 / 1e12
 VALU_MEASURED_TLANEOPS = 70.0
