@@ -2,25 +2,5 @@
 # Scratch pad for one-off measurements on the GPU box (gpurun -- 'bash tools/scratch_experiment.sh'); rewritten per experiment.
 set -e -o pipefail
 cd $GRAFT_REPO_ROOT
-cat > /tmp/adapt.py <<'PY'
-import sys, time, importlib, torch
-sys.path.insert(0, '.')
-xrt = importlib.import_module("xna-ray-trace_amd")
-name, q = sys.argv[1], int(sys.argv[2])
-spec = xrt.configs.config(name)
-spec.multisampling, spec.multisample_quality = xrt.abi.MS_ADAPTIVE, q
-scene, tracer = xrt.configs.build_product(spec)
-out = torch.zeros(spec.width * spec.height, dtype=torch.int32, device="cuda")
-fr = tracer.PrepareDevice(out.data_ptr())
-for _ in range(3):
-    st = fr()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-N = 10
-for _ in range(N):
-    st = fr()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / N
-print("%s adaptive quality %d: %.3f ms per frame (gpu %.3f, traversal %.3f in %d launches)" % (name, q, dt * 1e3, st["ms_total"], st["ms_intersect"], st["intersect_launches"]))
-PY
-for m in -1 1 3 7; do echo XRT_PACKET=$m; XRT_PACKET=$m python /tmp/adapt.py C5_1spp 1; XRT_PACKET=$m python /tmp/adapt.py C5_1spp 2; done
+timeout -k 10 120 python tools/blocking.py C3 20 > /dev/null
+for c in C3 C4; do for v in "XRT_HEAVY_SPARSE=0" "XRT_HEAVY_SPARSE=1 XRT_HEAVY_SHIFT=1" "XRT_HEAVY_SPARSE=1 XRT_HEAVY_SHIFT=2" "XRT_HEAVY_SPARSE=1 XRT_HEAVY_SHIFT=3" "XRT_HEAVY_SPARSE=1 XRT_HEAVY_SHIFT=2 XRT_LONG_FRAC=6,12"; do echo $c $v; env $v timeout -k 10 200 python tools/blocking.py $c 30 | tail -1; done; done
