@@ -211,6 +211,28 @@ def test_no_light_many_lights_and_deep_chains(xrt, orc):
             assert st["intersect_launches"] >= 1 and st["ms_intersect"] > 0
 
 
+def test_host_written_in_c(xrt, tmp_path):
+    """A host in plain C99 (tests/c_host/c_host.c: include/xrt.h and libxrt.so, nothing else) loads a scene file, builds it and
+    renders the frame the Python binding renders -- the FFI path of the reference's C# host (csharp/XrtNative.cs), without Python."""
+    import subprocess
+    import ctypes as C
+    from util import build_c_host
+    exe = build_c_host()
+    for spec in (xrt.configs.config("C1"), xrt.configs.content_scene(96, 54)):
+        scene, tracer = xrt.configs.build_product(spec)
+        want = tracer.Render().copy()
+        path = str(tmp_path / (spec.name + ".xrts"))
+        scene.Save(path)
+        cam, opts, lights = tracer._camera_abi(), tracer._opts_abi(), tracer._lights_abi()
+        n = len(tracer.Lights)
+        with open(str(tmp_path / "frame.bin"), "wb") as f:
+            f.write(bytes(cam)); f.write(C.c_int32(n)); f.write(bytes(lights)[: n * C.sizeof(xrt.abi.xrt_light)]); f.write(bytes(opts))
+        out = str(tmp_path / "out.rgba")
+        r = subprocess.run([exe, path, str(tmp_path / "frame.bin"), out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert np.array_equal(np.fromfile(out, dtype=np.uint32), want), spec.name
+
+
 def test_golden_frames_on_gpu(xrt):
     for fname, spec in (("c1_rgba.npy", xrt.configs.config("C1")), ("c3_96x54_rgba.npy", xrt.configs.crate_grid_scene(96, 54)),
                         ("h224_48x27_ms16_rgba.npy", xrt.configs.heightfield_scene(48, 27, m=224, multisampling=xrt.abi.MS_FIXED16))):

@@ -27,6 +27,22 @@ def test_abi_exports_every_declared_symbol(xrt):
     assert lib.xrt_last_error() is not None
 
 
+def test_header_is_plain_c_and_the_c_host_builds(xrt, tmp_path):
+    """The boundary is a C ABI: include/xrt.h compiles as strict C99 (no C++, no torch types), and a host written in C against it
+    alone (tests/c_host/c_host.c) links with libxrt.so.  Without a GPU it stops at xrt_device_count, loudly."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "xrt.h"\nint main(void) { return (int)sizeof(xrt_hit) - 48; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", str(src)])
+    from util import build_c_host
+    exe = build_c_host()
+    n = C.c_int(0)
+    if xrt.abi.lib().xrt_device_count(C.byref(n)) != 0 or n.value < 1:
+        r = subprocess.run([exe, "none.xrts", "none.bin", str(tmp_path / "out.rgba")], capture_output=True, text=True)
+        assert r.returncode == 1 and "xrt_device_count" in r.stderr
+
+
 def test_no_cpu_fallback_and_error_codes(xrt):
     lib, abi = xrt.abi.lib(), xrt.abi
     h = C.c_void_p()

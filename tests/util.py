@@ -201,3 +201,15 @@ def tight_box_adversarial_rays(xrt, mesh, nodes, refs, n_leaves, per_leaf, seed)
         dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
         add(feat - dirs * diag * 10.0 ** rng.uniform(0, 4, size=(per_leaf, 1)), feat)
     return xrt.rays_array(np.concatenate(O).astype(np.float32), np.concatenate(D).astype(np.float32))
+
+
+def build_c_host():
+    """tests/c_host/c_host.c -> tests/c_host/c_host (plain C99 against include/xrt.h, linked with the in-tree libxrt.so)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src, exe = os.path.join(root, "tests", "c_host", "c_host.c"), os.path.join(root, "tests", "c_host", "c_host")
+    lib = os.path.join(root, "xna-ray-trace_amd", "csrc")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), src, "-L", lib, "-lxrt",
+                               "-Wl,-rpath," + lib, "-o", exe])
+    return exe
