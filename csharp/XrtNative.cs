@@ -55,36 +55,41 @@ namespace RayTraceProject.Native
     public static class Xrt
     {
         const string Lib = "xrt";   // libxrt.so / xrt.dll
+        // include/xrt.h promises cdecl.  The reference builds x86 (RayTraceProject.csproj:47,60), where P/Invoke defaults to StdCall
+        // and a cdecl callee would unbalance the stack: every import names its convention.  (The Avi.cs precedent binds Win32
+        // stdcall APIs and does not carry over.)
         public const int OK = 0, E_INVALID_ARG = -1, E_BUSY = -2, E_NO_DEVICE = -3;
 
-        [DllImport(Lib)] public static extern int xrt_version();
-        [DllImport(Lib)] public static extern IntPtr xrt_last_error();
-        [DllImport(Lib)] public static extern int xrt_scene_create(int device, out IntPtr scene);
-        [DllImport(Lib)] public static extern int xrt_scene_destroy(IntPtr scene);
-        [DllImport(Lib)] public static extern int xrt_scene_add_mesh(IntPtr scene, float[] v, float[] n, float[] uv, float[] surfN, float[] color,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_version();
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr xrt_last_error();
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_scene_create(int device, out IntPtr scene);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_scene_destroy(IntPtr scene);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_scene_add_mesh(IntPtr scene, float[] v, float[] n, float[] uv, float[] surfN, float[] color,
                                                                     int ntri, ref XrtMaterial material, float[] bbox, out int meshId);
-        [DllImport(Lib)] public static extern int xrt_scene_add_object(IntPtr scene, int[] meshIds, int nMeshes, float[] world, float[] invWorld,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_scene_add_object(IntPtr scene, int[] meshIds, int nMeshes, float[] world, float[] invWorld,
                                                                       float[] bbox, float[] worldBbox, out int objectId);
-        [DllImport(Lib)] public static extern int xrt_scene_build(IntPtr scene, int meshThreshold, int sceneThreshold);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_scene_build(IntPtr scene, int meshThreshold, int sceneThreshold);
         // scene file: the content-pipeline step writes it once (instead of .xnb reflection serialisation of Model.Tag), the game loads it
-        [DllImport(Lib)] public static extern int xrt_scene_save(IntPtr scene, [MarshalAs(UnmanagedType.LPStr)] string path);
-        [DllImport(Lib)] public static extern int xrt_scene_load(int device, [MarshalAs(UnmanagedType.LPStr)] string path, out IntPtr scene);
-        [DllImport(Lib)] public static extern int xrt_scene_intersect(IntPtr scene, [In] XrtRay[] rays, int[] ignoreObject, long n,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_scene_save(IntPtr scene, [MarshalAs(UnmanagedType.LPStr)] string path);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_scene_load(int device, [MarshalAs(UnmanagedType.LPStr)] string path, out IntPtr scene);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_scene_intersect(IntPtr scene, [In] XrtRay[] rays, int[] ignoreObject, long n,
                                                                      [Out] XrtHit[] hits, IntPtr stats);
-        [DllImport(Lib)] public static extern unsafe int xrt_render(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern unsafe int xrt_render(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,
                                                                    ref XrtRenderOpts opts, uint* rgbaOut, float* rgbF32Out, IntPtr stats);
         // pipelined form (two frames in flight; device output): RenderAsync / RenderCompleted without a host round trip
-        [DllImport(Lib)] public static extern int xrt_render_device_begin(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_render_device_begin(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,
                                                                             ref XrtRenderOpts opts, IntPtr dRgbaOut, IntPtr stream, out int ticket);
-        [DllImport(Lib)] public static extern int xrt_render_device_end(IntPtr scene, int ticket, IntPtr statsOut);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_render_device_end(IntPtr scene, int ticket, IntPtr statsOut);
         // pipelined form with the frame ending in the host's Color[] (RenderAsync + CurrentTarget.SetData, RayTracer.cs:59-79,122-123):
         // pin renderTargetData (GCHandle.Alloc(.., GCHandleType.Pinned)) and xrt_host_register it once; up to two tickets open
-        [DllImport(Lib)] public static extern int xrt_render_begin(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_render_begin(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,
                                                                      ref XrtRenderOpts opts, IntPtr rgbaOut, out int ticket);
-        [DllImport(Lib)] public static extern int xrt_render_end(IntPtr scene, int ticket, IntPtr statsOut);
-        [DllImport(Lib)] public static extern int xrt_host_register(IntPtr hostPtr, ulong bytes);
-        [DllImport(Lib)] public static extern int xrt_host_unregister(IntPtr hostPtr);
-        [DllImport(Lib)] public static extern float xrt_progress(IntPtr scene);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_render_end(IntPtr scene, int ticket, IntPtr statsOut);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_host_register(IntPtr hostPtr, ulong bytes);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_host_unregister(IntPtr hostPtr);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern float xrt_progress(IntPtr scene);
+        // can n_gpus > 1 load RCCL?  OK or E_RCCL (-6) with the loader's message; no device is touched
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_rccl_probe();
 
         // error convention of the reference: InvalidOperationException when busy (RayTracer.cs:26-27,62-63),
         // ArgumentException for bad arguments (SceneObject.cs:123-124, Material.cs:85,97)

@@ -50,8 +50,6 @@ extern "C" {
 #define XRT_ADDRESS_WRAP     1
 #define XRT_ADDRESS_MIRROR   2
 
-#define XRT_MAX_LIGHTS        32   /* more lights per frame: XRT_E_INVALID_ARG */
-
 #define XRT_LIGHT_SPOT         0   /* SPOT: IsPositionable == true  */
 #define XRT_LIGHT_DIRECTIONAL  1   /* DIR:  IsPositionable == false */
 
@@ -308,6 +306,11 @@ int xrt_shard_layout(int32_t width, int32_t height, int32_t shard_count, int32_t
  * rank 0 after the RCCL gather; a stride lets one gather carry the tiles of several frames). */
 int xrt_detile_device(int32_t width, int32_t height, int32_t shard_count, const void *d_gathered, int64_t rank_stride,
                       void *d_rgba_out, void *stream);
+
+/* Can the in-library multi-GPU path (xrt_render_opts.n_gpus > 1) load RCCL?  XRT_OK, or XRT_E_RCCL with the loader's message in
+ * xrt_last_error().  Touches no device: a host can ask before it offers the option (the reference has no counterpart; the call
+ * exists so that the failure a C# host would otherwise meet inside RenderInternal, RT:103-126, can be met up front). */
+int xrt_rccl_probe(void);
 
 /* RayTracer.Progress (RT:43-46): fraction of the frame's ray generations completed; callable from
  * another thread during xrt_render. */

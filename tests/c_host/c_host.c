@@ -10,6 +10,8 @@
 
 #include "xrt.h"
 
+#define C_HOST_MAX_LIGHTS 64   /* this host's own array; the library takes any number (RT:534-542 iterates a list) */
+
 static int fail(const char *what, int rc) {
     fprintf(stderr, "c_host: %s failed (%d): %s\n", what, rc, xrt_last_error());
     return 1;
@@ -18,7 +20,7 @@ static int fail(const char *what, int rc) {
 int main(int argc, char **argv) {
     xrt_scene *scene = NULL;
     xrt_camera cam;
-    xrt_light lights[XRT_MAX_LIGHTS];
+    xrt_light lights[C_HOST_MAX_LIGHTS];
     xrt_render_opts opts;
     xrt_stats stats;
     int32_t n_lights = 0;
@@ -31,7 +33,7 @@ int main(int argc, char **argv) {
     if (xrt_version() != XRT_VERSION) { fprintf(stderr, "c_host: header %d, library %d\n", XRT_VERSION, xrt_version()); return 1; }
     if ((rc = xrt_device_count(&n_dev)) != XRT_OK || n_dev < 1) return fail("xrt_device_count", rc);
     f = fopen(argv[2], "rb");
-    if (!f || fread(&cam, sizeof(cam), 1, f) != 1 || fread(&n_lights, sizeof(n_lights), 1, f) != 1 || n_lights < 0 || n_lights > XRT_MAX_LIGHTS ||
+    if (!f || fread(&cam, sizeof(cam), 1, f) != 1 || fread(&n_lights, sizeof(n_lights), 1, f) != 1 || n_lights < 0 || n_lights > C_HOST_MAX_LIGHTS ||
         (n_lights && fread(lights, sizeof(xrt_light), (size_t)n_lights, f) != (size_t)n_lights) || fread(&opts, sizeof(opts), 1, f) != 1) {
         fprintf(stderr, "c_host: cannot read %s\n", argv[2]);
         return 1;

@@ -446,3 +446,64 @@ def test_reference_content_scene_on_the_cpu():
     assert hits_equal(o_hits, e.intersect(prim)) == {}
     sec = secondary_rays(xrt, o_hits, seed=5)
     assert hits_equal(o.intersect(sec), e.intersect(sec)) == {}
+
+
+def test_scene_file_hostile_and_truncated_headers(xrt, tmp_path):
+    """xrt_scene_load trusts nothing in the file: counts and array sizes are bounded by the bytes the file really
+    holds before anything is allocated, the records go through the checks of xrt_scene_add_mesh / _add_object, and no C++
+    exception crosses the C boundary -- every bad file is XRT_E_INVALID_ARG (ValueError in the mirror) in well under a second."""
+    import struct
+    import time
+
+    def load(data):
+        p = str(tmp_path / "h.xrts")
+        open(p, "wb").write(data)
+        t0 = time.perf_counter()
+        try:
+            xrt.api.OctreeSpatialManager.Load(p, device=-1)
+            return None, time.perf_counter() - t0
+        except ValueError as e:
+            return str(e), time.perf_counter() - t0
+    head = b"XRTSCENE" + struct.pack("<I", 1)
+
+    def mesh(ntri, flags, tw, th, body=b""):
+        return struct.pack("<i6fffiii", ntri, 0, 0, 0, 1, 1, 1, 0.5, 0.0, flags, tw, th) + body
+    tri = struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + struct.pack("<9f", *([0, 0, 1] * 3)) + struct.pack("<6f", 0, 0, 1, 0, 0, 1) + \
+        struct.pack("<3f", 0, 0, 1) + struct.pack("<4f", 1, 1, 1, 1)
+    cases = {
+        "20-byte file announcing 2^24 meshes": head + struct.pack("<II", 1 << 24, 0),
+        "2^24 objects, none present": head + struct.pack("<II", 0, 1 << 24),
+        "a mesh of 2^28 - 1 triangles in a 60-byte file": head + struct.pack("<II", 1, 0) + mesh((1 << 28) - 1, 0, 0, 0),
+        "UseTexture with a 0 x 0 texture": head + struct.pack("<II", 1, 0) + mesh(1, 4, 0, 0, tri),
+        "premultiplied texels without UseTexture": head + struct.pack("<II", 1, 0) + mesh(1, 8, 1, 1, tri + struct.pack("<I", 0)),
+        "a 2^15 x 2^15 texture that is not there": head + struct.pack("<II", 1, 0) + mesh(1, 4, 1 << 15, 1 << 15, tri),
+        "unknown flag bits": head + struct.pack("<II", 1, 0) + mesh(1, 64, 0, 0, tri),
+        "an object naming a mesh that does not exist": head + struct.pack("<II", 1, 1) + mesh(1, 0, 0, 0, tri) + struct.pack("<ii", 1, 7) + b"\0" * (4 * 44),
+        "an object with 2^20 mesh ids, none present": head + struct.pack("<II", 0, 1) + struct.pack("<i", 1 << 20),
+        "empty file": b"",
+    }
+    for what, data in cases.items():
+        err, dt = load(data)
+        assert err is not None and dt < 1.0, (what, err, dt)
+    # ... and the smallest honest file loads: one triangle, one body
+    ok = head + struct.pack("<II", 1, 1) + mesh(1, 0, 0, 0, tri) + struct.pack("<ii", 1, 0) + \
+        struct.pack("<16f", *np.eye(4).ravel()) * 2 + struct.pack("<6f", 0, 0, 0, 1, 1, 1) * 2
+    assert load(ok)[0] is None
+
+
+def test_rccl_load_failure_is_an_error_code_not_a_crash(xrt, tmp_path):
+    """ADVICE r2: with librccl missing, RcclGather::load built its message from a second dlerror() call (NULL -> std::string(NULL),
+    undefined behaviour) -- on a host without RCCL every n_gpus > 1 render would have crashed instead of returning XRT_E_RCCL.
+    xrt_rccl_probe takes the same load path without touching a device: a library that does not exist and one that lacks the
+    RCCL entry points both come back as XRT_E_RCCL with the loader's message.  (In a child process: the override is read from
+    the environment at load time and a loaded library stays loaded.)"""
+    import subprocess
+    import sys
+    code = ("import importlib, sys; sys.path.insert(0, %r); x = importlib.import_module('xna-ray-trace_amd'); l = x.abi.lib(); "
+            "rc = l.xrt_rccl_probe(); print(rc, l.xrt_last_error().decode())") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for libname, needle in (("/nonexistent/librccl-missing.so", "cannot load librccl.so"), ("libm.so.6", "lacks ncclCommInitAll")):
+        env = dict(os.environ, XRT_RCCL_LIB=libname)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rc, _, msg = out.stdout.strip().partition(" ")
+        assert int(rc) == xrt.abi.XRT_E_RCCL and needle in msg and len(msg) > len(needle), out.stdout

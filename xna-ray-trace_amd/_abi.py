@@ -110,6 +110,7 @@ SYMBOLS = {
     "xrt_shard_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "xrt_detile_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "xrt_progress": (C.c_float, [C.c_void_p]),
+    "xrt_rccl_probe": (C.c_int, []),
     "xrt_generate_primary_rays": (C.c_int, [C.c_void_p, _P(xrt_camera), _P(xrt_ray)]),
 }
 

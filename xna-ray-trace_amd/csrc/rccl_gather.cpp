@@ -6,18 +6,28 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
+
 namespace xrt {
 
 static_assert(sizeof(ncclComm_t) == sizeof(void *), "ncclComm_t is an opaque pointer");
 
 bool RcclGather::load(std::string &err) {
     if (lib_) return true;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
+    // XRT_RCCL_LIB=<path> names the library to load instead (a site with RCCL elsewhere; the CPU test of this failure path)
+    const char *given = getenv("XRT_RCCL_LIB");
+    const char *defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string why;   // message of the last failed dlopen (dlerror() clears the error it returns: read it once per failure)
+    for (const char *n : defaults) {
+        if (given) n = given;
+        (void)dlerror();
         lib_ = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (lib_) break;
+        const char *e = dlerror();
+        why = e ? e : "?";
+        if (given) break;
     }
-    if (!lib_) { err = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?"); return false; }
+    if (!lib_) { err = std::string("cannot load librccl.so: ") + why; return false; }
     auto sym = [&](const char *n) -> void * {
         void *p = dlsym(lib_, n);
         if (!p && err.empty()) err = std::string("librccl.so lacks ") + n;

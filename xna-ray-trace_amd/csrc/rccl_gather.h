@@ -15,6 +15,8 @@ public:
     // Communicators for `devices` (distinct HIP device ids, rank i = devices[i]).  Idempotent for the same list.
     bool init(const std::vector<int> &devices, std::string &err);
     int ranks() const { return (int)comms_.size(); }
+    // Can librccl be loaded and does it export what the gather needs?  No device is touched (xrt_rccl_probe).
+    bool probe(std::string &err) { return load(err); }
     // One grouped exchange: for every i, `count` 32-bit words go from src[i] (on rank srcRank[i], enqueued on
     // srcStream[i]) to dst[i] on rank 0 (enqueued on dstStream).  srcRank[i] == 0 is a send-to-self on rank 0's
     // communicator (RCCL matches the pairs of one group in order) -- the form the single-device test mode uses.

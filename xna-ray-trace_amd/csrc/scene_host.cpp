@@ -321,9 +321,18 @@ struct FileW {
 };
 struct FileR {
     FILE *f; bool ok = true;
-    template <class T> void get(T *p, size_t n) { if (ok && n && fread(p, sizeof(T), n, f) != n) ok = false; }
+    long long left = 0;   // bytes of the file not read yet: no array is sized for more than the file can hold
+    template <class T> void get(T *p, size_t n) {
+        if (!ok || !n) return;
+        if ((unsigned long long)n > (unsigned long long)left / sizeof(T) || fread(p, sizeof(T), n, f) != n) { ok = false; return; }
+        left -= (long long)(n * sizeof(T));
+    }
     template <class T> T one() { T v{}; get(&v, 1); return v; }
-    template <class T> void vec(std::vector<T> &v, size_t n) { if (!ok) return; if (n > ((size_t)1 << 31)) { ok = false; return; } v.resize(n); get(v.data(), n); }
+    template <class T> void vec(std::vector<T> &v, size_t n) {
+        if (!ok) return;
+        if ((unsigned long long)n > (unsigned long long)left / sizeof(T)) { ok = false; return; }   // a hostile header cannot ask for more than the file holds
+        v.resize(n); get(v.data(), n);
+    }
 };
 }  // namespace
 
@@ -355,34 +364,51 @@ bool HostScene::load(const char *path, std::string &err) {
     FILE *f = path ? fopen(path, "rb") : nullptr;
     if (!f) { err = "xrt_scene_load: cannot open the file"; return false; }
     FileR r{f};
+    if (fseek(f, 0, SEEK_END) == 0) { r.left = ftell(f); if (r.left < 0 || fseek(f, 0, SEEK_SET) != 0) r.ok = false; } else r.ok = false;
     char magic[8] = {0};
     r.get(magic, 8);
     const uint32_t version = r.one<uint32_t>(), nm = r.one<uint32_t>(), no = r.one<uint32_t>();
     if (!r.ok || std::memcmp(magic, "XRTSCENE", 8) != 0 || version != 1 || nm > (1u << 24) || no > (1u << 24)) { fclose(f); err = "xrt_scene_load: not a version-1 xrt scene file"; return false; }
-    std::vector<HostMesh> ms(nm);
-    std::vector<HostObject> os(no);
-    for (HostMesh &m : ms) {
+    // The records are read into a scratch scene through add_mesh / add_object -- the very calls (and checks) the header promises a
+    // load is equivalent to; the lists grow as records arrive, so the counts of a hostile header allocate nothing.
+    HostScene tmp;
+    std::string why;
+    for (uint32_t i = 0; i < nm && r.ok; i++) {
+        HostMesh m;
         m.ntri = r.one<int32_t>(); r.get(m.bbox, 6); m.reflectiveness = r.one<float>(); m.refractionIndex = r.one<float>();
         const int flags = r.one<int32_t>();
         m.texW = r.one<int32_t>(); m.texH = r.one<int32_t>();
-        if (!r.ok || m.ntri < 0 || m.ntri >= (1 << 28) || m.texW < 0 || m.texH < 0 || (long long)m.texW * m.texH > (1LL << 30)) { r.ok = false; break; }
-        m.transparent = (flags & 1) != 0; m.interpolateNormals = (flags & 2) != 0; m.useTexture = (flags & 4) != 0;
+        if (!r.ok || m.ntri < 0 || m.ntri >= (1 << 28) || m.texW < 0 || m.texH < 0 || (long long)m.texW * m.texH > (1LL << 30) || (flags & ~15)) { r.ok = false; break; }
+        const bool useTexture = (flags & 4) != 0, hasP = (flags & 8) != 0;
+        if (hasP && !useTexture) { r.ok = false; why = "premultiplied texels without UseTexture"; break; }
+        if (!useTexture && (m.texW != 0 || m.texH != 0)) { r.ok = false; why = "texture size without UseTexture"; break; }
         const size_t n = (size_t)m.ntri;
         r.vec(m.v, n * 9); r.vec(m.n, n * 9); r.vec(m.uv, n * 6); r.vec(m.sn, n * 3); r.vec(m.color, n * 4);
-        if (m.useTexture) r.vec(m.texels, (size_t)m.texW * m.texH);
-        if (flags & 8) r.vec(m.texelsP, (size_t)m.texW * m.texH);
-    }
-    for (HostObject &o : os) {
+        if (useTexture) r.vec(m.texels, (size_t)m.texW * m.texH);
+        if (hasP) r.vec(m.texelsP, (size_t)m.texW * m.texH);
         if (!r.ok) break;
+        xrt_material xm;
+        std::memset(&xm, 0, sizeof(xm));
+        xm.reflectiveness = m.reflectiveness; xm.refraction_index = m.refractionIndex;
+        xm.transparent = (flags & 1) ? 1 : 0; xm.interpolate_normals = (flags & 2) ? 1 : 0; xm.use_texture = useTexture ? 1 : 0;
+        xm.tex_argb = useTexture ? m.texels.data() : nullptr; xm.tex_pargb = hasP ? m.texelsP.data() : nullptr;
+        xm.tex_width = m.texW; xm.tex_height = m.texH;
+        static const float none[9] = {0};   // (an empty vector has no address; add_mesh rejects null arrays)
+        if (tmp.add_mesh(n ? m.v.data() : none, n ? m.n.data() : none, n ? m.uv.data() : none, n ? m.sn.data() : none, n ? m.color.data() : none, m.ntri, &xm, m.bbox, why) < 0) { r.ok = false; break; }
+    }
+    for (uint32_t i = 0; i < no && r.ok; i++) {
+        HostObject o;
         const int k = r.one<int32_t>();
         if (!r.ok || k < 0 || k > (1 << 20)) { r.ok = false; break; }
         r.vec(o.meshes, (size_t)k);
-        for (int id : o.meshes) if (id < 0 || id >= (int)nm) r.ok = false;
         r.get(o.world, 16); r.get(o.invWorld, 16); r.get(o.bbox, 6); r.get(o.worldBbox, 6);
+        if (!r.ok) break;
+        static const int noId[1] = {0};
+        if (tmp.add_object(k ? o.meshes.data() : noId, k, o.world, o.invWorld, o.bbox, o.worldBbox, why) < 0) { r.ok = false; break; }
     }
     fclose(f);
-    if (!r.ok) { err = "xrt_scene_load: truncated or corrupt scene file"; return false; }
-    meshes = std::move(ms); objects = std::move(os);
+    if (!r.ok) { err = "xrt_scene_load: truncated or corrupt scene file" + (why.empty() ? std::string() : " (" + why + ")"); return false; }
+    meshes = std::move(tmp.meshes); objects = std::move(tmp.objects);
     built = false;
     return true;
 }

@@ -6,6 +6,8 @@
 #include <dlfcn.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -82,6 +84,16 @@ struct Range {   // RAII: a named range for the enclosing scope
     ~Range() { if (on) roctx().pop(); }
 };
 
+// No C++ exception may cross the C boundary (a P/Invoke, ctypes or C host would be terminated): the entry points that
+// allocate host memory from caller-given sizes run inside this guard.
+template <class F>
+int guarded(const char *fn, F &&f) {
+    try { return f(); }
+    catch (const std::bad_alloc &) { return fail(XRT_E_OOM, "%s: out of host memory", fn); }
+    catch (const std::exception &e) { return fail(XRT_E_INVALID_ARG, "%s: %s", fn, e.what()); }
+    catch (...) { return fail(XRT_E_INTERNAL, "%s: unknown exception", fn); }
+}
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -106,6 +118,43 @@ int upload(DevBuf<T> &b, const std::vector<T> &v) {
 }
 
 }  // namespace
+
+// One host thread per replica device (in-library multi-GPU, xrt_render_opts.n_gpus), created with the replica and parked on a
+// condition variable between frames: it has made its device current once and enqueues that device's share of every frame.
+// (Round 2 spawned and joined n-1 std::threads per frame: tens of microseconds of host time on a 0.75 ms frame.)
+struct RankWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool posted = false, finished = false, quit = false;
+    explicit RankWorker(int device) {
+        th = std::thread([this, device] {
+            (void)hipSetDevice(device);
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                cv.wait(lk, [this] { return posted || quit; });
+                if (quit) return;
+                posted = false;
+                lk.unlock();
+                job();
+                lk.lock();
+                finished = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void post(std::function<void()> f) {
+        { std::lock_guard<std::mutex> lk(m); job = std::move(f); finished = false; posted = true; }
+        cv.notify_all();
+    }
+    void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return finished; }); }
+    ~RankWorker() {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
 
 constexpr int MAX_STAMP_ROWS = 256;   // traversal launches of one frame that can time themselves (kernels.h STAMP_*)
 struct xrt_scene {
@@ -258,6 +307,8 @@ struct xrt_scene {
     // communicators, and per ticket the buffer the tile shards are gathered into.  XRT_FAKE_GPUS=1 (test boxes with one
     // GPU): the replicas live on the scene's own device and the exchange is RCCL send-to-self.
     std::vector<xrt_scene *> replicas;
+    std::vector<std::unique_ptr<RankWorker>> workers;   // workers[i - 1] drives replica i
+    int visibleDevices = 0;                             // hipGetDeviceCount at xrt_scene_create
     RcclGather rccl;
     bool fakeGpus = false;
     DevBuf<uint32_t> gathered[2];    // primary: n * tiles_per_rank * 512 pixels, rank-major
@@ -272,6 +323,7 @@ struct xrt_scene {
     bool noRectCull = false, oneStream = false, noFeedback = false;
 
     ~xrt_scene() {
+        workers.clear();   // (joins the threads)
         for (xrt_scene *r : replicas) delete r;
         replicas.clear();
         if (device >= 0) {
@@ -442,7 +494,6 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const bool stats = true;   // the read-back is two small pinned copies; always taken
     xrt_scene::WorkBufs &W = F.w;
     if (!cam || !opts || (!lights && nLights > 0) || nLights < 0) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
-    if (nLights > XRT_MAX_LIGHTS) return fail(XRT_E_INVALID_ARG, "xrt_render: more than XRT_MAX_LIGHTS (%d) lights", XRT_MAX_LIGHTS);
     if (opts->max_reflections < 0 || opts->max_reflections > 64) return fail(XRT_E_INVALID_ARG, "max_reflections out of range");
     if (opts->address_mode < XRT_ADDRESS_CLAMP || opts->address_mode > XRT_ADDRESS_MIRROR)
         return fail(XRT_E_INVALID_ARG, "Value does not fall within the expected range: addressMode (MAT:85)");
@@ -484,9 +535,13 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // level records bounded by 8 GB) and a chunk whose generation overflows is retried with a quarter of the paths.
     const size_t nodes = heap ? (((size_t)1 << (R + 1)) - 1) : (size_t)(R + 1);
     long long maxPaths = s->maxChunkPaths;
-    if (nL > 1 && maxPaths > (1LL << 30) / nL) maxPaths = ((1LL << 30) / nL) & ~8191LL;   // shadow rays of a generation are counted in an int
+    // The reference iterates a List<ILight> of any length (RT:534-542).  The shadow rays of one generation are counted in an int
+    // (at most 2^30): many lights shrink the chunk, they are not refused -- until not even 8192 paths fit a generation.
+    const long long lightBound = (1LL << 30) / (nL > 0 ? nL : 1);
+    if (maxPaths > lightBound) maxPaths = lightBound & ~8191LL;
+    if (maxPaths < 8192) return fail(XRT_E_UNSUPPORTED, "%d lights: the shadow rays of 8192 paths do not fit one generation (2^30 rays)", nL);
     if (heap) {
-        maxPaths = 1 << 21;   // (a 1080p frame is one chunk when the level records fit 8 GB: MaxReflections <= 6)
+        if (maxPaths > (1 << 21)) maxPaths = 1 << 21;   // (a 1080p frame is one chunk when the level records fit 8 GB: MaxReflections <= 6)
         const long long byRecords = (long long)((8ull << 30) / (nodes * 36ull));
         if (byRecords < maxPaths) maxPaths = byRecords;
         maxPaths &= ~63LL;
@@ -495,8 +550,11 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const long long chunkPaths = firstPaths < maxPaths ? firstPaths : maxPaths;
     const int P = (int)chunkPaths;
     size_t rayCap = (size_t)P;
-    if (heap) { rayCap = (R < 20 && ((size_t)P << R) < (size_t)s->heapRayCap) ? ((size_t)P << R) : (size_t)s->heapRayCap; if (rayCap < (size_t)P) rayCap = (size_t)P; }
-    // shadow rays of one generation are counted in an int (rayCap <= 2^25, nL <= XRT_MAX_LIGHTS = 32: at most 2^30)
+    if (heap) {
+        const size_t capL = (size_t)std::min<long long>(s->heapRayCap, lightBound);   // (>= 8192 >= ... see above; P <= lightBound as well)
+        rayCap = (R < 20 && ((size_t)P << R) < capL) ? ((size_t)P << R) : capL;
+        if (rayCap < (size_t)P) rayCap = (size_t)P;
+    }
     if ((unsigned long long)rayCap * (unsigned long long)(nL > 0 ? nL : 1) > (1ull << 30)) return fail(XRT_E_UNSUPPORTED, "frame too large: %zu rays x %d lights per generation", rayCap, nL);
     const size_t shadowCap = rayCap;   // hits of one generation (each emits nL shadow rays)
     const bool wantF32 = d_outF32 != nullptr && !adaptive && g.samples == 1;
@@ -1069,6 +1127,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         HIPCHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
         int rc = scene_upload(r.get());
         if (rc != XRT_OK) return rc;
+        s->workers.emplace_back(new RankWorker(r->device));
         s->replicas.push_back(r.release());
     }
     return hipSetDevice(s->device) == hipSuccess ? XRT_OK : fail(XRT_E_HIP, "hipSetDevice failed");
@@ -1086,11 +1145,8 @@ int multi_begin(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *
     if (opts->shard_count > 1) return fail(XRT_E_INVALID_ARG, "n_gpus > 1 shards the frame inside the library: shard_count must be 0 or 1");
     if (n > XRT_MAX_GPUS) return fail(XRT_E_INVALID_ARG, "n_gpus %d exceeds %d", n, XRT_MAX_GPUS);
     if (!cam || cam->vp_width <= 0 || cam->vp_height <= 0) return fail(XRT_E_INVALID_ARG, "viewport must be positive");
-    if (!s->fakeGpus) {
-        int nd = 0;
-        if (hipGetDeviceCount(&nd) != hipSuccess) { (void)hipGetLastError(); nd = 0; }
-        if (s->device + n > nd) return fail(XRT_E_NO_DEVICE, "n_gpus %d from device %d needs %d visible devices, %d present", n, s->device, s->device + n, nd);
-    }
+    if (!s->fakeGpus && s->device + n > s->visibleDevices)
+        return fail(XRT_E_NO_DEVICE, "n_gpus %d from device %d needs %d visible devices, %d present", n, s->device, s->device + n, s->visibleDevices);
     int rc;
     if ((rc = ensure_replicas(s, n))) return rc;
     {
@@ -1108,11 +1164,11 @@ int multi_begin(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *
     for (int i = 1; i < n; i++) {
         xrt_scene *r = rank_scene(s, i);
         HIPCHECK(hipSetDevice(r->device));
-        if ((rc = r->tileOut[slot].ensure(count))) return rc;
+        if ((rc = r->tileOut[slot].ensure(count))) { (void)hipSetDevice(s->device); return rc; }
         if (s->fakeGpus && !r->tilesReady[slot]) HIPCHECK(hipEventCreateWithFlags(&r->tilesReady[slot], hipEventDisableTiming));
     }
     HIPCHECK(hipSetDevice(s->device));
-    // one host thread per device
+    // every device's share is enqueued by its own (persistent) host thread
     std::vector<int> rcs((size_t)n, XRT_OK);
     std::vector<std::string> errs((size_t)n);
     auto work = [&](int i) {
@@ -1124,51 +1180,51 @@ int multi_begin(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *
         rcs[(size_t)i] = frame_begin(r, r->frames[slot], cam, lights, nLights, &o, dst, nullptr, nullptr, 0, 1, false);   // (the gather is enqueued behind the frame: no redo)
         if (rcs[(size_t)i] != XRT_OK) errs[(size_t)i] = g_err;
     };
-    {
-        std::vector<std::thread> th;
-        for (int i = 1; i < n; i++) th.emplace_back(work, i);
-        work(0);
-        for (auto &t : th) t.join();
-    }
-    HIPCHECK(hipSetDevice(s->device));
-    for (int i = 0; i < n; i++)
-        if (rcs[(size_t)i] != XRT_OK) {   // wait for the ranks that did start, then report the first failure
-            for (int j = 0; j < n; j++) {
-                xrt_scene *r = rank_scene(s, j);
-                if (r->frames[slot].pending) { (void)hipSetDevice(r->device); (void)frame_finish(r, r->frames[slot], nullptr); }
+    for (int i = 1; i < n; i++) s->workers[(size_t)i - 1]->post([&work, i] { work(i); });
+    work(0);
+    for (int i = 1; i < n; i++) s->workers[(size_t)i - 1]->wait();
+    // From here on frames are in flight on the ranks: whatever fails, every rank's frame is waited for before the error is
+    // reported -- a ticket that was never handed out must not leave a context pending (later renders would be XRT_E_BUSY).
+    auto drain = [&]() {
+        for (int j = 0; j < n; j++) {
+            xrt_scene *r = rank_scene(s, j);
+            if (r->frames[slot].pending) { (void)hipSetDevice(r->device); (void)frame_finish(r, r->frames[slot], nullptr); }
+        }
+        (void)hipSetDevice(s->device);
+    };
+    auto tail = [&]() -> int {
+        HIPCHECK(hipSetDevice(s->device));
+        for (int i = 0; i < n; i++)
+            if (rcs[(size_t)i] != XRT_OK) return fail(rcs[(size_t)i], "rank %d: %s", i, errs[(size_t)i].c_str());
+        hipStream_t st0 = s->frames[slot].w.lastStream;
+        std::vector<const void *> src;
+        std::vector<int> srcRank;
+        std::vector<hipStream_t> srcStream;
+        std::vector<void *> dst;
+        for (int i = 1; i < n; i++) {
+            xrt_scene *r = rank_scene(s, i);
+            hipStream_t sti = r->frames[slot].w.lastStream;
+            if (s->fakeGpus) {   // same device, one communicator: rank 0's stream waits for the tiles, then sends to itself
+                HIPCHECK(hipEventRecord(r->tilesReady[slot], sti));
+                HIPCHECK(hipStreamWaitEvent(st0, r->tilesReady[slot], 0));
+                sti = st0;
             }
-            (void)hipSetDevice(s->device);
-            return fail(rcs[(size_t)i], "rank %d: %s", i, errs[(size_t)i].c_str());
+            src.push_back(r->tileOut[slot].p); srcRank.push_back(s->fakeGpus ? 0 : i); srcStream.push_back(sti);
+            dst.push_back(s->gathered[slot].p + (size_t)i * count);
         }
-    hipStream_t st0 = s->frames[slot].w.lastStream;
-    std::vector<const void *> src;
-    std::vector<int> srcRank;
-    std::vector<hipStream_t> srcStream;
-    std::vector<void *> dst;
-    for (int i = 1; i < n; i++) {
-        xrt_scene *r = rank_scene(s, i);
-        hipStream_t sti = r->frames[slot].w.lastStream;
-        if (s->fakeGpus) {   // same device, one communicator: rank 0's stream waits for the tiles, then sends to itself
-            HIPCHECK(hipEventRecord(r->tilesReady[slot], sti));
-            HIPCHECK(hipStreamWaitEvent(st0, r->tilesReady[slot], 0));
-            sti = st0;
+        {
+            std::string err;
+            if (!s->rccl.gather(src, srcRank, srcStream, dst, count, st0, err)) return fail(XRT_E_RCCL, "%s", err.c_str());
         }
-        src.push_back(r->tileOut[slot].p); srcRank.push_back(s->fakeGpus ? 0 : i); srcStream.push_back(sti);
-        dst.push_back(s->gathered[slot].p + (size_t)i * count);
-    }
-    {
-        std::string err;
-        if (!s->rccl.gather(src, srcRank, srcStream, dst, count, st0, err)) {
-            for (int j = 0; j < n; j++) { xrt_scene *r = rank_scene(s, j); (void)hipSetDevice(r->device); (void)frame_finish(r, r->frames[slot], nullptr); }
-            (void)hipSetDevice(s->device);
-            return fail(XRT_E_RCCL, "%s", err.c_str());
-        }
-    }
-    HIPCHECK(hipSetDevice(s->device));
-    launch_detile(cam->vp_width, cam->vp_height, n, tpr, s->gathered[slot].p, (long long)count, d_out, st0);
-    HIPCHECK(hipGetLastError());
-    *stream0_out = st0;
-    return XRT_OK;
+        HIPCHECK(hipSetDevice(s->device));
+        launch_detile(cam->vp_width, cam->vp_height, n, tpr, s->gathered[slot].p, (long long)count, d_out, st0);
+        HIPCHECK(hipGetLastError());
+        *stream0_out = st0;
+        return XRT_OK;
+    };
+    rc = tail();
+    if (rc != XRT_OK) { const std::string keep = g_err; drain(); g_err = keep; }
+    return rc;
 }
 
 // Counters add up over the pieces of a frame (ranks, halves); times are the slowest piece's (the frame's critical path).
@@ -1433,6 +1489,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     }
     xrt_scene *s = new xrt_scene();
     s->device = device;
+    if (device >= 0 && hipGetDeviceCount(&s->visibleDevices) != hipSuccess) { (void)hipGetLastError(); s->visibleDevices = 0; }
     s->waveTimesPath = getenv("XRT_WAVE_TIMES") ? getenv("XRT_WAVE_TIMES") : "";
     s->stampDumpPath = getenv("XRT_STAMP_DUMP") ? getenv("XRT_STAMP_DUMP") : "";
     s->fakeGpus = getenv("XRT_FAKE_GPUS") != nullptr;
@@ -1452,8 +1509,11 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_SPLIT_MS")) s->splitMinMs = (float)atof(e);
     if (const char *e = getenv("XRT_SPLIT_PARTS")) { const int v = atoi(e); if (v >= 2 && v <= 4) s->splitParts = v; }
     if (const char *e = getenv("XRT_PK_CULL_MIN")) s->packetCullMin = atoi(e);
-    if (const char *e = getenv("XRT_LEAF_CULL")) { const double v = atof(e); if (v >= 0.0 && v <= 1e6) s->hs.leafCullSafety = v; }   // development: 0 = no tight leaf boxes, 1 = the proven margin
-    if (const char *e = getenv("XRT_CULL_SAFETY")) { const double v = atof(e); if (v >= 0.0 && v <= 1e6) s->hs.cullSafety = v; }   // development: factor S of the object pre-cull margin (below 2 the bound is no longer proven)
+#ifdef XRT_DEV   // (make DEV=1) the two margin factors are the only switches that can change a result: below their proven values the skips
+                 // are no longer exact.  A shipped library does not read them from the environment of its host process.
+    if (const char *e = getenv("XRT_LEAF_CULL")) { const double v = atof(e); if (v >= 0.0 && v <= 1e6) s->hs.leafCullSafety = v; }   // 0 = no tight leaf boxes, 1 = the proven margin
+    if (const char *e = getenv("XRT_CULL_SAFETY")) { const double v = atof(e); if (v >= 0.0 && v <= 1e6) s->hs.cullSafety = v; }   // factor S of the object pre-cull margin (below 2 the bound is no longer proven)
+#endif
     s->noRectCull = getenv("XRT_NO_RECT_CULL") != nullptr; s->oneStream = getenv("XRT_ONE_STREAM") != nullptr; s->noFeedback = getenv("XRT_NO_FEEDBACK") != nullptr;
     if (const char *e = getenv("XRT_OVERLAP_MS")) s->overlapMinMs = (float)atof(e);   // 0: every single-chunk frame gets its context's stream
     if (const char *e = getenv("XRT_HEAP_RAY_CAP")) { long long v = atoll(e); if (v >= 1024 && v <= HEAP_RAY_CAP) s->heapRayCap = v; }
@@ -1487,55 +1547,69 @@ int xrt_scene_add_mesh(xrt_scene *scene, const float *v, const float *n, const f
                        int32_t ntri, const xrt_material *material, const float bbox[6], int32_t *mesh_id_out) {
     if (!scene || !mesh_id_out) return fail(XRT_E_INVALID_ARG, "xrt_scene_add_mesh: null argument");
     if (in_flight(scene)) return fail(XRT_E_BUSY, "scene is rendering");
-    std::string err;
-    int id = scene->hs.add_mesh(v, n, uv, surf_n, color, ntri, material, bbox, err);
-    if (id < 0) return fail(XRT_E_INVALID_ARG, "%s", err.c_str());
-    scene->resident = false;
-    *mesh_id_out = id;
-    return XRT_OK;
+    return guarded("xrt_scene_add_mesh", [&]() -> int {
+        std::string err;
+        int id = scene->hs.add_mesh(v, n, uv, surf_n, color, ntri, material, bbox, err);
+        if (id < 0) return fail(XRT_E_INVALID_ARG, "%s", err.c_str());
+        scene->resident = false;
+        *mesh_id_out = id;
+        return XRT_OK;
+    });
 }
 
 int xrt_scene_add_object(xrt_scene *scene, const int32_t *mesh_ids, int32_t n_meshes, const float world[16], const float inv_world[16],
                          const float bbox[6], const float world_bbox[6], int32_t *object_id_out) {
     if (!scene || !object_id_out) return fail(XRT_E_INVALID_ARG, "xrt_scene_add_object: null argument");
     if (in_flight(scene)) return fail(XRT_E_BUSY, "scene is rendering");
-    std::string err;
-    int id = scene->hs.add_object(mesh_ids, n_meshes, world, inv_world, bbox, world_bbox, err);
-    if (id < 0) return fail(XRT_E_INVALID_ARG, "%s", err.c_str());
-    scene->resident = false;
-    *object_id_out = id;
-    return XRT_OK;
+    return guarded("xrt_scene_add_object", [&]() -> int {
+        std::string err;
+        int id = scene->hs.add_object(mesh_ids, n_meshes, world, inv_world, bbox, world_bbox, err);
+        if (id < 0) return fail(XRT_E_INVALID_ARG, "%s", err.c_str());
+        scene->resident = false;
+        *object_id_out = id;
+        return XRT_OK;
+    });
 }
 
 int xrt_scene_build(xrt_scene *scene, int32_t mesh_threshold, int32_t scene_threshold) {
     if (!scene) return fail(XRT_E_INVALID_ARG, "xrt_scene_build: null scene");
     if (in_flight(scene)) return fail(XRT_E_BUSY, "scene is rendering");
-    std::string err;
-    scene->resident = false;
-    if (!scene->hs.build(mesh_threshold, scene_threshold, err)) return fail(XRT_E_UNSUPPORTED, "%s", err.c_str());
-    for (xrt_scene *r : scene->replicas) delete r;   // copies of the previous build on other devices
-    scene->replicas.clear();
-    return scene_upload(scene);
+    return guarded("xrt_scene_build", [&]() -> int {
+        std::string err;
+        scene->resident = false;
+        if (!scene->hs.build(mesh_threshold, scene_threshold, err)) return fail(XRT_E_UNSUPPORTED, "%s", err.c_str());
+        scene->workers.clear();
+        for (xrt_scene *r : scene->replicas) delete r;   // copies of the previous build on other devices
+        scene->replicas.clear();
+        return scene_upload(scene);
+    });
 }
 
 int xrt_scene_save(const xrt_scene *scene, const char *path) {
     if (!scene || !path) return fail(XRT_E_INVALID_ARG, "xrt_scene_save: null argument");
-    std::string err;
-    if (!scene->hs.save(path, err)) return fail(XRT_E_INVALID_ARG, "%s (%s)", err.c_str(), path);
-    return XRT_OK;
+    return guarded("xrt_scene_save", [&]() -> int {
+        std::string err;
+        if (!scene->hs.save(path, err)) return fail(XRT_E_INVALID_ARG, "%s (%s)", err.c_str(), path);
+        return XRT_OK;
+    });
 }
 
 int xrt_scene_load(int device, const char *path, xrt_scene **scene_out) {
     if (!scene_out || !path) return fail(XRT_E_INVALID_ARG, "xrt_scene_load: null argument");
     int rc = xrt_scene_create(device, scene_out);
     if (rc != XRT_OK) return rc;
-    std::string err;
-    if (!(*scene_out)->hs.load(path, err)) {
+    rc = guarded("xrt_scene_load", [&]() -> int {
+        std::string err;
+        if (!(*scene_out)->hs.load(path, err)) return fail(XRT_E_INVALID_ARG, "%s (%s)", err.c_str(), path);
+        return XRT_OK;
+    });
+    if (rc != XRT_OK) {
+        const std::string keep = g_err;
         delete *scene_out;
         *scene_out = nullptr;
-        return fail(XRT_E_INVALID_ARG, "%s (%s)", err.c_str(), path);
+        g_err = keep;
     }
-    return XRT_OK;
+    return rc;
 }
 
 int xrt_scene_get_tree(const xrt_scene *scene, int32_t mesh_id, xrt_node_info *nodes, int64_t *n_nodes_inout, int32_t *refs,
@@ -1701,6 +1775,15 @@ int xrt_detile_device(int32_t width, int32_t height, int32_t shard_count, const 
                   (uint32_t *)d_rgba_out, (hipStream_t)stream);
     HIPCHECK(hipGetLastError());
     return XRT_OK;
+}
+
+int xrt_rccl_probe(void) {
+    return guarded("xrt_rccl_probe", [&]() -> int {
+        RcclGather g;
+        std::string err;
+        if (!g.probe(err)) return fail(XRT_E_RCCL, "%s", err.c_str());
+        return XRT_OK;
+    });
 }
 
 float xrt_progress(const xrt_scene *scene) { return scene ? scene->progress.load() : 0.0f; }
