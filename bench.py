@@ -215,6 +215,8 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
     st0 = tracer.RenderDevice(outs[0].data_ptr(), shard_rank=rank, shard_count=world)
     tracer.collect_stats = False
     dt, ms_int, launches = time_frames(tracer, outs, steps, warmup, rank, world, W, H, final)
+    # the pixels the timed loop's own render objects produced last (read back after the timed region): what main() compares with the oracle
+    last_frame = outs[(steps - 1) % 2].cpu().numpy().view(np.uint32).copy() if (world == 1 and steps > 0) else None
     if world > 1 and rank == 0 and os.environ.get("XRT_BENCH_VERIFY"):   # rehearsals: the gathered, de-tiled frame is the unsharded one
         whole = torch.zeros(W * H, dtype=torch.int32, device="cuda")
         tracer.RenderDevice(whole.data_ptr())
@@ -222,7 +224,7 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
         assert torch.equal(whole, final), "gathered frame differs from the unsharded render"
         print("bench.py: gathered frame verified against the unsharded render", file=sys.stderr)
     rays = st0["rays_closest"] + st0["rays_shadow"]
-    res = dict(rays=rays, seconds=dt, ms_intersect=ms_int, launches=launches, stats=st0, build_s=build_s, width=W, height=H,
+    res = dict(rays=rays, seconds=dt, ms_intersect=ms_int, launches=launches, stats=st0, build_s=build_s, width=W, height=H, last_frame=last_frame,
                tris=sum(m[0].ntri for m in spec.meshes), instances=len(spec.objects), overlapped=False)
     if world == 1 and dt / max(steps, 1) * 1e3 >= 0.04:
         # The frames of the timed region overlapped pairwise on the GPU (two streams), so a launch's duration includes time
@@ -275,8 +277,10 @@ def time_host_output(tracer, spec, steps, warmup):
 
 def cpu_baseline(spec, budget_s=12.0):
     """The CPU oracle (C++ restatement of the reference's C# path, kind "port") on the host cores, rank 0 at
-    N=1 only, on a bounded sample of the same workload (about `budget_s` seconds of single-thread work): centre
-    rows of the frame, or the whole frame repeated when one frame is quicker than the budget."""
+    N=1 only, on a bounded sample of the same workload: about `budget_s` seconds of single-thread work on centre rows of
+    the frame (`value`: the shipped reference renders on one thread, RayTracer.cs:99), then the WHOLE frame once on all cores
+    (`value_all_cores`).  Returns the block for the JSON line and the oracle's pixels of that whole frame with the rows they
+    cover -- main() compares them with a frame of the timed loop."""
     from oracle import oracle_py as orc
     o = orc.OracleScene(spec)
     H = spec.height
@@ -295,16 +299,29 @@ def cpu_baseline(spec, budget_s=12.0):
         if dt >= budget_s * 0.8 or rows < H:
             break
     nt = min(os.cpu_count() or 1, 16)
+    # all cores: the whole frame when that fits about the same budget (a C5 frame takes ~4 s on 16 cores), else the same rows
+    est_whole = probe * (H / 4.0) / max(nt * 0.8, 1.0)
+    rows_m = (0, H) if est_whole <= 3.0 * budget_s else (r0, r0 + rows)
     t0 = time.perf_counter()
-    rays_m = 0
-    for _ in range(reps):
-        _, _, stm = o.render(nthreads=nt, rows=(r0, r0 + rows), want_float=False)
-        rays_m += stm["rays_closest"] + stm["rays_shadow"]
+    rgba_m, _, stm = o.render(nthreads=nt, rows=rows_m, want_float=False)
     dtm = time.perf_counter() - t0
-    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": "rows %d..%d of the %dx%d frame x%d (%d rays, %.1f s) of %s: oracle/ (C++ restatement of the C# path), single thread as the shipped reference (RayTracer.cs:99)"
-                      % (r0, r0 + rows, spec.width, H, reps, rays, dt, spec.name),
-            "value_all_cores": round(rays_m / dtm / 1e6, 4), "cores_all": nt}
+    rays_m = stm["rays_closest"] + stm["rays_shadow"]
+    block = {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+             "sample": "rows %d..%d of the %dx%d frame x%d (%d rays, %.1f s) of %s: oracle/ (C++ restatement of the C# path), single thread as the shipped reference (RayTracer.cs:99)"
+                       % (r0, r0 + rows, spec.width, H, reps, rays, dt, spec.name),
+             "value_all_cores": round(rays_m / dtm / 1e6, 4), "cores_all": nt,
+             "sample_all_cores": "rows %d..%d (%d rays, %.1f s)" % (rows_m[0], rows_m[1], rays_m, dtm)}
+    return block, rgba_m, rows_m
+
+
+def parity_block(last_frame, oracle_rgba, rows, width):
+    """The headline checks itself: rows `rows` of a frame the timed loop's own render objects produced (read back after the
+    timed region) against the oracle's pixels of the same rows -- RGBA8, bit for bit."""
+    a = last_frame.reshape(-1, width)[rows[0]:rows[1]]
+    b = oracle_rgba.reshape(-1, width)[rows[0]:rows[1]]
+    bad = int((a != b).sum())
+    return {"parity_rows": [int(rows[0]), int(rows[1])], "parity_ok": bad == 0, "parity_mismatched_pixels": bad,
+            "parity_what": "rows of the LAST frame of the timed region (pipelined, two in flight) vs the CPU oracle's render of the same rows, RGBA8 bit for bit"}
 
 
 def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_frame, serial=None):
@@ -399,7 +416,7 @@ def main():
     res, spec = run_config(args.config, args.scale, args.steps, args.warmup, rank, local_rank, world)
     # max over ranks of the timed region; total rays over ranks
     t = torch.tensor([res["seconds"]], dtype=torch.float64, device="cuda")
-    r = torch.tensor([float(res["rays"]), float(intersect_bytes(res["stats"])), res["ms_intersect"], float(res["launches"])],
+    r = torch.tensor([float(res["rays"]), float(intersect_bytes(res["stats"])), res["ms_intersect"], float(res["launches"]), float(res["stats"]["rays_traversed"])],
                      dtype=torch.float64, device="cuda")
     if world > 1:
         if dist.get_backend() != "nccl":
@@ -412,7 +429,9 @@ def main():
     seconds = float(t.item())
     rays_frame = float(rsum[0].item())
     value = rays_frame * args.steps / seconds / 1e6
+    trav_frame = float(rsum[4].item())   # queries handed to the traversal kernels (xrt_stats.rays_traversed): the rest are primary rays that miss the scene's root box
 
+    parity_failed = False
     if rank == 0:
         st = res["stats"]
         metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
@@ -435,7 +454,10 @@ def main():
             "config": {"workload": WORKLOADS[args.config], "width": res["width"], "height": res["height"], "triangles": res["tris"],
                        "instances": res["instances"], "rays_per_frame": int(rays_frame),
                        "rays_closest_per_frame": int(st["rays_closest"]) if world == 1 else None, "rays_shadow_per_frame": int(st["rays_shadow"]) if world == 1 else None,
+                       "rays_traversed_per_frame": int(trav_frame),
+                       "rays_answered_by_raygen_per_frame": int(rays_frame - trav_frame),
                        "parallelism": "image tiles 64x8 round-robin x%d" % world, "scene_build_s": round(res["build_s"], 3)},
+            "Mrays_per_s_traversed": round(trav_frame * args.steps / seconds / 1e6, 3),
             "roofline": roofline_block(args.config if world == 1 else "(N > 1: no PMC pass)", bytes_per_launch, ms_per_launch, launches // max(args.steps, 1), serial),
         }
         if world == 1 and not args.no_host and args.scale == 1.0:
@@ -467,8 +489,34 @@ def main():
                 del tracer_b, outb
             except Exception as e:
                 line["ms_per_step_blocking"] = None
+        if world == 1 and args.scale == 1.0:
+            try:   # THE seam, literally (RT:103-126): one blocking xrt_render per frame, ending in the host's Color[] (page-locked)
+                _, tracer_x = xrt.configs.build_product(spec, device=local_rank)
+                hostb = np.zeros(spec.width * spec.height, dtype=np.uint32)
+                lib = xrt.abi.lib()
+                xrt.abi.check(lib.xrt_host_register(C.c_void_p(hostb.ctypes.data), hostb.nbytes))
+                try:
+                    fx = tracer_x.PrepareHost(hostb)
+                    for _ in range(3):
+                        fx.end(fx.begin())
+                    kb = max(2, min(args.steps, 10))
+                    t0 = time.perf_counter()
+                    for _ in range(kb):
+                        fx.end(fx.begin())   # begin + end back to back = the blocking call: nothing else in flight
+                    line["ms_per_step_blocking_host"] = round((time.perf_counter() - t0) / kb * 1e3, 4)
+                    if res.get("last_frame") is not None:
+                        line["blocking_host_equals_timed_frame"] = bool(np.array_equal(hostb, res["last_frame"]))
+                finally:
+                    lib.xrt_host_unregister(C.c_void_p(hostb.ctypes.data))
+                del tracer_x
+            except Exception as e:
+                line["ms_per_step_blocking_host"] = None
+                line["blocking_host_error"] = str(e)[:200]
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(spec)
+            line["cpu_baseline"], oracle_rgba, oracle_rows = cpu_baseline(spec)
+            if res.get("last_frame") is not None:
+                line.update(parity_block(res["last_frame"], oracle_rgba, oracle_rows, spec.width))
+                parity_failed = not line["parity_ok"]
         if world == 1 and not args.no_extra and args.scale == 1.0:
             other = {}
             for name, k in (("C2", 20), ("C3", 5), ("C4", 3), ("G1", 5)):   # G1: the scene the reference's own Stopwatch would time (Game1.cs)
@@ -489,6 +537,10 @@ def main():
                     other[name] = {"error": str(e)[:200]}
             line["other_configs"] = other
         print(json.dumps(line))
+        sys.stdout.flush()
+        if parity_failed:
+            print("bench.py: the timed loop's frame differs from the oracle in %d pixels of rows %s: the measurement is void"
+                  % (line["parity_mismatched_pixels"], line["parity_rows"]), file=sys.stderr)
         try:   # per-run metrics file: the line plus the frame's accounting
             mdir = os.environ.get("XRT_METRICS_DIR", os.path.join(ROOT, "gpurun_out"))
             os.makedirs(mdir, exist_ok=True)
@@ -500,6 +552,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and parity_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define XRT_VERSION 200
+#define XRT_VERSION 201
 
 /* error codes (C# shim: BUSY -> InvalidOperationException (RT:26-27,62-63),
  * INVALID_ARG -> ArgumentException (SO:123-124, MAT:85,97)) */
@@ -169,6 +169,10 @@ typedef struct xrt_stats {
                                      on the launches otherwise, or always with XRT_LAUNCH_EVENTS=1 */
     uint32_t intersect_launches;
     uint32_t pieces;              /* the frame was rendered in this many concurrent pieces (halves on two streams, GPUs); 1 otherwise */
+    uint64_t rays_traversed;      /* queries (of rays_closest + rays_shadow) that were handed to the traversal kernels: all of them except
+                                     the primary rays the ray-generation kernel answers itself because they cannot reach the scene
+                                     octree's root box (OSM:318-320 returns false for them before any node is visited).  Not a
+                                     counter of the reference: how much of the ray count is real traversal work on this library */
 } xrt_stats;
 
 /* Flattened octree node for inspection by tests (mirrors the private CubeNode, MO:32-40 / OSM:37-48). */

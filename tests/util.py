@@ -209,7 +209,8 @@ def build_c_host():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src, exe = os.path.join(root, "tests", "c_host", "c_host.c"), os.path.join(root, "tests", "c_host", "c_host")
     lib = os.path.join(root, "xna-ray-trace_amd", "csrc")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    hdr = os.path.join(root, "include", "xrt.h")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), src, "-L", lib, "-lxrt",
                                "-Wl,-rpath," + lib, "-o", exe])
     return exe

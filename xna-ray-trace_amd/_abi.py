@@ -67,7 +67,7 @@ class xrt_stats(C.Structure):
         "rays_closest", "rays_shadow", "hits_closest", "hits_shadow", "scene_node_tests", "instance_visits",
         "mesh_aabb_tests", "mesh_queries", "node_tests", "leaf_refs", "tri_tests", "shaded_hits", "pixels",
         "algorithmic_bytes")] + [("ms_total", C.c_double), ("ms_intersect", C.c_double),
-                                 ("intersect_launches", C.c_uint32), ("pieces", C.c_uint32)]
+                                 ("intersect_launches", C.c_uint32), ("pieces", C.c_uint32), ("rays_traversed", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -79,7 +79,7 @@ class xrt_node_info(C.Structure):
 
 
 assert C.sizeof(xrt_ray) == 32 and C.sizeof(xrt_hit) == 48 and C.sizeof(xrt_render_opts) == 48
-XRT_VERSION = 200
+XRT_VERSION = 201
 
 # every symbol include/xrt.h declares: name -> (restype, argtypes)
 _P = C.POINTER

@@ -1083,6 +1083,7 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
             hcnt[C_COUNT + C_RAYS] = F.shaded * (unsigned long long)F.nL;
         }
         fill_stats(stats, hcnt, F.shaded, F.validPixels);
+        stats->rays_traversed = stats->rays_closest + stats->rays_shadow - (F.livePaths - F.live0);   // all but the primary rays k_raygen answered
         if (!F.collect) stats->algorithmic_bytes = 0;   // needs the counting pass
         float ms = 0;
         HIPCHECK(hipEventElapsedTime(&ms, F.events[0], F.events[1]));
@@ -1236,6 +1237,7 @@ void add_stats(xrt_stats &acc, const xrt_stats &st, bool first) {
     if (st.ms_intersect > acc.ms_intersect) acc.ms_intersect = st.ms_intersect;
     if (first) acc.intersect_launches = st.intersect_launches;
     acc.pieces += 1;
+    acc.rays_traversed += st.rays_traversed;
 }
 
 int multi_end(xrt_scene *s, int slot, int n, xrt_stats *stats) {
@@ -1394,6 +1396,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
         unsigned long long hcnt[2 * C_COUNT];
         HIPCHECK(hipMemcpy(hcnt, s->counters.p, sizeof(hcnt), hipMemcpyDeviceToHost));
         fill_stats(stats, hcnt, 0, 0);
+        stats->rays_traversed = stats->rays_closest + stats->rays_shadow;
         float ms = 0;
         if (n > 0) HIPCHECK(hipEventElapsedTime(&ms, a0, a1));
         stats->ms_total = ms; stats->ms_intersect = ms; stats->intersect_launches = n > 0 ? 1 : 0;
