@@ -749,17 +749,10 @@ def test_scheduling_switches_never_change_results(xrt, monkeypatch, env):
 
 
 # 32 committed seeds in the default run; XRT_FUZZ_EXTRA=n adds n more scenes
-FUZZ_SEEDS = [101, 202, 303, 404, 505, 606, 707, 808, 909, 1111, 1212, 1313, 1414, 1515, 1616, 1717, 1818, 1919, 2020, 2121, 2222, 2323, 2424, 2525,
-              2626, 2727, 2828, 2929, 3030, 3131, 3232, 3333] + list(range(5000, 5000 + int(os.environ.get("XRT_FUZZ_EXTRA", "0"))))
-
-
-@pytest.mark.parametrize("seed", FUZZ_SEEDS)
-def test_random_scenes_against_the_oracle(xrt, orc, seed):
-    """Fuzz: random bodies (1-7) of random triangle soups (one to three meshes each, 20-600 triangles, leaf thresholds
-    2-40) under random rotations, non-uniform scales and translations; rays from outside, from inside the boxes, exactly
-    axis-parallel, with zero and non-finite components, and the secondary rays of the hits.  Hit triangle, leaf, u/v/d
-    and world position bit for bit; one small frame with every shading term."""
-    rng = np.random.default_rng(seed)
+def fuzz_spec(xrt, seed, rng=None):
+    """Random bodies (1-7) of random triangle soups (one to three meshes each, 20-600 triangles, leaf thresholds 2-40) under
+    random rotations, non-uniform scales and translations."""
+    rng = rng if rng is not None else np.random.default_rng(seed)
     s = xrt.configs.SceneSpec("fuzz%d" % seed)
     n_mesh = int(rng.integers(1, 4))
     for m in range(n_mesh):
@@ -774,7 +767,21 @@ def test_random_scenes_against_the_oracle(xrt, orc, seed):
     s.camera = xrt.configs.camera((0, 9, 17), (0, 0, 0))
     s.lights = [xrt.configs.spot((3, 20, 12)), xrt.configs.directional((0.2, 0.9, 0.3), (0.5, 0.5, 0.4), 0.6)]
     s.max_reflections = 2
-    s = s.with_size(96, 54)
+    return s.with_size(96, 54)
+
+
+FUZZ_SEEDS = [101, 202, 303, 404, 505, 606, 707, 808, 909, 1111, 1212, 1313, 1414, 1515, 1616, 1717, 1818, 1919, 2020, 2121, 2222, 2323, 2424, 2525,
+              2626, 2727, 2828, 2929, 3030, 3131, 3232, 3333] + list(range(5000, 5000 + int(os.environ.get("XRT_FUZZ_EXTRA", "0"))))
+
+
+@pytest.mark.parametrize("seed", FUZZ_SEEDS)
+def test_random_scenes_against_the_oracle(xrt, orc, seed):
+    """Fuzz: random bodies (1-7) of random triangle soups (one to three meshes each, 20-600 triangles, leaf thresholds
+    2-40) under random rotations, non-uniform scales and translations; rays from outside, from inside the boxes, exactly
+    axis-parallel, with zero and non-finite components, and the secondary rays of the hits.  Hit triangle, leaf, u/v/d
+    and world position bit for bit; one small frame with every shading term."""
+    rng = np.random.default_rng(seed)
+    s = fuzz_spec(xrt, seed, rng)
     try:
         scene, tracer = xrt.configs.build_product(s)
     except xrt.abi.XrtError as e:
@@ -1151,6 +1158,107 @@ def test_wave_packet_kernel_against_the_oracle(xrt, orc, monkeypatch):
     _, tracer = xrt.configs.build_product(spec)
     o_rgba, _, _ = orc.OracleScene(spec).render(nthreads=8, want_float=False)
     assert np.array_equal(tracer.Render(), o_rgba)
+
+
+def test_scene_packets_against_the_oracle(xrt, orc, monkeypatch):
+    """k_packet<MODE_SCENE> (packet.hip): one wavefront walks the SCENE octree, the bodies of its leaves and each body's mesh
+    octree once for 64 rays (OSM:312-455 -> MO:259-353).  XRT_PACKET=31 routes every ray population of two-level scenes through
+    it -- seam-1 batches included: incoherent random rays, rays from inside the bodies, axis-parallel / zero / non-finite rays,
+    rays leaving surfaces with an ignored triangle, and the pre-cull's far-origin and grazing rays -- the worst cases for a packet,
+    and it must still give the reference's answers bit for bit (object, mesh, triangle, leaf id, u/v/d, world position); bodies
+    that share meshes, meshes whose octree root is a leaf (MO:265 with a single bucket), rotated / non-uniformly scaled bodies,
+    two meshes per body; frames with 1 and 16 sub-rays equal the oracle's."""
+    from util import far_origin_scene, far_origin_rays, precull_adversarial_scene, grazing_rays
+    monkeypatch.setenv("XRT_PACKET", "31")
+    specs = {}
+    s = xrt.configs.SceneSpec("inst")
+    s.meshes.append((xrt.fixtures.crate(3), xrt.configs.material(0.5, texture=xrt.fixtures.crate_texture())))
+    s.meshes.append((triangle_soup(80, 11, 0.4), xrt.configs.material(0.2, interpolate_normals=True)))
+    s.meshes.append((xrt.fixtures.crate(1), xrt.configs.material(0.6)))   # 12 triangles: the octree root is a leaf
+    k = 0
+    for ix in range(5):
+        for iz in range(5):
+            ids = [[0], [0, 1], [2], [2, 0]][k % 4]
+            s.objects.append((ids, (-60.0 + 30.0 * ix, 2.0 * (k % 2), -60.0 + 30.0 * iz), (0.1 * ix, 0.37 * iz, 0.05 * (ix + iz)), (1.0 + 0.1 * ix, 1.0, 0.8 + 0.1 * iz)))
+            k += 1
+    s.camera = xrt.configs.camera((0, 80, 160), (0, 0, 0))
+    s.lights = [xrt.configs.spot((0, 100, 100)), xrt.configs.directional((0.3, 0.8, 0.5), (0.4, 0.5, 0.6), 0.7)]
+    s.max_reflections = 3
+    specs["inst"] = s.with_size(160, 90)
+    specs["grid"] = xrt.configs.crate_grid_scene(160, 90)
+    three = xrt.configs.SceneSpec("leaf_roots")
+    three.meshes.append((xrt.fixtures.crate(1), xrt.configs.material(0.5)))
+    for i in range(3):
+        three.objects.append(([0], (-20.0 + 20.0 * i, 0.0, 3.0 * i), (0.0, 0.5 * i, 0.0), (1.0, 1.0 + 0.2 * i, 1.0)))
+    three.camera = xrt.configs.camera((0, 32, 64), (0, 8, 0))
+    three.lights = [xrt.configs.spot((0, 40, 60))]
+    three.max_reflections = 2
+    specs["leaf_roots"] = three.with_size(128, 72)
+    for seed in (101, 404, 909, 1717, 2626):
+        fs = fuzz_spec(xrt, seed)
+        if fs is not None:
+            specs["fuzz%d" % seed] = fs
+    nan = float("nan")
+    for name, spec in specs.items():
+        try:
+            scene, tracer = xrt.configs.build_product(spec)
+        except xrt.abi.XrtError as e:
+            assert "would not terminate" in str(e)
+            continue
+        o = orc.OracleScene(spec)
+        first_use = []
+        for ids, _, _, _ in spec.objects:
+            first_use += [i for i in ids if i not in first_use]
+        to_spec = np.array(first_use + [-1], dtype=np.int32)
+        inv = {v: i for i, v in enumerate(first_use)}
+
+        def product_hits(r):
+            h = scene.IntersectBatch(r).copy()
+            h["mesh"] = np.where(h["hit"] != 0, to_spec[np.clip(h["mesh"], 0, len(first_use))], h["mesh"])
+            return h
+        prim = o.primary_rays()
+        radius = 12.0 if name.startswith("fuzz") else 150.0
+        def wide_rays(n, seed, r):   # origins on a sphere of radius r, aimed anywhere into the scene (random_rays aims at the origin)
+            g = np.random.default_rng(seed)
+            oo = g.normal(size=(n, 3)).astype(np.float32)
+            oo *= (r / np.linalg.norm(oo, axis=1, keepdims=True)).astype(np.float32)
+            dd = g.uniform(-0.6 * r, 0.6 * r, size=(n, 3)).astype(np.float32) * np.array([1.0, 0.1, 1.0], dtype=np.float32) - oo
+            dd /= np.linalg.norm(dd, axis=1, keepdims=True).astype(np.float32)
+            return xrt.rays_array(oo, dd.astype(np.float32))
+        sets = [prim, wide_rays(20000, 5, radius), wide_rays(6000, 6, radius * 0.3), random_rays(xrt, 4000, 7, radius=radius)]
+        sets.append(xrt.rays_array([(0, 50, 0), (0, 50, 0), (0, 50, 0), (1e30, 0, 0), (0, 50, 0), (0, 4.0, 0), (0, 2, 0), (1, 2, 1)] * 9,
+                                   [(0, 0, 0), (nan, -1, 0), (0, -1, 0), (-1, 0, 0), (1e-7, -1, 1e-7), (0, 1, 0), (1, 0, 0), (0, 0, -1)] * 9))
+        for rays in sets:
+            ho = o.intersect(rays)
+            assert hits_equal(ho, product_hits(rays)) == {}, name
+            sec = secondary_rays(xrt, ho, seed=4)
+            if len(sec):
+                sec_p = sec.copy()
+                sec_p["ignore_mesh"] = np.array([inv.get(int(m), -1) for m in sec["ignore_mesh"]], dtype=np.int32)
+                assert hits_equal(o.intersect(sec), product_hits(sec_p)) == {}, name
+        rgba, rgbf = tracer.Render(want_float=True)
+        o_rgba, o_rgbf, o_st = o.render(nthreads=8)
+        assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+        for k in ("rays_closest", "rays_shadow", "hits_closest", "shaded_hits"):
+            assert tracer.last_stats[k] == o_st[k], (name, k)
+        import copy
+        s16 = copy.deepcopy(spec).with_size(64, 36)
+        s16.multisampling = xrt.abi.MS_FIXED16
+        _, tr16 = xrt.configs.build_product(s16)
+        o16, _, _ = orc.OracleScene(s16).render(nthreads=8, want_float=False)
+        assert np.array_equal(tr16.Render(), o16), name
+    # the object pre-cull's adversarial rays through the packet kernel (it applies the same margin, traverse.h precull_hit)
+    s = far_origin_scene(xrt)
+    scene, _ = xrt.configs.build_product(s)
+    o = orc.OracleScene(s)
+    for radius, seed in ((1e3, 1), (1e4, 2), (1e5, 3)):
+        rays = far_origin_rays(xrt, s, radius, 2000, seed)
+        assert hits_equal(o.intersect(rays), scene.IntersectBatch(rays)) == {}, radius
+    s = precull_adversarial_scene(xrt)
+    scene, _ = xrt.configs.build_product(s)
+    o = orc.OracleScene(s)
+    rays = grazing_rays(xrt, s, 6000, 11)
+    assert hits_equal(o.intersect(rays), scene.IntersectBatch(rays)) == {}
 
 
 def test_changing_frame_parameters_between_pipelined_frames(xrt):

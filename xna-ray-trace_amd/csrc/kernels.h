@@ -80,7 +80,7 @@ struct PacketArgs {
     int cullMin = 4;              // leaves of at least this many references are tested against their tight box first (the test costs about two triangles)
     unsigned long long *stamps = nullptr;   // this launch's row of device-clock stamps (device_util.h), or null
 };
-bool packet_supported(int mode, int meshDepth);
+bool packet_supported(int mode, int meshDepth, int sceneDepth);
 int  packet_blocks_per_cu(int mode);
 void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 

@@ -104,39 +104,9 @@ __device__ __forceinline__ int block_append(int *counter, bool flag, int *ldsCou
 // ---- the hot kernel ------------------------------------------------------------------------------------------
 
 // Scene mode keeps the scene-level half of every lane's query (SceneLane, 27 words: world ray, scene cursor, best answer
-// so far) in LDS: only advance_scene and the final answer touch it, through these proxies, one word at a time where it
-// is needed.  The node and leaf loops then fit the 128-register budget of four waves per SIMD without scratch traffic.
-// Layout [word][lane] -- one bank per lane, like the traversal stack.
-template <class T>
-struct LdsField {
-    unsigned *p;
-    __device__ __forceinline__ operator T() const { T v; __builtin_memcpy(&v, p, 4); return v; }
-    __device__ __forceinline__ LdsField &operator=(T v) { __builtin_memcpy(p, &v, 4); return *this; }
-    __device__ __forceinline__ LdsField &operator=(const LdsField &o) { *p = *o.p; return *this; }
-    __device__ __forceinline__ T operator++(int) { T v = *this; *this = v + 1; return v; }
-    __device__ __forceinline__ T operator--() { T v = (T)(*this) - 1; *this = v; return v; }
-    __device__ __forceinline__ LdsField &operator&=(T m) { *this = (T)(*this) & m; return *this; }
-};
-struct LdsRay {
-    unsigned *p;   // 9 words, stride 64 (the parallel-axis bits are recomputed from the direction)
-    __device__ __forceinline__ operator RayPre() const {
-        RayPre r;
-        r.o = mk(i2f((int)p[0]), i2f((int)p[64]), i2f((int)p[128]));
-        r.d = mk(i2f((int)p[192]), i2f((int)p[256]), i2f((int)p[320]));
-        r.inv = mk(i2f((int)p[384]), i2f((int)p[448]), i2f((int)p[512]));
-        r.par = (fabsf(r.d.x) < 1e-06f ? 1 : 0) | (fabsf(r.d.y) < 1e-06f ? 2 : 0) | (fabsf(r.d.z) < 1e-06f ? 4 : 0);   // as make_ray
-        return r;
-    }
-    __device__ __forceinline__ LdsRay &operator=(const RayPre &r) {
-        p[0] = (unsigned)f2i(r.o.x); p[64] = (unsigned)f2i(r.o.y); p[128] = (unsigned)f2i(r.o.z);
-        p[192] = (unsigned)f2i(r.d.x); p[256] = (unsigned)f2i(r.d.y); p[320] = (unsigned)f2i(r.d.z);
-        p[384] = (unsigned)f2i(r.inv.x); p[448] = (unsigned)f2i(r.inv.y); p[512] = (unsigned)f2i(r.inv.z);
-        return *this;
-    }
-};
-__device__ __forceinline__ void ray_axis(const LdsRay &w, int k, float &o, float &d, float &inv) {
-    o = i2f((int)w.p[64 * k]); d = i2f((int)w.p[64 * (3 + k)]); inv = i2f((int)w.p[64 * (6 + k)]);
-}
+// so far) in LDS: only advance_scene and the final answer touch it, through the proxies of device_util.h (LdsField, LdsRay), one
+// word at a time where it is needed.  The node and leaf loops then fit the 128-register budget of four waves per SIMD without
+// scratch traffic.  Layout [word][lane] -- one bank per lane, like the traversal stack.
 constexpr int PARK_WORDS = 27;
 struct ParkedScene {
     LdsRay w;

@@ -1,23 +1,35 @@
-// packet.hip — k_packet: wave-packet form of MeshOctree.GetRayIntersection (MO:259-353) for COHERENT ray populations
-// (primary rays of neighbouring pixels / sub-samples, shadow rays towards one light): gfx950, wave64.
+// packet.hip — k_packet: wave-packet form of ISpatialManager.GetRayIntersection (OSM:312-455) -> MeshOctree.GetRayIntersection
+// (MO:259-353) for COHERENT ray populations (primary rays of neighbouring pixels / sub-samples, shadow rays towards one light, the
+// first reflections off flat surfaces): gfx950, wave64.
 //
 // k_intersect gives every lane its own walk: its own stack, block descriptor, pending masks, parent box.  For rays that
 // go the same way that is ~50 registers of state per lane repeating what the neighbour holds, lanes of one wave wait for
-// each other in different phases (utilisation 0.4-0.6), and four waves per SIMD are all the registers allow.  Here ONE
-// wavefront walks the octree once for its 64 rays:
+// each other in different phases (utilisation 0.4-0.6), every step of a lane's walk is a dependent vector load (block descriptor,
+// body record, leaf records, triangles: a chain of 100-500 cycle round trips that four waves per SIMD cannot hide -- C3's waves
+// spent 52 % of their life parked on memory), and four waves per SIMD are all the registers allow.  Here ONE wavefront walks the
+// octrees once for its 64 rays:
 //   * wave-uniform state (SGPRs / one LDS frame per level): current block, its descriptor, the parent box, the lanes that
-//     are inside it, the position in the child order;
+//     are inside it, the position in the child order; everything the walk reads is the same for all lanes and arrives through the
+//     scalar cache (s_load), requested ahead of its use;
 //   * per lane only the ray, its best answer so far and one byte per level (which children of that level's block the
 //     ray's own box tests accepted);
 //   * a child is visited when ANY lane of the current set passed its box test (MO:331 -- hit8_*_children evaluates the
 //     reference's test for all eight children of a block); lanes that did not are masked off for that subtree, as are
 //     lanes the bucket rule lets prune it (key above the lane's best key on a `safe` interior node or a leaf);
 //   * in a leaf every remaining lane tests every triangle (RE:42-75): the triangle is the same for all lanes, so its
-//     16 + 36 bytes arrive through the scalar cache (s_load) and the vector units only do arithmetic.
+//     16 + 36 bytes arrive through the scalar cache and the vector units only do arithmetic.
 // Each lane therefore performs exactly the (leaf, triangle) tests its own walk in k_intersect could perform, minus ones
 // that cannot win, and keeps the lexicographic arg-min (leaf entry key, distance, leaf DFS index, list position) -- the
 // order-independent form of MO:281-301: bit-identical answers, in any visiting order.
 // Lanes with a parallel axis or a non-finite component take the literal box test (`slab`) inside the same walk.
+//
+// MODE_SCENE (two-level scenes, OSM:312-455): the scene octree is walked wave-uniformly too, in the reference's DFS order (the
+// scene-level rule is the streaming one, traverse.h merge_mesh_result: the order of the visits matters there and every lane sees
+// its own visits in the order its own walk would make them).  A scene node is visited by the lanes whose own box test (OSM:460)
+// accepted it and all its ancestors; a body of a leaf by the lanes of that leaf the world-space pre-cull (traverse.h precull_hit)
+// does not exclude -- its record is one scalar load for the whole wave, where the per-lane kernel pays two dependent vector loads
+// per lane and body -- ; those lanes transform their ray into the body's space (OSM:349-364), test the mesh boxes (MESH:34-39) and
+// share one walk of the mesh octree; a lane's answer for the body is merged into its scene-level best as OSM:370-378 does.
 #include "device_util.h"
 #include "kernels.h"
 
@@ -27,6 +39,8 @@ namespace xrt {
 
 constexpr int PK_LEVELS = 24;        // deeper octrees than this fall back to k_intersect (scene_build limits depth to 20)
 constexpr int PK_FRAME_WORDS = 12;   // blk, next child position, order mask, lanes (2), parent box min (3), half (3), pad
+constexpr int PK_SLEVELS = 12;       // scene octree levels a packet can stack (deeper scene trees: k_intersect)
+constexpr int PK_SFRAME_WORDS = 4;   // scene block, pending children, lanes (2)
 constexpr int PK_SGPRS = 112;        // SGPR allocation the kernel may reach (checked against the ISA in tests/test_numerics_contract.py)
 
 struct PkUniform {   // wave-uniform cursor
@@ -39,11 +53,225 @@ struct alignas(4) TriWords { float w[16]; };   // a 13-word record of refT and t
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float rflf(float v) { return i2f(__builtin_amdgcn_readfirstlane(f2i(v))); }
 
+// MO:288-304 for the lanes selected by the caller (exec), over the references r0 .. r1-1 of one leaf.  The triangle is the same
+// for every lane: normals and geometry come through the scalar cache.  Two register sets take turns, and a triangle's 52 bytes are
+// requested before the previous one's arithmetic starts (the records of a leaf are back to back; the arrays end in two dummy
+// records, so asking one past the leaf is safe).  One record of 13 words (refT: normal, id, v1, E1, E2) = one s_load_dwordx16
+// (the three words past it belong to the next record; the array ends in padding): the scalar unit is this kernel's scarce
+// resource, and a triangle used to cost three loads from two streams.  `keyed`: L.leafKey holds the leaf's entry key already;
+// otherwise entry_key() is evaluated by the lanes that find a candidate.
+template <class KeyFn>
+__device__ __forceinline__ void pk_scan_leaf(const float *__restrict__ refT, int r0, int r1, Lane &L, const SceneView &S, bool keyed, KeyFn entry_key) {
+    const char *pt = reinterpret_cast<const char *>(refT) + (size_t)r0 * TRI_REC_BYTES;
+    auto test = [&](const TriWords &q, int r) {
+        const bool f = !(facing(mk(q.w[0], q.w[1], q.w[2]), L.r.d) > 0.0f) & (f2i(q.w[3]) != L.ignoreId);   // RE:48-51, MO:290
+        v3 T; float det, row2;
+        const v3 gb = mk(q.w[7], q.w[8], q.w[9]), gc = mk(q.w[10], q.w[11], q.w[12]);
+        const bool sA = tri_stage_a(L.r.o, L.r.d, mk(q.w[4], q.w[5], q.w[6]), gb, gc, T, det, row2) & f;
+        if (sA) {   // one wave-level branch per triangle (s_cbranch_execz): most are rejected by the sign of u for every lane
+            float u, v, t;
+            if (tri_stage_b(L.r.d, gb, gc, T, det, row2, u, v, t)) {
+                if (!keyed) L.leafKey = entry_key();
+                leaf_candidate(L, S, r, -2, true, u, v, t);   // (the ignored triangle was filtered above: -2 matches no id)
+            }
+        }
+    };
+    TriWords qA = *reinterpret_cast<const TriWords *>(pt);
+    int r = r0;
+    for (;;) {
+        const TriWords qB = *reinterpret_cast<const TriWords *>(pt + TRI_REC_BYTES);
+        test(qA, r);
+        if (r + 1 >= r1) break;
+        qA = *reinterpret_cast<const TriWords *>(pt + 2 * TRI_REC_BYTES);
+        test(qB, r + 1);
+        r += 2; pt += 2 * TRI_REC_BYTES;
+        if (r >= r1) break;
+    }
+}
+
+// One shared walk of the mesh octree whose root block is `rootBlock` (parent box rmin .. rmax) for the lanes `lanes0`: the lanes
+// whose ray passed the root's own box test (MO:265 / MO:331).  On return every lane's L.mfound / mKey / mDist / mU / mV / mRef /
+// mLeaf hold its answer of MeshOctree.GetRayIntersection (the caller cleared mfound).
+__device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const float *__restrict__ refT, const f4 *__restrict__ leafNB,
+                                        const f4 *__restrict__ leafTB, const SceneView &S, int cullMin, unsigned *stk, int lane, Lane &L,
+                                        const RayCull &RC, bool fastL, int rootBlock, v3 rmin, v3 rmax, unsigned long long lanes0) {
+    PkUniform U;
+    U.blk = rootBlock;
+    U.bmin = rmin;
+    U.half = half_of(rmin, rmax);
+    U.lanes = lanes0;
+    U.p = 0; U.dm0 = 0;
+    // per lane: for every level of the shared stack, which children of that level's block the lane's own box tests accepted
+    unsigned long long cbLo = 0, cbMid = 0, cbHi = 0;
+    int sp = 0;
+    bool entering = true, anyFound = false;   // anyFound: some lane of the wave has a candidate
+    int d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+    unsigned long long offLo = 0, offHi = 0;
+    int cb = 0;
+    // The scalar unit is shared by the CU's four SIMDs, so scalar instructions are the scarce resource of this kernel
+    // (measured: 3,900 per packet against 4,000 vector ones made it scalar-bound): the pending children are a bit mask
+    // walked with ctz, the lanes of a leaf are selected once for the whole leaf, a triangle costs one wave-level branch.
+    while (U.lanes != 0ull) {
+        const bool in = ((U.lanes >> lane) & 1ull) != 0;
+        if (entering) {
+            const f4 lo = blocks[2 * (size_t)U.blk], hi = blocks[2 * (size_t)U.blk + 1];
+            d0 = f2i(lo.x); d1 = f2i(lo.y); d2 = f2i(lo.z); d3 = f2i(lo.w);
+            offLo = (unsigned long long)(unsigned)f2i(hi.x) | ((unsigned long long)(unsigned)f2i(hi.y) << 32);
+            offHi = (unsigned long long)(unsigned)f2i(hi.z) | ((unsigned long long)(unsigned)f2i(hi.w) << 32);
+            cb = 0;
+            if (in) cb = fastL ? hit8_fast_children(L.r, L.dmask, U.bmin, U.half) : hit8_slow_children(L.r, U.bmin, U.half);
+            cb &= 0xff & ~((d2 >> 8) & 0xff);   // empty leaves can never hit (Q4)
+            {   // remember it for the return to this level
+                const int sh = (sp & 7) * 8;
+                const unsigned long long m = ~(0xffull << sh), v = (unsigned long long)(unsigned)cb << sh;
+                if (sp < 8) cbLo = (cbLo & m) | v; else if (sp < 16) cbMid = (cbMid & m) | v; else cbHi = (cbHi & m) | v;
+            }
+            U.dm0 = __builtin_amdgcn_readlane(L.dmask, (int)__builtin_ctzll(U.lanes));   // front-to-back order of the first lane
+            // children some lane entered, in that order: bit p <-> child (p ^ dm0)
+            int un = wave_or(cb);
+            if (U.dm0 & 4) un = ((un & 0xf0) >> 4) | ((un & 0x0f) << 4);
+            if (U.dm0 & 2) un = ((un & 0xcc) >> 2) | ((un & 0x33) << 2);
+            if (U.dm0 & 1) un = ((un & 0xaa) >> 1) | ((un & 0x55) << 1);
+            U.p = un;
+            entering = false;
+        }
+        if (U.p == 0) {   // block exhausted: back to the level above
+            if (sp == 0) break;
+            sp--;
+            const unsigned *f = stk + sp * PK_FRAME_WORDS;
+            U.blk = rfl((int)f[0]); U.p = rfl((int)f[1]); U.dm0 = rfl((int)f[2]);
+            U.lanes = (unsigned long long)(unsigned)rfl((int)f[3]) | ((unsigned long long)(unsigned)rfl((int)f[4]) << 32);
+            U.bmin = mk(rflf(i2f((int)f[5])), rflf(i2f((int)f[6])), rflf(i2f((int)f[7])));
+            U.half = mk(rflf(i2f((int)f[8])), rflf(i2f((int)f[9])), rflf(i2f((int)f[10])));
+            const f4 lo = blocks[2 * (size_t)U.blk], hi = blocks[2 * (size_t)U.blk + 1];
+            d0 = f2i(lo.x); d1 = f2i(lo.y); d2 = f2i(lo.z); d3 = f2i(lo.w);
+            offLo = (unsigned long long)(unsigned)f2i(hi.x) | ((unsigned long long)(unsigned)f2i(hi.y) << 32);
+            offHi = (unsigned long long)(unsigned)f2i(hi.z) | ((unsigned long long)(unsigned)f2i(hi.w) << 32);
+            const int sh = (sp & 7) * 8;
+            cb = (int)(((sp < 8 ? cbLo : (sp < 16 ? cbMid : cbHi)) >> sh) & 0xffull);
+            continue;
+        }
+        const int c = (int)__builtin_ctz((unsigned)U.p) ^ U.dm0;
+        U.p &= U.p - 1;
+        const bool inC = in && ((cb >> c) & 1);
+        v3 cmin, cmax;
+        child_box(U.bmin, U.half, c, cmin, cmax);
+        // The child's own test gives the entry key (its outcome is known: hit).  The bucket rule compares keys only once a lane
+        // has a candidate; until some lane of the wave has one (most of a packet's walk) the key of a leaf is computed by the
+        // lanes that find a candidate in it, and nobody computes the key of an interior child.
+        auto entry_key = [&]() {
+            float k = 0.0f;
+            if (fastL) (void)slab_fast(L.r, L.dmask, cmin, cmax, k);
+            else (void)slab(L.r, cmin.x, cmin.y, cmin.z, cmax.x, cmax.y, cmax.z, k);
+            return k;
+        };
+        const bool keyed = anyFound;   // wave-uniform
+        float key = 0.0f;
+        if (keyed && inC) key = entry_key();
+        const int node = U.blk * 8 + c;
+        if (!((d2 >> c) & 1)) {   // ---- leaf (non-empty): MO:288-304 for the lanes the bucket rule lets in ----
+            const f4 nlo = leafNB[2 * (size_t)node], nhi = leafNB[2 * (size_t)node + 1];
+            bool go = inC && !(L.mfound && key > L.mKey) && !all_back_facing(nlo, nhi, L.r.d);
+            if (!__any(go)) continue;
+            const int r0 = d1 + child_ref_offset(offLo, offHi, c);
+            const int r1 = d1 + ((c == 7) ? d3 : child_ref_offset(offLo, offHi, c + 1));
+            if (r1 - r0 >= cullMin) {   // lanes whose ray cannot reach any triangle of the leaf (xrt_core.h leaf_certainly_missed) stay out of it
+                const f4 *tb = leafTB + 4 * (size_t)node;
+                go = go && !leaf_certainly_missed(L.r, RC, tb[0], tb[1], tb[2], tb[3]);
+                if (!__any(go)) continue;
+            }
+            if (go) {   // the lanes of this leaf, selected once for all its triangles
+                L.leafKey = key; L.leafNode = node;
+                // (kept inline: as a function of its own the same loop costs 13 more VGPRs, i.e. the sixth wave per SIMD)
+                const char *pt = reinterpret_cast<const char *>(refT) + (size_t)r0 * TRI_REC_BYTES;
+                auto test = [&](const TriWords &q, int r) {
+                    const bool f = !(facing(mk(q.w[0], q.w[1], q.w[2]), L.r.d) > 0.0f) & (f2i(q.w[3]) != L.ignoreId);   // RE:48-51, MO:290
+                    v3 T; float det, row2;
+                    const v3 gb = mk(q.w[7], q.w[8], q.w[9]), gc = mk(q.w[10], q.w[11], q.w[12]);
+                    const bool sA = tri_stage_a(L.r.o, L.r.d, mk(q.w[4], q.w[5], q.w[6]), gb, gc, T, det, row2) & f;
+                    if (sA) {   // one wave-level branch per triangle (s_cbranch_execz): most are rejected by the sign of u for every lane
+                        float u, v, t;
+                        if (tri_stage_b(L.r.d, gb, gc, T, det, row2, u, v, t)) {
+                            if (!keyed) L.leafKey = entry_key();
+                            leaf_candidate(L, S, r, -2, true, u, v, t);   // (the ignored triangle was filtered above: -2 matches no id)
+                        }
+                    }
+                };
+                TriWords qA = *reinterpret_cast<const TriWords *>(pt);
+                int r = r0;
+                for (;;) {
+                    const TriWords qB = *reinterpret_cast<const TriWords *>(pt + TRI_REC_BYTES);
+                    test(qA, r);
+                    if (r + 1 >= r1) break;
+                    qA = *reinterpret_cast<const TriWords *>(pt + 2 * TRI_REC_BYTES);
+                    test(qB, r + 1);
+                    r += 2; pt += 2 * TRI_REC_BYTES;
+                    if (r >= r1) break;
+                }
+            }
+            if (!keyed) anyFound = __any(L.mfound != 0);
+            continue;
+        }
+        // ---- interior child: a lane prunes it by key only where that is a proven lower bound (safe bit) ----
+        const bool go = inC && !(L.mfound && ((d2 >> (16 + c)) & 1) && key > L.mKey);
+        const unsigned long long LL = __ballot(go);
+        if (LL == 0ull) continue;
+        if (sp >= PK_LEVELS - 1) continue;   // (cannot happen: packet_supported checks the depth)
+        if (U.p != 0) {   // something is left to do at this level: come back
+            if (lane == 0) {
+                unsigned *f = stk + sp * PK_FRAME_WORDS;
+                f[0] = (unsigned)U.blk; f[1] = (unsigned)U.p; f[2] = (unsigned)U.dm0;
+                f[3] = (unsigned)U.lanes; f[4] = (unsigned)(U.lanes >> 32);
+                f[5] = (unsigned)f2i(U.bmin.x); f[6] = (unsigned)f2i(U.bmin.y); f[7] = (unsigned)f2i(U.bmin.z);
+                f[8] = (unsigned)f2i(U.half.x); f[9] = (unsigned)f2i(U.half.y); f[10] = (unsigned)f2i(U.half.z);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            sp++;
+        }
+        U.blk = d0 + __builtin_popcount((unsigned)(d2 & 0xff) & ((1u << c) - 1u));
+        U.bmin = cmin; U.half = half_of(cmin, cmax);
+        U.lanes = LL;
+        entering = true;
+    }
+}
+
+// Scene mode: what a lane keeps for the whole query but touches only between mesh walks -- the world ray and its scene-level best
+// answer (OSM:370-378) -- lives in LDS ([word][lane], device_util.h LdsField): the mesh walk then has the registers of the
+// one-body variants.
+constexpr int PK_PARK_WORDS = 19;
+struct PkScene {
+    LdsRay w;                       // world ray (9 words)
+    LdsField<float> sKey;           // entry key of the scene leaf being scanned (OSM:334 bucket key)
+    LdsField<int> sfound;
+    LdsField<float> sbKey, sbD, sbU, sbV;
+    LdsField<int> sbRef, sbLeaf, sbObj, sbMesh;
+    int obj;                        // (wave-uniform: the body being visited)
+    __device__ __forceinline__ explicit PkScene(unsigned *b)   // b = &park[wave][0][lane]
+        : w{b}, sKey{b + 9 * 64}, sfound{b + 10 * 64}, sbKey{b + 11 * 64}, sbD{b + 12 * 64}, sbU{b + 13 * 64}, sbV{b + 14 * 64},
+          sbRef{b + 15 * 64}, sbLeaf{b + 16 * 64}, sbObj{b + 17 * 64}, sbMesh{b + 18 * 64}, obj(-1) {}
+};
+template <int M> __device__ __forceinline__ unsigned *scene_park() {
+    if constexpr (M == MODE_SCENE) { __shared__ unsigned mem[4 * PK_PARK_WORDS * 64]; return mem; }
+    else return nullptr;
+}
+template <int M> __device__ __forceinline__ unsigned *scene_frames() {
+    if constexpr (M == MODE_SCENE) { __shared__ unsigned mem[4 * PK_SLEVELS * PK_SFRAME_WORDS]; return mem; }
+    else return nullptr;
+}
+
+#ifndef PK_SCENE_WAVES
+#define PK_SCENE_WAVES 4   // waves per SIMD the scene variant is compiled for (108 VGPRs as it stands; 5 would spill 44 bytes per lane)
+#endif
 template <int M>
-__global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, const float *__restrict__ refT,
-                                                const f4 *__restrict__ leafNB, const f4 *__restrict__ leafTB, const MeshRec *__restrict__ meshes, SceneView S,
-                                                PacketArgs A) {
+__global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k_packet(const f4 *__restrict__ blocks, const float *__restrict__ refT,
+                                                const f4 *__restrict__ leafNB, const f4 *__restrict__ leafTB, const MeshRec *__restrict__ meshes,
+                                                const f4 *__restrict__ snodes, const int *__restrict__ srefs, const ObjRec *__restrict__ objects,
+                                                const int *__restrict__ objMesh, SceneView S, PacketArgs A) {
     __shared__ unsigned frames[4 * PK_LEVELS * PK_FRAME_WORDS];
+    unsigned *const sframesAll = scene_frames<M>();
+    unsigned *const parkAll = scene_park<M>();
     stamp_begin(A.stamps);
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     unsigned *const stk = &frames[wave * PK_LEVELS * PK_FRAME_WORDS];
@@ -80,184 +308,160 @@ __global__ __launch_bounds__(256) void k_packet(const f4 *__restrict__ blocks, c
         const int w = pk * 64 + lane;
         const bool valid = w < n;
         Lane L;
-        SceneLane C;
-        L.state = ST_FINISH; L.mfound = 0; L.cost = 0; L.rayIndex = 0; L.mesh = 0; L.weird = 0; L.dmask = 0; L.ignoreId = -1;
+        L.state = ST_FINISH; L.mfound = 0; L.cost = 0; L.rayIndex = 0; L.mesh = 0; L.weird = 0; L.dmask = 0; L.ignoreId = -1; L.mask = 0;
         L.r = make_ray(mk(0, 0, 0), mk(1, 1, 1));
-        C.sfound = 0; C.obj = 0;
         int idx = 0;
+        v3 o = mk(0, 0, 0), d = mk(0, 0, 0);
+        int im = DEAD_RAY, it = -1;
         if (valid) {
             idx = A.index ? A.index[w] : w;
-            v3 o, d; int im, it;
             load_ray(A.rays + idx, o, d, im, it);
             if (A.unmark && heavy_marked(it)) it ^= HEAVY_BIT;
-            if (im != DEAD_RAY) lane_begin(L, C, S, o, d, im, it, idx, M, A.meshId, false);
         }
-        const RayCull RC = make_ray_cull(L.r.o, L.r.d);   // tight leaf boxes (xrt_core.h): what depends on the ray alone
-        const int mesh = (M == MODE_MESH) ? A.meshId : 0;
-        const MeshRec &mr = meshes[mesh];
-        const bool fastL = L.r.par == 0 && L.weird == 0;
-        PkUniform U;
-        U.blk = mr.rootBlock;
-        U.bmin = mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]);
-        U.half = half_of(U.bmin, mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]));
-        U.lanes = __ballot(valid && L.state == ST_NODE);   // inside the root box of an interior root (MO:265)
-        U.p = 0; U.dm0 = 0;
-        // per lane: for every level of the shared stack, which children of that level's block the lane's own box tests accepted
-        unsigned long long cbLo = 0, cbMid = 0, cbHi = 0;
-        int sp = 0;
-        bool entering = true, anyFound = false;   // anyFound: some lane of the wave has a candidate
-        int d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-        unsigned long long offLo = 0, offHi = 0;
-        int cb = 0;
-        if (U.blk < 0) U.lanes = 0ull;   // (a root that is a leaf is k_intersect's business: packet_supported)
-        // The scalar unit is shared by the CU's four SIMDs, so scalar instructions are the scarce resource of this kernel
-        // (measured: 3,900 per packet against 4,000 vector ones made it scalar-bound): the pending children are a bit mask
-        // walked with ctz, the lanes of a leaf are selected once for the whole leaf, a triangle costs one wave-level branch.
-        while (U.lanes != 0ull) {
-            const bool in = ((U.lanes >> lane) & 1ull) != 0;
-            if (entering) {
-                const f4 lo = blocks[2 * (size_t)U.blk], hi = blocks[2 * (size_t)U.blk + 1];
-                d0 = f2i(lo.x); d1 = f2i(lo.y); d2 = f2i(lo.z); d3 = f2i(lo.w);
-                offLo = (unsigned long long)(unsigned)f2i(hi.x) | ((unsigned long long)(unsigned)f2i(hi.y) << 32);
-                offHi = (unsigned long long)(unsigned)f2i(hi.z) | ((unsigned long long)(unsigned)f2i(hi.w) << 32);
-                cb = 0;
-                if (in) cb = fastL ? hit8_fast_children(L.r, L.dmask, U.bmin, U.half) : hit8_slow_children(L.r, U.bmin, U.half);
-                cb &= 0xff & ~((d2 >> 8) & 0xff);   // empty leaves can never hit (Q4)
-                {   // remember it for the return to this level
-                    const int sh = (sp & 7) * 8;
-                    const unsigned long long m = ~(0xffull << sh), v = (unsigned long long)(unsigned)cb << sh;
-                    if (sp < 8) cbLo = (cbLo & m) | v; else if (sp < 16) cbMid = (cbMid & m) | v; else cbHi = (cbHi & m) | v;
-                }
-                U.dm0 = __builtin_amdgcn_readlane(L.dmask, (int)__builtin_ctzll(U.lanes));   // front-to-back order of the first lane
-                // children some lane entered, in that order: bit p <-> child (p ^ dm0)
-                int un = wave_or(cb);
-                if (U.dm0 & 4) un = ((un & 0xf0) >> 4) | ((un & 0x0f) << 4);
-                if (U.dm0 & 2) un = ((un & 0xcc) >> 2) | ((un & 0x33) << 2);
-                if (U.dm0 & 1) un = ((un & 0xaa) >> 1) | ((un & 0x55) << 1);
-                U.p = un;
-                entering = false;
+        if constexpr (M != MODE_SCENE) {
+            SceneLane C;
+            C.sfound = 0; C.obj = 0;
+            if (valid && im != DEAD_RAY) lane_begin(L, C, S, o, d, im, it, idx, M, A.meshId, false);
+            const RayCull RC = make_ray_cull(L.r.o, L.r.d);   // tight leaf boxes (xrt_core.h): what depends on the ray alone
+            const int mesh = (M == MODE_MESH) ? A.meshId : 0;
+            const MeshRec &mr = meshes[mesh];
+            const bool fastL = L.r.par == 0 && L.weird == 0;
+            // the lanes inside the root box of an interior root (MO:265; lane_begin left them in ST_NODE with mask 1 -- a root that is a
+            // leaf is k_intersect's business: packet_supported)
+            const unsigned long long lanes0 = mr.rootBlock < 0 ? 0ull : __ballot(valid && L.state == ST_NODE && L.mask != 0);
+            pk_walk(blocks, refT, leafNB, leafTB, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]),
+                    mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]), lanes0);
+            L.mesh = mesh;
+            if (valid) {
+                const HitOut h = lane_result(L, C, S, M);
+                if (A.flags) A.flags[idx] = h.hit;
+                if (!A.flags || h.hit) store_hit(A.hits + idx, h);
             }
-            if (U.p == 0) {   // block exhausted: back to the level above
-                if (sp == 0) break;
-                sp--;
-                const unsigned *f = stk + sp * PK_FRAME_WORDS;
-                U.blk = rfl((int)f[0]); U.p = rfl((int)f[1]); U.dm0 = rfl((int)f[2]);
-                U.lanes = (unsigned long long)(unsigned)rfl((int)f[3]) | ((unsigned long long)(unsigned)rfl((int)f[4]) << 32);
-                U.bmin = mk(rflf(i2f((int)f[5])), rflf(i2f((int)f[6])), rflf(i2f((int)f[7])));
-                U.half = mk(rflf(i2f((int)f[8])), rflf(i2f((int)f[9])), rflf(i2f((int)f[10])));
-                const f4 lo = blocks[2 * (size_t)U.blk], hi = blocks[2 * (size_t)U.blk + 1];
-                d0 = f2i(lo.x); d1 = f2i(lo.y); d2 = f2i(lo.z); d3 = f2i(lo.w);
-                offLo = (unsigned long long)(unsigned)f2i(hi.x) | ((unsigned long long)(unsigned)f2i(hi.y) << 32);
-                offHi = (unsigned long long)(unsigned)f2i(hi.z) | ((unsigned long long)(unsigned)f2i(hi.w) << 32);
-                const int sh = (sp & 7) * 8;
-                cb = (int)(((sp < 8 ? cbLo : (sp < 16 ? cbMid : cbHi)) >> sh) & 0xffull);
-                continue;
-            }
-            const int c = (int)__builtin_ctz((unsigned)U.p) ^ U.dm0;
-            U.p &= U.p - 1;
-            const bool inC = in && ((cb >> c) & 1);
-            v3 cmin, cmax;
-            child_box(U.bmin, U.half, c, cmin, cmax);
-            // The child's own test gives the entry key (its outcome is known: hit).  The bucket rule compares keys only once a lane
-            // has a candidate; until some lane of the wave has one (most of a packet's walk) the key of a leaf is computed by the
-            // lanes that find a candidate in it, and nobody computes the key of an interior child.
-            auto entry_key = [&]() {
-                float k = 0.0f;
-                if (fastL) (void)slab_fast(L.r, L.dmask, cmin, cmax, k);
-                else (void)slab(L.r, cmin.x, cmin.y, cmin.z, cmax.x, cmax.y, cmax.z, k);
-                return k;
-            };
-            const bool keyed = anyFound;   // wave-uniform
-            float key = 0.0f;
-            if (keyed && inC) key = entry_key();
-            const int node = U.blk * 8 + c;
-            if (!((d2 >> c) & 1)) {   // ---- leaf (non-empty): MO:288-304 for the lanes the bucket rule lets in ----
-                const f4 nlo = leafNB[2 * (size_t)node], nhi = leafNB[2 * (size_t)node + 1];
-                bool go = inC && !(L.mfound && key > L.mKey) && !all_back_facing(nlo, nhi, L.r.d);
-                if (!__any(go)) continue;
-                const int r0 = d1 + child_ref_offset(offLo, offHi, c);
-                const int r1 = d1 + ((c == 7) ? d3 : child_ref_offset(offLo, offHi, c + 1));
-                if (r1 - r0 >= A.cullMin) {   // lanes whose ray cannot reach any triangle of the leaf (xrt_core.h leaf_certainly_missed) stay out of it
-                    const f4 *tb = leafTB + 4 * (size_t)node;
-                    go = go && !leaf_certainly_missed(L.r, RC, tb[0], tb[1], tb[2], tb[3]);
-                    if (!__any(go)) continue;
+        } else {
+            // ---- OSM:312-455, wave-uniform: scene octree in DFS order, bodies and meshes in list order ---------------------------
+            PkScene C(parkAll + wave * PK_PARK_WORDS * 64 + lane);
+            unsigned *const sfr = sframesAll + wave * PK_SLEVELS * PK_SFRAME_WORDS;
+            // start of the query (traverse.h lane_begin): ignoreTriangle identity (MO:290), non-finite rays take the literal box
+            // tests, a NaN component means "no intersection" at once (no triangle can be accepted)
+            L.weird = (is_finite(o.x) && is_finite(o.y) && is_finite(o.z) && is_finite(d.x) && is_finite(d.y) && is_finite(d.z)) ? 0 : 1;
+            if (it >= 0 && im >= 0 && im < S.nMeshes && it < meshes[im].ntri) L.ignoreId = meshes[im].triBase + it;
+            const bool nan = is_nan(o.x) || is_nan(o.y) || is_nan(o.z) || is_nan(d.x) || is_nan(d.y) || is_nan(d.z);
+            C.w = make_ray(o, d);
+            C.sfound = 0;
+            int sblk = 0, smask = 1, ssp = 0;   // root = slot 0 of block 0
+            unsigned long long slanes = __ballot(valid && im != DEAD_RAY && !nan);
+            while (slanes != 0ull) {
+                if (smask == 0) {
+                    if (ssp == 0) break;
+                    ssp--;
+                    const unsigned *f = sfr + ssp * PK_SFRAME_WORDS;
+                    sblk = rfl((int)f[0]); smask = rfl((int)f[1]);
+                    slanes = (unsigned long long)(unsigned)rfl((int)f[2]) | ((unsigned long long)(unsigned)rfl((int)f[3]) << 32);
+                    continue;
                 }
-                if (go) {   // the lanes of this leaf, selected once for all its triangles
-                    L.leafKey = key; L.leafNode = node;
-                    // The triangle is the same for every lane: normals and geometry come through the scalar cache.  Two register
-                    // sets take turns, and a triangle's 52 bytes are requested before the previous one's arithmetic starts (the
-                    // records of a leaf are back to back; the arrays end in two dummy records, so asking one past the leaf is safe).
-                    // One record of 13 words (refT: normal, id, v1, E1, E2) = one s_load_dwordx16 (the three words past it belong to
-                    // the next record; the array ends in padding): the scalar unit is this kernel's scarce resource, and a
-                    // triangle used to cost three loads from two streams.
-                    const char *pt = reinterpret_cast<const char *>(refT) + (size_t)r0 * TRI_REC_BYTES;
-                    auto test = [&](const TriWords &q, int r) {
-                        const bool f = !(facing(mk(q.w[0], q.w[1], q.w[2]), L.r.d) > 0.0f) & (f2i(q.w[3]) != L.ignoreId);   // RE:48-51, MO:290
-                        v3 T; float det, row2;
-                        const v3 gb = mk(q.w[7], q.w[8], q.w[9]), gc = mk(q.w[10], q.w[11], q.w[12]);
-                        const bool sA = tri_stage_a(L.r.o, L.r.d, mk(q.w[4], q.w[5], q.w[6]), gb, gc, T, det, row2) & f;
-                        if (sA) {   // one wave-level branch per triangle (s_cbranch_execz): most are rejected by the sign of u for every lane
-                            float u, v, t;
-                            if (tri_stage_b(L.r.d, gb, gc, T, det, row2, u, v, t)) {
-                                if (!keyed) L.leafKey = entry_key();
-                                leaf_candidate(L, S, r, -2, true, u, v, t);   // (the ignored triangle was filtered above: -2 matches no id)
-                            }
+                const int c = (int)__builtin_ctz((unsigned)smask);
+                smask &= smask - 1;
+                const int node = sblk * 8 + c;
+                const f4 lo = snodes[2 * (size_t)node], hi = snodes[2 * (size_t)node + 1];
+                const bool in = ((slanes >> lane) & 1ull) != 0;
+                float key = 0.0f;
+                bool hit = false;
+                if (in) { const RayPre wr = C.w; hit = slab(wr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, key); }   // OSM:460
+                const unsigned long long hm = __ballot(hit);
+                if (hm == 0ull) continue;
+                const int a_ = rfl(f2i(lo.w)), b_ = rfl(f2i(hi.w));
+                if (b_ >= 0) {   // interior
+                    if (ssp >= PK_SLEVELS - 1) continue;   // (cannot happen: packet_supported checks the depth)
+                    if (smask) {
+                        if (lane == 0) {
+                            unsigned *f = sfr + ssp * PK_SFRAME_WORDS;
+                            f[0] = (unsigned)sblk; f[1] = (unsigned)smask; f[2] = (unsigned)slanes; f[3] = (unsigned)(slanes >> 32);
                         }
-                    };
-                    TriWords qA = *reinterpret_cast<const TriWords *>(pt);
-                    int r = r0;
-                    for (;;) {
-                        const TriWords qB = *reinterpret_cast<const TriWords *>(pt + TRI_REC_BYTES);
-                        test(qA, r);
-                        if (r + 1 >= r1) break;
-                        qA = *reinterpret_cast<const TriWords *>(pt + 2 * TRI_REC_BYTES);
-                        test(qB, r + 1);
-                        r += 2; pt += 2 * TRI_REC_BYTES;
-                        if (r >= r1) break;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        ssp++;
+                    }
+                    sblk = a_ >> 3; smask = 0xff; slanes = hm;
+                    continue;
+                }
+                const int cnt = b_ & 0x0fffffff;
+                if (cnt == 0) continue;
+                const bool go = hit && !((int)C.sfound && key > (float)C.sbKey);   // a later bucket than the one that already has a hit (OSM:334)
+                if (!__any(go)) continue;
+                if (go) C.sKey = key;
+                for (int r = a_; r < a_ + cnt; r++) {   // OSM:341-364: the bodies of the leaf, in list order
+                    const int o = rfl(srefs[r]);
+                    const ObjRec &ob = objects[o];
+                    bool inB = go;
+                    if (ob.cullOk) inB = go && (L.weird != 0 || precull_hit(C.w, ob));   // conservative world-space reject
+                    if (!__any(inB)) continue;
+                    if (inB) {   // world -> object space
+                        const RayPre wr = C.w;
+                        const v3 rayDirPosition = add(wr.o, wr.d);                  // OSM:358
+                        const v3 v1 = transform(wr.o, ob.invWorld);                 // OSM:360
+                        const v3 v2 = transform(rayDirPosition, ob.invWorld);       // OSM:361
+                        const v3 dir = normalize(sub(v2, v1));                      // OSM:362-364
+                        L.r = make_ray(v1, dir);
+                        L.dmask = dir_mask(dir);
+                        if (!(is_finite(v1.x) && is_finite(v1.y) && is_finite(v1.z) && is_finite(dir.x) && is_finite(dir.y) && is_finite(dir.z))) L.weird = 1;
+                    }
+                    const RayCull RC = make_ray_cull(L.r.o, L.r.d);
+                    const bool fastL = L.r.par == 0 && L.weird == 0;
+                    const int m0 = rfl(ob.meshStart), m1 = m0 + rfl(ob.meshCount);
+                    for (int mi = m0; mi < m1; mi++) {   // OSM:366-368: its meshes
+                        const int m = rfl(objMesh[mi]);
+                        const MeshRec &mr = meshes[m];
+                        float k;
+                        const bool inM = inB && slab(L.r, mr.bmin[0], mr.bmin[1], mr.bmin[2], mr.bmax[0], mr.bmax[1], mr.bmax[2], k);   // MESH:34-39
+                        if (!__any(inM)) continue;
+                        float rkey = 0.0f;
+                        const bool inRoot = inM && slab(L.r, mr.rmin[0], mr.rmin[1], mr.rmin[2], mr.rmax[0], mr.rmax[1], mr.rmax[2], rkey);   // MO:265 on the root (MO:331)
+                        L.mfound = 0;
+                        const int rootBlock = rfl(mr.rootBlock);
+                        if (rootBlock < 0) {   // the root is a leaf: one bucket
+                            const int r0 = rfl(mr.rootRef), rc = rfl(mr.rootCount);
+                            if (rc > 0 && __any(inRoot)) {
+                                if (inRoot) {
+                                    L.leafKey = rkey; L.leafNode = ROOT_NODE;
+                                    pk_scan_leaf(refT, r0, r0 + rc, L, S, true, [&]() { return rkey; });
+                                }
+                            }
+                        } else {
+                            const unsigned long long lanes0 = __ballot(inRoot);
+                            if (lanes0 != 0ull)
+                                pk_walk(blocks, refT, leafNB, leafTB, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]),
+                                        mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]), lanes0);
+                        }
+                        if (L.mfound) {   // OSM:370-378
+                            L.mesh = m; C.obj = o;
+                            merge_mesh_result(L, C);
+                            L.mfound = 0;
+                        }
                     }
                 }
-                if (!keyed) anyFound = __any(L.mfound != 0);
-                continue;
             }
-            // ---- interior child: a lane prunes it by key only where that is a proven lower bound (safe bit) ----
-            const bool go = inC && !(L.mfound && ((d2 >> (16 + c)) & 1) && key > L.mKey);
-            const unsigned long long LL = __ballot(go);
-            if (LL == 0ull) continue;
-            if (sp >= PK_LEVELS - 1) continue;   // (cannot happen: packet_supported checks the depth)
-            if (U.p != 0) {   // something is left to do at this level: come back
-                if (lane == 0) {
-                    unsigned *f = stk + sp * PK_FRAME_WORDS;
-                    f[0] = (unsigned)U.blk; f[1] = (unsigned)U.p; f[2] = (unsigned)U.dm0;
-                    f[3] = (unsigned)U.lanes; f[4] = (unsigned)(U.lanes >> 32);
-                    f[5] = (unsigned)f2i(U.bmin.x); f[6] = (unsigned)f2i(U.bmin.y); f[7] = (unsigned)f2i(U.bmin.z);
-                    f[8] = (unsigned)f2i(U.half.x); f[9] = (unsigned)f2i(U.half.y); f[10] = (unsigned)f2i(U.half.z);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                sp++;
+            if (valid) {
+                L.mfound = 0;
+                const HitOut h = lane_result(L, C, S, M);
+                if (A.flags) A.flags[idx] = h.hit;
+                if (!A.flags || h.hit) store_hit(A.hits + idx, h);
             }
-            U.blk = d0 + __builtin_popcount((unsigned)(d2 & 0xff) & ((1u << c) - 1u));
-            U.bmin = cmin; U.half = half_of(cmin, cmax);
-            U.lanes = LL;
-            entering = true;
-        }
-        if (valid) {
-            L.mesh = mesh;
-            const HitOut h = lane_result(L, C, S, M);
-            if (A.flags) A.flags[idx] = h.hit;
-            if (!A.flags || h.hit) store_hit(A.hits + idx, h);
         }
     }
     stamp_end(A.stamps);
 }
 
-bool packet_supported(int mode, int meshDepth) { return (mode == MODE_SINGLE || mode == MODE_MESH) && meshDepth > 0 && meshDepth + 1 < PK_LEVELS; }
+bool packet_supported(int mode, int meshDepth, int sceneDepth) {
+    if (mode == MODE_SCENE) return meshDepth + 1 < PK_LEVELS && sceneDepth + 1 < PK_SLEVELS;   // (meshes whose root is a leaf are handled here)
+    return (mode == MODE_SINGLE || mode == MODE_MESH) && meshDepth > 0 && meshDepth + 1 < PK_LEVELS;
+}
 
 int packet_blocks_per_cu(int mode) {
     int nb = 0;
     hipError_t e = mode == MODE_MESH ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_packet<MODE_MESH>, 256, 0)
-                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_packet<MODE_SINGLE>, 256, 0);
+                   : (mode == MODE_SCENE ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_packet<MODE_SCENE>, 256, 0)
+                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_packet<MODE_SINGLE>, 256, 0));
     if (e != hipSuccess || nb < 1) nb = 1;
     // 800 SGPRs per SIMD, allocated in sixteens plus sixteen per wave: the API does not account for it in the 81-112 range
     const int bySgpr = 800 / (((PK_SGPRS + 15) / 16) * 16 + 16);
@@ -267,8 +471,12 @@ int packet_blocks_per_cu(int mode) {
 
 void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     dim3 g((unsigned)gridBlocks), b(256);
-    if (A.mode == MODE_MESH) hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S, A);
-    else hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S, A);
+    if (A.mode == MODE_MESH)
+        hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S.snodes, S.srefs, S.objects, S.objMesh, S, A);
+    else if (A.mode == MODE_SCENE)
+        hipExtLaunchKernelGGL((k_packet<MODE_SCENE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S.snodes, S.srefs, S.objects, S.objMesh, S, A);
+    else
+        hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S.snodes, S.srefs, S.objects, S.objMesh, S, A);
 }
 
 }  // namespace xrt

@@ -189,7 +189,7 @@ XRT_HD int child_ref_offset(unsigned long long offLo, unsigned long long offHi, 
     return (int)((w >> (16 * (c & 3))) & 0xffffull);
 }
 
-// enter == false (the wave-packet kernel, packet.hip): stop after the root's own box test -- state ST_NODE then only says
+// enter == false (the wave-packet kernel, packet.hip): stop after the root's own box test -- state ST_NODE with mask != 0 then says
 // "the ray is inside the root box of an interior root"; the packet enters the root block itself.
 XRT_HD void begin_mesh_query(Lane &L, const SceneView &S, int mesh, bool enter = true) {
     const MeshRec &mr = S.meshes[mesh];
@@ -208,7 +208,7 @@ XRT_HD void begin_mesh_query(Lane &L, const SceneView &S, int mesh, bool enter =
         }
         return;
     }
-    if (!enter) return;
+    if (!enter) { L.mask = 1; return; }   // (mask 1 tells the packet "inside the root box": a ray that misses it ends here with mask 0, MO:265)
     L.bmin = mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]);
     L.half = half_of(L.bmin, mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]));
     load_block(L, S, mr.rootBlock);

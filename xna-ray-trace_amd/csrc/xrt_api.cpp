@@ -619,7 +619,9 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     }
     // which ray populations the wave-packet kernel traces this frame (packet.hip): bit 0 primary rays, 1 shadow rays, 2 closest-hit
     // rays of later generations
-    const int pkMask = (s->packetOk && !heap) ? (s->packetMask >= 0 ? s->packetMask : (g.samples >= 16 ? 7 : 0)) : 0;
+    // (two-level scenes: at any sample count -- what a packet shares there is the scene walk, the bodies' records and the mesh walk of
+    // a body, and an 8x8-pixel block of a 1-sample frame sees one or two bodies; one-body scenes: only with 16 sub-rays, see above)
+    const int pkMask = (s->packetOk && !heap) ? (s->packetMask >= 0 ? s->packetMask : ((g.samples >= 16 || s->sceneMode == MODE_SCENE) ? 7 : 0)) : 0;
     const bool laneClosest = (pkMask & 5) != 5;   // some closest-hit generation is traced ray by ray: the long-ray feedback has a reader
     const bool wantFeedback = fast && !heap && s->deepMeshes && !s->noFeedback && laneClosest;
     {   // The other context's frame may still be running on another stream.  Two single-chunk frames share nothing they
@@ -1378,7 +1380,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
         HIPCHECK(hipMemsetAsync(s->counters.p, 0, 2 * C_COUNT * sizeof(unsigned long long), st));
     }
     const bool meshOk = mode != MODE_MESH || (meshId >= 0 && meshId < (int)s->host->meshTrees.size() && !s->host->meshTrees[(size_t)meshId].rootIsLeaf);
-    if (n > 0 && s->packetMask >= 0 && (s->packetMask & 8) && mode != MODE_SCENE && packet_supported(mode, s->host->arrays.meshDepth) && meshOk) {   // (testing aid: arbitrary batches through the packet kernel)
+    if (n > 0 && s->packetMask >= 0 && (s->packetMask & 8) && packet_supported(mode, s->host->arrays.meshDepth, s->host->arrays.sceneDepth) && meshOk) {   // (testing aid: arbitrary batches through the packet kernel)
         PacketArgs PA;
         PA.rays = d_rays; PA.hits = d_hits; PA.n = (int)n; PA.queue = queue + 1; PA.mode = mode; PA.meshId = meshId;
         int grid = s->numCUs * packet_blocks_per_cu(mode);
@@ -1430,7 +1432,7 @@ int scene_upload(xrt_scene *scene) {
     if (getenv("XRT_NO_SINGLE")) scene->sceneMode = MODE_SCENE;
     scene->blocksPerCU = intersect_blocks_per_cu(scene->stackNeeded, scene->sceneMode);
     scene->blocksPerCUMesh = intersect_blocks_per_cu(scene->stackNeeded, MODE_MESH);
-    scene->packetOk = packet_supported(scene->sceneMode, A.meshDepth);
+    scene->packetOk = packet_supported(scene->sceneMode, A.meshDepth, A.sceneDepth);
     // Refill threshold of k_intersect.  A two-level scene refills a wave only when ALL its lanes are idle: fresh rays start in the
     // scene phase while the others are deep in a mesh, and every partial refill made the wave run that phase for a few lanes
     // (measured with 8x8-pixel waves, whose rays take about equally long: C3 3.1 -> 2.45 ms, C4 8.9 -> 6.2 ms of traversal per frame).
