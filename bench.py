@@ -48,10 +48,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 # 2 cycles on a SIMD-32 with >= 2 waves resident, chip table "Max clock 2400 MHz") = 78.6 T lane-operations per second
 # (= the 157.3 TFLOP/s vector peak, which counts a fused multiply-add as two; this path is built with contraction off)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-SCALAR_PEAK_TINST = 256 * 2.4e9 / 1e12   # one scalar-unit instruction per cycle per CU
-# what micro-benchmarks of nothing but independent instructions reach (tools/microbench/, profiles/r02_m/*_peak.txt): 0.94 scalar
-# instructions per cycle and CU, 0.44 wave64 VALU instructions per cycle and SIMD, both with eight waves per SIMD
-SCALAR_MEASURED_TINST = 256 * 2.238e9 / 1e12
+CU_CYCLES_PER_S = 256 * 2.4e9           # CU-cycles per second (256 CUs, 2.4 GHz; the microbenchmarks ran at 2.39-2.40)
+# Scalar-side issue rates, measured (tools/microbench/scalar_mix.hip -> profiles/r03/scalar_mix_peak.txt, six waves per SIMD = k_packet's
+# occupancy; MI355X_MICROARCH.md gives none).  Instructions per CU per cycle with nothing else running:
+#   SALU 0.964 | s_cbranch not taken 0.946, s_branch taken 0.591 (harmonic mean 0.728: a kernel's taken share is not counted) | s_load_dwordx8 0.138
+# and the classes ISSUE SIDE BY SIDE: k_packet's mix (80 % SALU / 16 % branch / 4 % SMEM) retires 1.035 instructions per cycle -- more than
+# SALU alone, where one shared port would give 0.747 -- so each class is a ceiling of its own and the kernel's scalar-side bound is the
+# largest of the three fractions, not their sum (round 2 summed them over the SALU-only peak).
+SALU_PEAK_IPC, BRANCH_PEAK_IPC, SMEM_PEAK_IPC, MIX_PK_IPC = 0.964, 0.728, 0.138, 1.035
+# VALU: 0.44 wave64 instructions per cycle and SIMD with eight waves per SIMD (tools/microbench/valu_peak.hip, profiles/r02_m)
 VALU_MEASURED_TLANEOPS = 70.0
 KERNEL_SOURCES = ("kernels.hip", "packet.hip", "kernels.h", "device_util.h", "traverse.h", "xrt_core.h", "xrt_api.cpp")
 
@@ -200,10 +205,11 @@ def time_frames(tracer, outs, steps, warmup, rank, world, width, height, gathere
     return dt, acc[0], acc[1]
 
 
-def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=True):
+def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=True, n_gpus_in_library=1):
     spec = xrt.configs.config(name, scale)
     t0 = time.perf_counter()
     scene, tracer = xrt.configs.build_product(spec, device=local_rank)
+    tracer.NumGpus = n_gpus_in_library   # > 1: every frame below is ONE xrt_render_device call that the library spreads over that many devices
     build_s = time.perf_counter() - t0
     W, H = spec.width, spec.height
     tx, ty, tpr = xrt.dist.shard_layout(W, H, world)
@@ -352,24 +358,30 @@ def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_fra
                       "waves_waiting_frac": round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 3) if pmc.get("SQ_WAVE_CYCLES") else None}
         cands = {"valu": fr["valu"]["issue_frac"], "hbm": fr["hbm"]["frac"]}
         if pmc.get("SQ_INSTS_SALU") is not None:
-            # the scalar unit (SALU, branches, scalar loads) is shared by a CU's four SIMDs: one instruction per cycle per CU
-            # (MI355X_MICROARCH.md gives no figure; measured with independent s_add_u32: 0.94 per cycle per CU at best)
-            sc = (pmc["SQ_INSTS_SALU"] + pmc.get("SQ_INSTS_BRANCH", 0.0) + pmc.get("SQ_INSTS_SMEM", 0.0)) / t / 1e12
-            fr["scalar"] = {"achieved": round(sc, 3), "peak": round(SCALAR_PEAK_TINST, 3), "unit": "Tinst/s", "frac": round(sc / SCALAR_PEAK_TINST, 4),
-                            "scalar_instructions_per_launch": int(pmc["SQ_INSTS_SALU"] + pmc.get("SQ_INSTS_BRANCH", 0.0) + pmc.get("SQ_INSTS_SMEM", 0.0))}
-            fr["scalar"]["issue_frac"] = fr["scalar"]["frac"]
-            fr["scalar"]["measured_peak"] = round(SCALAR_MEASURED_TINST, 3)
-            fr["scalar"]["frac_of_measured_peak"] = round(sc / SCALAR_MEASURED_TINST, 4)
-            cands["scalar"] = fr["scalar"]["frac"]
+            # The scalar unit is shared by a CU's four SIMDs.  Its three instruction classes issue side by side (measured, see the
+            # constants above), so each is priced against its OWN measured rate; `mix` is the information round 2 reported (the
+            # sum) over the rate measured for that very mix.
+            cyc = t * CU_CYCLES_PER_S
+            n_s, n_b, n_m = pmc["SQ_INSTS_SALU"], pmc.get("SQ_INSTS_BRANCH", 0.0), pmc.get("SQ_INSTS_SMEM", 0.0)
+            for key, n, peak in (("salu", n_s, SALU_PEAK_IPC), ("branch", n_b, BRANCH_PEAK_IPC), ("smem", n_m, SMEM_PEAK_IPC)):
+                fr[key] = {"achieved": round(n / cyc, 4), "peak": peak, "unit": "instructions per CU per cycle", "frac": round(n / cyc / peak, 4),
+                           "issue_frac": round(n / cyc / peak, 4), "instructions_per_launch": int(n)}
+                cands[key] = fr[key]["frac"]
+            fr["scalar_mix"] = {"achieved": round((n_s + n_b + n_m) / cyc, 4), "peak": MIX_PK_IPC, "unit": "instructions per CU per cycle",
+                                "frac": round((n_s + n_b + n_m) / cyc / MIX_PK_IPC, 4),
+                                "what": "SALU + branch + SMEM together over the rate measured for k_packet's 80/16/4 mix (information; the classes issue side by side, "
+                                        "so the bound is the largest single-class fraction)", "source": "profiles/r03/scalar_mix_peak.txt"}
         bound = max(cands, key=cands.get)
         top = fr[bound]
     out = {"bound": bound, "kernel": "traversal launches of a frame: k_packet (wave-packet form, coherent rays) + k_intersect (per-lane form)",
            "achieved": top["achieved"] if top else None, "peak": top["peak"] if top else None, "unit": top["unit"] if top else None,
-           "frac": (top["issue_frac"] if bound in ("valu", "scalar") else top["frac"]) if top else None,
+           "frac": (top["issue_frac"] if bound in ("valu", "salu", "branch", "smem") else top["frac"]) if top else None,
            "traffic": traffic, "ms_per_launch": round(ms_per_launch, 5), "launches_per_frame": launches_per_frame, "fractions": fr,
            "pmc_build_id": build_id() if pmc else None,
-           "note": "branchy scalar fp32 traversal, scene resident in the 256 MiB Infinity Cache: not HBM-bound. `frac` is the named bound's "
-                   "(valu: VALU instruction-issue slots used, of which fractions.valu.frac did useful lane work); durations = every launch of the timed region "
+           "note": "branchy scalar fp32 traversal, scene resident in the 256 MiB Infinity Cache: not HBM-bound. `frac` is the largest PHYSICAL fraction -- "
+                   "hbm (bytes moved / 8 TB/s), valu (issue slots used of 78.6 T lane-op/s; fractions.valu.frac of them did useful lane work), salu / branch / smem "
+                   "(each class over its own measured issue rate: they issue side by side, profiles/r03/scalar_mix_peak.txt); fractions.algorithmic is the "
+                   "SURVEY 8d equivalent rate of the un-pruned reference algorithm, not a physical fraction; durations = every launch of the timed region "
                    "times itself on the device clock, first wave's start to last wave's end (events on the dispatch packets cost ~5 us a launch; "
                    "rocprofv3's dispatch-level durations are ~4 us per launch longer); PMC = rocprofv3 passes of this build (profiles/), per launch"}
     if serial:
@@ -378,8 +390,9 @@ def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_fra
             serial["fractions"] = {"hbm": round(traffic / ts / 1e9 / HBM_PEAK_GBS, 4),
                                    "valu_issue": round(pmc["SQ_INSTS_VALU"] * 64.0 / ts / 1e12 / VALU_PEAK_TLANEOPS, 4),
                                    "valu_useful": round(pmc["SQ_THREAD_CYCLES_VALU"] / ts / 1e12 / VALU_PEAK_TLANEOPS, 4)}
-            if "scalar" in fr:
-                serial["fractions"]["scalar"] = round(fr["scalar"]["scalar_instructions_per_launch"] / ts / 1e12 / SCALAR_PEAK_TINST, 4)
+            for key, peak in (("salu", SALU_PEAK_IPC), ("branch", BRANCH_PEAK_IPC), ("smem", SMEM_PEAK_IPC)):
+                if key in fr:
+                    serial["fractions"][key] = round(fr[key]["instructions_per_launch"] / (ts * CU_CYCLES_PER_S) / peak, 4)
         out["serialised"] = serial
     return out
 
@@ -394,10 +407,18 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements of the other configs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--no-host", action="store_true", help="skip the host-output (PCIe-inclusive) timing")
+    ap.add_argument("--in-library", action="store_true",
+                    help="N > 1 from ONE process: xrt_render_opts.n_gpus = N (replicas, per-device host threads, grouped RCCL send/recv and "
+                         "de-tile inside libxrt) -- the path the C# host's single RenderInternal call would use; run as plain `python bench.py "
+                         "--gpus N --in-library` (no torch.distributed launcher)")
     args = ap.parse_args()
 
     rank, local_rank, world = xrt.dist.env_rank_world()
-    if args.gpus > 1 and world == 1:
+    in_library = args.in_library and args.gpus > 1
+    if in_library and world > 1:
+        print("bench.py: --in-library is one process driving N GPUs; start it without torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and world == 1 and not in_library:
         print("bench.py: --gpus %d needs one process per GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
               "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus), file=sys.stderr)
         sys.exit(2)
@@ -413,7 +434,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    res, spec = run_config(args.config, args.scale, args.steps, args.warmup, rank, local_rank, world)
+    res, spec = run_config(args.config, args.scale, args.steps, args.warmup, rank, local_rank, world, n_gpus_in_library=args.gpus if in_library else 1)
     # max over ranks of the timed region; total rays over ranks
     t = torch.tensor([res["seconds"]], dtype=torch.float64, device="cuda")
     r = torch.tensor([float(res["rays"]), float(intersect_bytes(res["stats"])), res["ms_intersect"], float(res["launches"]), float(res["stats"]["rays_traversed"])],
@@ -448,7 +469,7 @@ def main():
                       "ms_per_launch": round(ms_l, 5), "algorithmic_achieved": round(ach_s, 2), "ms_per_step": round(res["serial_seconds"] / res["serial_steps"] * 1e3, 4)}
         line = {
             "metric": metric if args.scale == 1.0 else "Mrays/sec (scaled image, not a benchmark)",
-            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": args.gpus if in_library else world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(seconds / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.config], "width": res["width"], "height": res["height"], "triangles": res["tris"],
@@ -456,11 +477,13 @@ def main():
                        "rays_closest_per_frame": int(st["rays_closest"]) if world == 1 else None, "rays_shadow_per_frame": int(st["rays_shadow"]) if world == 1 else None,
                        "rays_traversed_per_frame": int(trav_frame),
                        "rays_answered_by_raygen_per_frame": int(rays_frame - trav_frame),
-                       "parallelism": "image tiles 64x8 round-robin x%d" % world, "scene_build_s": round(res["build_s"], 3)},
+                       "parallelism": ("image tiles 64x8 round-robin x%d, one process: xrt_render_opts.n_gpus (in-library RCCL send/recv gather)" % args.gpus) if in_library
+                                      else "image tiles 64x8 round-robin x%d" % world, "scene_build_s": round(res["build_s"], 3)},
             "Mrays_per_s_traversed": round(trav_frame * args.steps / seconds / 1e6, 3),
-            "roofline": roofline_block(args.config if world == 1 else "(N > 1: no PMC pass)", bytes_per_launch, ms_per_launch, launches // max(args.steps, 1), serial),
+            "roofline": roofline_block(args.config if (world == 1 and not in_library) else "(N > 1: no PMC pass)", bytes_per_launch, ms_per_launch, launches // max(args.steps, 1), serial),
         }
-        if world == 1 and not args.no_host and args.scale == 1.0:
+        solo = world == 1 and not in_library   # the side measurements below are single-GPU figures
+        if solo and not args.no_host and args.scale == 1.0:
             try:
                 _, tracer_h = xrt.configs.build_product(spec, device=local_rank)
                 # (a fresh scene: six warm-up frames size both frame contexts, create their streams and let the library see a frame time)
@@ -471,7 +494,7 @@ def main():
                 del tracer_h
             except Exception as e:   # a side measurement must not take the headline down
                 line["host_output"] = {"error": str(e)[:200]}
-        if world == 1 and args.scale == 1.0:
+        if solo and args.scale == 1.0:
             try:   # what the C# host's blocking RenderInternal sees: one frame at a time (libxrt splits it over two streams)
                 _, tracer_b = xrt.configs.build_product(spec, device=local_rank)
                 outb = torch.zeros(spec.width * spec.height, dtype=torch.int32, device="cuda")
@@ -489,7 +512,7 @@ def main():
                 del tracer_b, outb
             except Exception as e:
                 line["ms_per_step_blocking"] = None
-        if world == 1 and args.scale == 1.0:
+        if solo and args.scale == 1.0:
             try:   # THE seam, literally (RT:103-126): one blocking xrt_render per frame, ending in the host's Color[] (page-locked)
                 _, tracer_x = xrt.configs.build_product(spec, device=local_rank)
                 hostb = np.zeros(spec.width * spec.height, dtype=np.uint32)
@@ -517,7 +540,7 @@ def main():
             if res.get("last_frame") is not None:
                 line.update(parity_block(res["last_frame"], oracle_rgba, oracle_rows, spec.width))
                 parity_failed = not line["parity_ok"]
-        if world == 1 and not args.no_extra and args.scale == 1.0:
+        if solo and not args.no_extra and args.scale == 1.0:
             other = {}
             for name, k in (("C2", 20), ("C3", 5), ("C4", 3), ("G1", 5)):   # G1: the scene the reference's own Stopwatch would time (Game1.cs)
                 if name == args.config:

@@ -619,7 +619,7 @@ def test_launch_timing_device_clock_vs_events(xrt, monkeypatch):
         b = tracer_e.Render().copy()
         st_e = dict(tracer_e.last_stats)
         assert np.array_equal(a, b)
-        assert st_c["intersect_launches"] == st_e["intersect_launches"] == spec.max_reflections + 2
+        assert st_c["intersect_launches"] == st_e["intersect_launches"] >= spec.max_reflections + 2   # (a step whose two ray populations both go to the packet kernel is two launches)
         if i >= 2:
             ms_c.append(st_c["ms_intersect"]); ms_e.append(st_e["ms_intersect"])
             assert 0 < st_c["ms_intersect"] < st_c["ms_total"]

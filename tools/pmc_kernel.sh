@@ -15,5 +15,5 @@ for CTR in "$A" "$B" "$C"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $CTR --output-format csv -d $OUT/p$i -- python3 $R/"$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
-python3 $R/tools/pmc_summary.py $OUT $KER | tee $OUT/summary.txt
+python3 $R/tools/pmc_summary.py $OUT $KER ${PMC_GROUPS:-1} | tee $OUT/summary.txt
 grep -h "blocking frame\|frame " $OUT/p1.log | tail -2

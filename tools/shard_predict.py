@@ -1,0 +1,96 @@
+"""One-GPU PREDICTION of image-tile strong scaling (VERDICT r2 #4a) -- not a measurement of N GPUs.
+
+    python tools/shard_predict.py [C4 C5 ...] [--out gpurun_out/shard_predict.json]
+
+For N = 2, 4, 8 every one of the N tile shards of a frame (tile t -> rank t % N) is rendered on the ONE device, alone,
+as blocking frames (xrt_render_device with shard_rank / shard_count): its GPU time (xrt_stats.ms_total, median of the timed
+frames), its rays and the rays that reach the traversal kernels.  Reported per configuration and N:
+    t_whole_ms                     the unsharded frame, same protocol
+    t_shard_ms[r]                  shard r alone on the device
+    predicted_strong_scaling       t_whole / max_r t_shard[r]           (what N devices would give if nothing else cost time)
+    balance                        mean_r t_shard / max_r t_shard       (1 = perfectly even tiles)
+    fixed_ms                       per-frame costs that do not shrink with N: the de-tile kernel over the gathered buffers (measured
+                                   here) and the gather itself, ESTIMATED as (N-1)/N of the frame's bytes over one xGMI link at
+                                   153 GB/s plus 10 us of launch latency (MI355X_MICROARCH.md has no measured RCCL figure)
+    predicted_with_fixed           t_whole / (max_r t_shard[r] + fixed_ms)
+A shard of 1/N of the tiles is NOT 1/N of the time: launches of persistent waves have a floor (5-6 us each, ten per frame) and a
+tail that does not shrink, which is exactly what this tool is for."""
+import argparse
+import importlib
+import json
+import os
+import statistics
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+xrt = importlib.import_module("xna-ray-trace_amd")
+XGMI_LINK_GBS = 153.0
+
+
+def timed(fr, reps):
+    for _ in range(3):
+        st = fr()
+    ms = []
+    for _ in range(reps):
+        st = fr()
+        ms.append(st["ms_total"])
+    return statistics.median(ms), st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("configs", nargs="*", default=["C4", "C5"])
+    ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--out", default=os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "shard_predict.json"))
+    args = ap.parse_args()
+    out = {"what": "one-GPU PREDICTION of image-tile strong scaling: every shard rendered alone on one MI355X; not a multi-GPU measurement",
+           "xgmi_link_GBs_assumed": XGMI_LINK_GBS, "configs": {}}
+    for name in args.configs:
+        spec = xrt.configs.config(name)
+        scene, tracer = xrt.configs.build_product(spec)
+        W, H = spec.width, spec.height
+        whole = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+        t_whole, st_whole = timed(tracer.PrepareDevice(whole.data_ptr()), args.reps)
+        cfg = {"width": W, "height": H, "t_whole_ms": round(t_whole, 4), "rays_whole": int(st_whole["rays_closest"] + st_whole["rays_shadow"]),
+               "rays_traversed_whole": int(st_whole["rays_traversed"]), "shards": {}}
+        for n in (2, 4, 8):
+            tx, ty, tpr = xrt.dist.shard_layout(W, H, n)
+            count = tpr * 512
+            gathered = torch.zeros(n * count, dtype=torch.int32, device="cuda")
+            ts, rays, trav = [], [], []
+            for r in range(n):
+                t, st = timed(tracer.PrepareDevice(gathered[r * count:(r + 1) * count].data_ptr(), shard_rank=r, shard_count=n), args.reps)
+                ts.append(t); rays.append(int(st["rays_closest"] + st["rays_shadow"])); trav.append(int(st["rays_traversed"]))
+            final = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dts = []
+            for _ in range(5):
+                e0.record()
+                xrt.dist.detile_device(gathered, W, H, n, final)
+                e1.record()
+                torch.cuda.synchronize()
+                dts.append(e0.elapsed_time(e1))
+            assert torch.equal(final, whole), "sharded frame differs from the whole frame"
+            detile_ms = statistics.median(dts)
+            gather_ms = (n - 1) / n * (W * H * 4) / (XGMI_LINK_GBS * 1e9) * 1e3 + 0.010   # every rank sends over its own link; rank 0 receives n-1 buffers
+            fixed = detile_ms + gather_ms
+            cfg["shards"][str(n)] = {"t_shard_ms": [round(t, 4) for t in ts], "rays": rays, "rays_traversed": trav,
+                                     "predicted_strong_scaling": round(t_whole / max(ts), 3), "balance": round(sum(ts) / n / max(ts), 3),
+                                     "sum_of_shards_over_whole": round(sum(ts) / t_whole, 3),
+                                     "fixed_ms": {"detile_measured": round(detile_ms, 4), "gather_estimated": round(gather_ms, 4)},
+                                     "predicted_with_fixed": round(t_whole / (max(ts) + fixed), 3)}
+            print("%s N=%d: whole %.3f ms, shards %s ms -> predicted x%.2f (with fixed costs x%.2f), balance %.2f" % (
+                name, n, t_whole, " ".join("%.3f" % t for t in ts), t_whole / max(ts), t_whole / (max(ts) + fixed), sum(ts) / n / max(ts)), flush=True)
+        out["configs"][name] = cfg
+        del tracer, scene
+    out["time"] = time.strftime("%Y-%m-%dT%H:%M:%S")
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+    json.dump(out, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libxrt.so")
+LIB_PATH = os.path.join(_HERE, "csrc", os.environ.get("XRT_LIB_VARIANT", "libxrt.so"))   # XRT_LIB_VARIANT: a differently built libxrt (tools/ experiments: make VARIANT=..)
 
 XRT_OK = 0
 XRT_E_INVALID_ARG = -1

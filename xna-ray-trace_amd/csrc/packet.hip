@@ -27,8 +27,8 @@
 // scene-level rule is the streaming one, traverse.h merge_mesh_result: the order of the visits matters there and every lane sees
 // its own visits in the order its own walk would make them).  A scene node is visited by the lanes whose own box test (OSM:460)
 // accepted it and all its ancestors; a body of a leaf by the lanes of that leaf the world-space pre-cull (traverse.h precull_hit)
-// does not exclude -- its record is one scalar load for the whole wave, where the per-lane kernel pays two dependent vector loads
-// per lane and body -- ; those lanes transform their ray into the body's space (OSM:349-364), test the mesh boxes (MESH:34-39) and
+// does not exclude -- its record is one scalar load for the whole wave (SceneView::scull), where the per-lane kernel pays two
+// dependent vector loads per lane and body -- ; those lanes transform their ray into the body's space (OSM:349-364), test the mesh boxes (MESH:34-39) and
 // share one walk of the mesh octree; a lane's answer for the body is merged into its scene-level best as OSM:370-378 does.
 #include "device_util.h"
 #include "kernels.h"
@@ -267,7 +267,7 @@ template <int M> __device__ __forceinline__ unsigned *scene_frames() {
 template <int M>
 __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k_packet(const f4 *__restrict__ blocks, const float *__restrict__ refT,
                                                 const f4 *__restrict__ leafNB, const f4 *__restrict__ leafTB, const MeshRec *__restrict__ meshes,
-                                                const f4 *__restrict__ snodes, const int *__restrict__ srefs, const ObjRec *__restrict__ objects,
+                                                const f4 *__restrict__ snodes, const f4 *__restrict__ scull, const ObjRec *__restrict__ objects,
                                                 const int *__restrict__ objMesh, SceneView S, PacketArgs A) {
     __shared__ unsigned frames[4 * PK_LEVELS * PK_FRAME_WORDS];
     unsigned *const sframesAll = scene_frames<M>();
@@ -390,53 +390,74 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
                 const bool go = hit && !((int)C.sfound && key > (float)C.sbKey);   // a later bucket than the one that already has a hit (OSM:334)
                 if (!__any(go)) continue;
                 if (go) C.sKey = key;
-                for (int r = a_; r < a_ + cnt; r++) {   // OSM:341-364: the bodies of the leaf, in list order
-                    const int o = rfl(srefs[r]);
-                    const ObjRec &ob = objects[o];
-                    bool inB = go;
-                    if (ob.cullOk) inB = go && (L.weird != 0 || precull_hit(C.w, ob));   // conservative world-space reject
-                    if (!__any(inB)) continue;
-                    if (inB) {   // world -> object space
+                // OSM:341-364: the bodies of the leaf, in list order, 32 at a time.  First every lane of the leaf decides for each body
+                // whether the world-space pre-cull excludes it: one 48-byte record per body through the scalar cache
+                // (SceneView::scull, in leaf order: no srefs -> objects chain), the next one requested before this one is used, the
+                // lane's world ray in registers for the whole loop; then the bodies some lane kept are visited.
+                for (int base = 0; base < cnt; base += 32) {
+                    const int nb = min(32, cnt - base);
+                    const f4 *const rec = scull + 4 * (size_t)(a_ + base);
+                    unsigned pass = 0u;   // bit j: body base + j is not excluded for this lane
+                    if (go) {
                         const RayPre wr = C.w;
-                        const v3 rayDirPosition = add(wr.o, wr.d);                  // OSM:358
-                        const v3 v1 = transform(wr.o, ob.invWorld);                 // OSM:360
-                        const v3 v2 = transform(rayDirPosition, ob.invWorld);       // OSM:361
-                        const v3 dir = normalize(sub(v2, v1));                      // OSM:362-364
-                        L.r = make_ray(v1, dir);
-                        L.dmask = dir_mask(dir);
-                        if (!(is_finite(v1.x) && is_finite(v1.y) && is_finite(v1.z) && is_finite(dir.x) && is_finite(dir.y) && is_finite(dir.z))) L.weird = 1;
-                    }
-                    const RayCull RC = make_ray_cull(L.r.o, L.r.d);
-                    const bool fastL = L.r.par == 0 && L.weird == 0;
-                    const int m0 = rfl(ob.meshStart), m1 = m0 + rfl(ob.meshCount);
-                    for (int mi = m0; mi < m1; mi++) {   // OSM:366-368: its meshes
-                        const int m = rfl(objMesh[mi]);
-                        const MeshRec &mr = meshes[m];
-                        float k;
-                        const bool inM = inB && slab(L.r, mr.bmin[0], mr.bmin[1], mr.bmin[2], mr.bmax[0], mr.bmax[1], mr.bmax[2], k);   // MESH:34-39
-                        if (!__any(inM)) continue;
-                        float rkey = 0.0f;
-                        const bool inRoot = inM && slab(L.r, mr.rmin[0], mr.rmin[1], mr.rmin[2], mr.rmax[0], mr.rmax[1], mr.rmax[2], rkey);   // MO:265 on the root (MO:331)
-                        L.mfound = 0;
-                        const int rootBlock = rfl(mr.rootBlock);
-                        if (rootBlock < 0) {   // the root is a leaf: one bucket
-                            const int r0 = rfl(mr.rootRef), rc = rfl(mr.rootCount);
-                            if (rc > 0 && __any(inRoot)) {
-                                if (inRoot) {
-                                    L.leafKey = rkey; L.leafNode = ROOT_NODE;
-                                    pk_scan_leaf(refT, r0, r0 + rc, L, S, true, [&]() { return rkey; });
-                                }
-                            }
-                        } else {
-                            const unsigned long long lanes0 = __ballot(inRoot);
-                            if (lanes0 != 0ull)
-                                pk_walk(blocks, refT, leafNB, leafTB, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]),
-                                        mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]), lanes0);
+                        const bool weird = L.weird != 0;
+                        for (int j = 0; j < nb; j++) {
+                            const f4 c0 = rec[4 * j], c1 = rec[4 * j + 1], c2 = rec[4 * j + 2];
+                            const bool p = (f2i(c2.y) == 0) | weird | precull_box(wr, c0, c1, c2.x);
+                            pass |= (p ? 1u : 0u) << j;
                         }
-                        if (L.mfound) {   // OSM:370-378
-                            L.mesh = m; C.obj = o;
-                            merge_mesh_result(L, C);
+                    }
+                    unsigned any = (unsigned)wave_or((int)pass);
+                    while (any != 0u) {
+                        const int j = (int)__builtin_ctz(any);
+                        any &= any - 1u;
+                        const bool inB = ((pass >> j) & 1u) != 0u;
+                        const f4 h2 = rec[4 * j + 2], h3 = rec[4 * j + 3];
+                        const int o = rfl(f2i(h2.z)), m0 = rfl(f2i(h2.w)), m1 = m0 + rfl(f2i(h3.x));
+                        if (inB) {   // world -> object space
+                            const f4 *const oq = reinterpret_cast<const f4 *>(objects + o);   // InverseWorld, four wide scalar loads
+                            const f4 q0 = oq[0], q1 = oq[1], q2 = oq[2], q3 = oq[3];
+                            const float iw[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+                            const RayPre wr = C.w;
+                            const v3 rayDirPosition = add(wr.o, wr.d);                  // OSM:358
+                            const v3 v1 = transform(wr.o, iw);                          // OSM:360
+                            const v3 v2 = transform(rayDirPosition, iw);                // OSM:361
+                            const v3 dir = normalize(sub(v2, v1));                      // OSM:362-364
+                            L.r = make_ray(v1, dir);
+                            L.dmask = dir_mask(dir);
+                            if (!(is_finite(v1.x) && is_finite(v1.y) && is_finite(v1.z) && is_finite(dir.x) && is_finite(dir.y) && is_finite(dir.z))) L.weird = 1;
+                        }
+                        const RayCull RC = make_ray_cull(L.r.o, L.r.d);
+                        const bool fastL = L.r.par == 0 && L.weird == 0;
+                        for (int mi = m0; mi < m1; mi++) {   // OSM:366-368: its meshes
+                            const int m = rfl(objMesh[mi]);
+                            const MeshRec &mr = meshes[m];
+                            float k;
+                            const bool inM = inB && slab(L.r, mr.bmin[0], mr.bmin[1], mr.bmin[2], mr.bmax[0], mr.bmax[1], mr.bmax[2], k);   // MESH:34-39
+                            if (!__any(inM)) continue;
+                            float rkey = 0.0f;
+                            const bool inRoot = inM && slab(L.r, mr.rmin[0], mr.rmin[1], mr.rmin[2], mr.rmax[0], mr.rmax[1], mr.rmax[2], rkey);   // MO:265 on the root (MO:331)
                             L.mfound = 0;
+                            const int rootBlock = rfl(mr.rootBlock);
+                            if (rootBlock < 0) {   // the root is a leaf: one bucket
+                                const int r0 = rfl(mr.rootRef), rc = rfl(mr.rootCount);
+                                if (rc > 0 && __any(inRoot)) {
+                                    if (inRoot) {
+                                        L.leafKey = rkey; L.leafNode = ROOT_NODE;
+                                        pk_scan_leaf(refT, r0, r0 + rc, L, S, true, [&]() { return rkey; });
+                                    }
+                                }
+                            } else {
+                                const unsigned long long lanes0 = __ballot(inRoot);
+                                if (lanes0 != 0ull)
+                                    pk_walk(blocks, refT, leafNB, leafTB, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]),
+                                            mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]), lanes0);
+                            }
+                            if (L.mfound) {   // OSM:370-378
+                                L.mesh = m; C.obj = o;
+                                merge_mesh_result(L, C);
+                                L.mfound = 0;
+                            }
                         }
                     }
                 }
@@ -472,11 +493,11 @@ int packet_blocks_per_cu(int mode) {
 void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     dim3 g((unsigned)gridBlocks), b(256);
     if (A.mode == MODE_MESH)
-        hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S.snodes, S.srefs, S.objects, S.objMesh, S, A);
+        hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
     else if (A.mode == MODE_SCENE)
-        hipExtLaunchKernelGGL((k_packet<MODE_SCENE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S.snodes, S.srefs, S.objects, S.objMesh, S, A);
+        hipExtLaunchKernelGGL((k_packet<MODE_SCENE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
     else
-        hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S.snodes, S.srefs, S.objects, S.objMesh, S, A);
+        hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
 }
 
 }  // namespace xrt

@@ -8,7 +8,7 @@
 namespace xrt {
 
 size_t SceneArrays::bytes() const {
-    return (blocks.size() + refN.size() + snodes.size() + shade.size() + leafNB.size() + leafTB.size()) * sizeof(f4) + refT.size() * sizeof(float) + refG.size() * sizeof(g3) +
+    return (blocks.size() + refN.size() + snodes.size() + shade.size() + leafNB.size() + leafTB.size() + scull.size()) * sizeof(f4) + refT.size() * sizeof(float) + refG.size() * sizeof(g3) +
            (childDfs.size() + srefs.size() + objMesh.size()) * sizeof(int) + meshes.size() * sizeof(MeshRec) +
            objects.size() * sizeof(ObjRec) + materials.size() * sizeof(MaterialRec) + texels.size() * sizeof(uint32_t);
 }
@@ -284,6 +284,14 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
         A.objMesh.insert(A.objMesh.end(), o.meshes.begin(), o.meshes.end());
         A.objects.push_back(r);
     }
+    for (int o : A.srefs) {   // the pre-cull records in scene-leaf order (one 64-byte scalar load per body for the packet kernel)
+        const ObjRec &r = A.objects[(size_t)o];
+        A.scull.push_back(f4{r.cullMin[0], r.cullMin[1], r.cullMin[2], r.cullMin[3]});
+        A.scull.push_back(f4{r.cullMax[0], r.cullMax[1], r.cullMax[2], r.cullMax[3]});
+        A.scull.push_back(f4{r.cullK2, i2f(r.cullOk), i2f(o), i2f(r.meshStart)});
+        A.scull.push_back(f4{i2f(r.meshCount), 0, 0, 0});
+    }
+    for (int k = 0; k < 4; k++) A.scull.push_back(f4{0, 0, 0, 0});   // one record of padding: the packet kernel requests the next record a body ahead
     // never hand out empty arrays (a zero-size allocation has no address)
     // two dummy references at the end: the wave-packet kernel requests the next triangle's record before it knows the leaf has ended
     for (int k = 0; k < 2; k++) { A.refN.push_back(f4{0, 0, 0, i2f(-1)}); for (int j = 0; j < 3; j++) A.refG.push_back(g3{0, 0, 0}); }
@@ -418,7 +426,7 @@ SceneView HostScene::host_view() const {
     const SceneArrays &A = arrays;
     S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data(); S.leafNB = A.leafNB.data(); S.leafTB = A.leafTB.data(); S.refT = A.refT.data();
     S.refN = A.refN.data(); S.refG = A.refG.data(); S.meshes = A.meshes.data();
-    S.snodes = A.snodes.data(); S.srefs = A.srefs.data(); S.objects = A.objects.data(); S.objMesh = A.objMesh.data();
+    S.snodes = A.snodes.data(); S.srefs = A.srefs.data(); S.scull = A.scull.data(); S.objects = A.objects.data(); S.objMesh = A.objMesh.data();
     S.nMeshes = (int)meshes.size(); S.nObjects = (int)objects.size();
     S.sceneDepth = A.sceneDepth + 1; S.meshDepth = A.meshDepth + 1;
     return S;

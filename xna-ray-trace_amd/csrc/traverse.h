@@ -28,6 +28,8 @@ struct SceneView {
     const MeshRec *meshes;
     const f4 *snodes;       // scene octree, 2 per record
     const int *srefs;       // object id per scene leaf reference
+    const f4 *scull;        // 4 per scene leaf reference: the body's pre-cull record where the packet kernel's scalar loads find it without the
+                            // srefs -> objects chain: (cullMin.xyz, k0) (cullMax.xyz, k1) (k2, cullOk, object id, meshStart) (meshCount, -, -, -)
     const ObjRec *objects;
     const int *objMesh;
     int nMeshes, nObjects;
@@ -299,20 +301,22 @@ XRT_HD void merge_mesh_result(Lane &L, SC &C) {
 XRT_HD void ray_axis(const RayPre &w, int k, float &o, float &d, float &inv) {
     o = k == 0 ? w.o.x : (k == 1 ? w.o.y : w.o.z); d = k == 0 ? w.d.x : (k == 1 ? w.d.y : w.d.z); inv = k == 0 ? w.inv.x : (k == 1 ? w.inv.y : w.inv.z);
 }
+// (cmn = cullMin[0..3], cmx = cullMax[0..3], k2 = cullK2 of an ObjRec: the packet kernel reads them from SceneView::scull)
 template <class W>
-XRT_HD bool precull_hit(const W &w, const ObjRec &ob) {
+XRT_HD bool precull_box(const W &w, const f4 &cmn, const f4 &cmx, float k2) {
     float ox, oy, oz, dd, ii;
     ray_axis(w, 0, ox, dd, ii); ray_axis(w, 1, oy, dd, ii); ray_axis(w, 2, oz, dd, ii);
     const float r = (fabsf(ox) + fabsf(oy)) + fabsf(oz);   // >= |o|
-    const float m = cull_margin(ob, r);
+    const float m = cmn.w + (cmx.w + k2 * r) * r;          // m(r) of ObjRec (xrt_core.h cull_margin)
     if (!(m <= 1.0e30f)) return true;   // an overflowing or NaN margin: no cull
+    const float mn[3] = {cmn.x, cmn.y, cmn.z}, mx[3] = {cmx.x, cmx.y, cmx.z};
     float tmin = 0.0f, tmax = FLT_MAX;
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float o, d, inv;
         ray_axis(w, k, o, d, inv);
-        const float lo = ob.cullMin[k] - m, hi = ob.cullMax[k] + m;
+        const float lo = mn[k] - m, hi = mx[k] + m;
         if (fabsf(d) < 1e-06f) ok = ok && !(o < lo || o > hi);
         else {
             const float t1 = ((d < 0.0f ? hi : lo) - o) * inv, t2 = ((d < 0.0f ? lo : hi) - o) * inv;
@@ -320,6 +324,10 @@ XRT_HD bool precull_hit(const W &w, const ObjRec &ob) {
         }
     }
     return ok && !(tmin > tmax);
+}
+template <class W>
+XRT_HD bool precull_hit(const W &w, const ObjRec &ob) {
+    return precull_box(w, f4{ob.cullMin[0], ob.cullMin[1], ob.cullMin[2], ob.cullMin[3]}, f4{ob.cullMax[0], ob.cullMax[1], ob.cullMax[2], ob.cullMax[3]}, ob.cullK2);
 }
 
 template <class Stack, class SC>
