@@ -13,6 +13,7 @@ frames), its rays and the rays that reach the traversal kernels.  Reported per c
                                    here) and the gather itself, ESTIMATED as (N-1)/N of the frame's bytes over one xGMI link at
                                    153 GB/s plus 10 us of launch latency (MI355X_MICROARCH.md has no measured RCCL figure)
     predicted_with_fixed           t_whole / (max_r t_shard[r] + fixed_ms)
+    period_*, predicted_throughput_scaling[_with_fixed]   the same with the frame PERIOD of two frames in flight (what bench.py --gpus N times)
 A shard of 1/N of the tiles is NOT 1/N of the time: launches of persistent waves have a floor (5-6 us each, ten per frame) and a
 tail that does not shrink, which is exactly what this tool is for."""
 import argparse
@@ -31,13 +32,29 @@ XGMI_LINK_GBS = 153.0
 
 
 def timed(fr, reps):
+    """Median GPU time of a blocking frame (xrt_stats.ms_total: the latency one call sees) and the period of the same frame rendered the way
+    bench.py times it: two tickets open, frame i+1 enqueued before frame i is waited for (launch tails of one frame fill with the other's work)."""
     for _ in range(3):
         st = fr()
     ms = []
     for _ in range(reps):
         st = fr()
         ms.append(st["ms_total"])
-    return statistics.median(ms), st
+    k = max(6, 2 * reps)
+    t_open = fr.begin()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        t_next = fr2_begin(fr)
+        fr.end(t_open)
+        t_open = t_next
+    fr.end(t_open)
+    torch.cuda.synchronize()
+    return statistics.median(ms), st, (time.perf_counter() - t0) / (k + 1) * 1e3
+
+
+def fr2_begin(fr):
+    return fr.begin()
 
 
 def main():
@@ -53,17 +70,17 @@ def main():
         scene, tracer = xrt.configs.build_product(spec)
         W, H = spec.width, spec.height
         whole = torch.zeros(W * H, dtype=torch.int32, device="cuda")
-        t_whole, st_whole = timed(tracer.PrepareDevice(whole.data_ptr()), args.reps)
-        cfg = {"width": W, "height": H, "t_whole_ms": round(t_whole, 4), "rays_whole": int(st_whole["rays_closest"] + st_whole["rays_shadow"]),
+        t_whole, st_whole, p_whole = timed(tracer.PrepareDevice(whole.data_ptr()), args.reps)
+        cfg = {"width": W, "height": H, "t_whole_ms": round(t_whole, 4), "period_whole_ms": round(p_whole, 4), "rays_whole": int(st_whole["rays_closest"] + st_whole["rays_shadow"]),
                "rays_traversed_whole": int(st_whole["rays_traversed"]), "shards": {}}
         for n in (2, 4, 8):
             tx, ty, tpr = xrt.dist.shard_layout(W, H, n)
             count = tpr * 512
             gathered = torch.zeros(n * count, dtype=torch.int32, device="cuda")
-            ts, rays, trav = [], [], []
+            ts, ps, rays, trav = [], [], [], []
             for r in range(n):
-                t, st = timed(tracer.PrepareDevice(gathered[r * count:(r + 1) * count].data_ptr(), shard_rank=r, shard_count=n), args.reps)
-                ts.append(t); rays.append(int(st["rays_closest"] + st["rays_shadow"])); trav.append(int(st["rays_traversed"]))
+                t, st, per = timed(tracer.PrepareDevice(gathered[r * count:(r + 1) * count].data_ptr(), shard_rank=r, shard_count=n), args.reps)
+                ts.append(t); ps.append(per); rays.append(int(st["rays_closest"] + st["rays_shadow"])); trav.append(int(st["rays_traversed"]))
             final = torch.zeros(W * H, dtype=torch.int32, device="cuda")
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -78,13 +95,16 @@ def main():
             detile_ms = statistics.median(dts)
             gather_ms = (n - 1) / n * (W * H * 4) / (XGMI_LINK_GBS * 1e9) * 1e3 + 0.010   # every rank sends over its own link; rank 0 receives n-1 buffers
             fixed = detile_ms + gather_ms
-            cfg["shards"][str(n)] = {"t_shard_ms": [round(t, 4) for t in ts], "rays": rays, "rays_traversed": trav,
+            cfg["shards"][str(n)] = {"t_shard_ms": [round(t, 4) for t in ts], "period_shard_ms": [round(t, 4) for t in ps],
+                                     "predicted_throughput_scaling": round(p_whole / max(ps), 3),
+                                     "predicted_throughput_scaling_with_fixed": round(p_whole / (max(ps) + fixed), 3), "rays": rays, "rays_traversed": trav,
                                      "predicted_strong_scaling": round(t_whole / max(ts), 3), "balance": round(sum(ts) / n / max(ts), 3),
                                      "sum_of_shards_over_whole": round(sum(ts) / t_whole, 3),
                                      "fixed_ms": {"detile_measured": round(detile_ms, 4), "gather_estimated": round(gather_ms, 4)},
                                      "predicted_with_fixed": round(t_whole / (max(ts) + fixed), 3)}
-            print("%s N=%d: whole %.3f ms, shards %s ms -> predicted x%.2f (with fixed costs x%.2f), balance %.2f" % (
-                name, n, t_whole, " ".join("%.3f" % t for t in ts), t_whole / max(ts), t_whole / (max(ts) + fixed), sum(ts) / n / max(ts)), flush=True)
+            print("%s N=%d: blocking: whole %.3f ms, shards %s ms -> predicted x%.2f (with fixed costs x%.2f), balance %.2f | two in flight: whole %.3f ms, shards %s ms -> x%.2f (with fixed x%.2f)" % (
+                name, n, t_whole, " ".join("%.3f" % t for t in ts), t_whole / max(ts), t_whole / (max(ts) + fixed), sum(ts) / n / max(ts),
+                p_whole, " ".join("%.3f" % t for t in ps), p_whole / max(ps), p_whole / (max(ps) + fixed)), flush=True)
         out["configs"][name] = cfg
         del tracer, scene
     out["time"] = time.strftime("%Y-%m-%dT%H:%M:%S")

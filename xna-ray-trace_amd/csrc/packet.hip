@@ -93,7 +93,7 @@ __device__ __forceinline__ void pk_scan_leaf(const float *__restrict__ refT, int
 // whose ray passed the root's own box test (MO:265 / MO:331).  On return every lane's L.mfound / mKey / mDist / mU / mV / mRef /
 // mLeaf hold its answer of MeshOctree.GetRayIntersection (the caller cleared mfound).
 __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const float *__restrict__ refT, const f4 *__restrict__ leafNB,
-                                        const f4 *__restrict__ leafTB, const SceneView &S, int cullMin, unsigned *stk, int lane, Lane &L,
+                                        const f4 *__restrict__ leafTB, const int *__restrict__ runBase, const f4 *__restrict__ runTB, const SceneView &S, int cullMin, unsigned *stk, int lane, Lane &L,
                                         const RayCull &RC, bool fastL, int rootBlock, v3 rmin, v3 rmax, unsigned long long lanes0) {
     PkUniform U;
     U.blk = rootBlock;
@@ -180,33 +180,48 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
                 go = go && !leaf_certainly_missed(L.r, RC, tb[0], tb[1], tb[2], tb[3]);
                 if (!__any(go)) continue;
             }
-            if (go) {   // the lanes of this leaf, selected once for all its triangles
-                L.leafKey = key; L.leafNode = node;
-                // (kept inline: as a function of its own the same loop costs 13 more VGPRs, i.e. the sixth wave per SIMD)
-                const char *pt = reinterpret_cast<const char *>(refT) + (size_t)r0 * TRI_REC_BYTES;
-                auto test = [&](const TriWords &q, int r) {
-                    const bool f = !(facing(mk(q.w[0], q.w[1], q.w[2]), L.r.d) > 0.0f) & (f2i(q.w[3]) != L.ignoreId);   // RE:48-51, MO:290
-                    v3 T; float det, row2;
-                    const v3 gb = mk(q.w[7], q.w[8], q.w[9]), gc = mk(q.w[10], q.w[11], q.w[12]);
-                    const bool sA = tri_stage_a(L.r.o, L.r.d, mk(q.w[4], q.w[5], q.w[6]), gb, gc, T, det, row2) & f;
-                    if (sA) {   // one wave-level branch per triangle (s_cbranch_execz): most are rejected by the sign of u for every lane
-                        float u, v, t;
-                        if (tri_stage_b(L.r.d, gb, gc, T, det, row2, u, v, t)) {
-                            if (!keyed) L.leafKey = entry_key();
-                            leaf_candidate(L, S, r, -2, true, u, v, t);   // (the ignored triangle was filtered above: -2 matches no id)
+            // A leaf of LEAF_RUN_MIN references or more is scanned run by run (LEAF_RUN references each, SceneView::runTB): every run has a
+            // tight box of its own and a run no lane can reach is passed over -- the octree stops splitting at 50 triangles (MO:42) and a
+            // coherent packet comes near only a few of them.  Smaller leaves are one run.
+            int nRuns = 1, rb = -1;
+            if (r1 - r0 >= LEAF_RUN_MIN) { rb = runBase[node]; if (rb >= 0) nRuns = (r1 - r0 + LEAF_RUN - 1) / LEAF_RUN; }
+            for (int jr = 0; jr < nRuns; jr++) {
+                int ra = r0, rz = r1;
+                bool goR = go;
+                if (rb >= 0) {
+                    ra = r0 + LEAF_RUN * jr; rz = min(ra + LEAF_RUN, r1);
+                    const f4 *tb = runTB + 4 * (size_t)(rb + jr);
+                    goR = go && !leaf_certainly_missed(L.r, RC, tb[0], tb[1], tb[2], tb[3]);
+                    if (!__any(goR)) continue;
+                }
+                if (goR) {   // the lanes of this run, selected once for all its triangles
+                    L.leafKey = key; L.leafNode = node;
+                    // (kept inline: as a function of its own the same loop costs 13 more VGPRs, i.e. the sixth wave per SIMD)
+                    const char *pt = reinterpret_cast<const char *>(refT) + (size_t)ra * TRI_REC_BYTES;
+                    auto test = [&](const TriWords &q, int r) {
+                        const bool f = !(facing(mk(q.w[0], q.w[1], q.w[2]), L.r.d) > 0.0f) & (f2i(q.w[3]) != L.ignoreId);   // RE:48-51, MO:290
+                        v3 T; float det, row2;
+                        const v3 gb = mk(q.w[7], q.w[8], q.w[9]), gc = mk(q.w[10], q.w[11], q.w[12]);
+                        const bool sA = tri_stage_a(L.r.o, L.r.d, mk(q.w[4], q.w[5], q.w[6]), gb, gc, T, det, row2) & f;
+                        if (sA) {   // one wave-level branch per triangle (s_cbranch_execz): most are rejected by the sign of u for every lane
+                            float u, v, t;
+                            if (tri_stage_b(L.r.d, gb, gc, T, det, row2, u, v, t)) {
+                                if (!keyed) L.leafKey = entry_key();
+                                leaf_candidate(L, S, r, -2, true, u, v, t);   // (the ignored triangle was filtered above: -2 matches no id)
+                            }
                         }
+                    };
+                    TriWords qA = *reinterpret_cast<const TriWords *>(pt);
+                    int r = ra;
+                    for (;;) {
+                        const TriWords qB = *reinterpret_cast<const TriWords *>(pt + TRI_REC_BYTES);
+                        test(qA, r);
+                        if (r + 1 >= rz) break;
+                        qA = *reinterpret_cast<const TriWords *>(pt + 2 * TRI_REC_BYTES);
+                        test(qB, r + 1);
+                        r += 2; pt += 2 * TRI_REC_BYTES;
+                        if (r >= rz) break;
                     }
-                };
-                TriWords qA = *reinterpret_cast<const TriWords *>(pt);
-                int r = r0;
-                for (;;) {
-                    const TriWords qB = *reinterpret_cast<const TriWords *>(pt + TRI_REC_BYTES);
-                    test(qA, r);
-                    if (r + 1 >= r1) break;
-                    qA = *reinterpret_cast<const TriWords *>(pt + 2 * TRI_REC_BYTES);
-                    test(qB, r + 1);
-                    r += 2; pt += 2 * TRI_REC_BYTES;
-                    if (r >= r1) break;
                 }
             }
             if (!keyed) anyFound = __any(L.mfound != 0);
@@ -266,7 +281,8 @@ template <int M> __device__ __forceinline__ unsigned *scene_frames() {
 #endif
 template <int M>
 __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k_packet(const f4 *__restrict__ blocks, const float *__restrict__ refT,
-                                                const f4 *__restrict__ leafNB, const f4 *__restrict__ leafTB, const MeshRec *__restrict__ meshes,
+                                                const f4 *__restrict__ leafNB, const f4 *__restrict__ leafTB, const int *__restrict__ runBase,
+                                                const f4 *__restrict__ runTB, const MeshRec *__restrict__ meshes,
                                                 const f4 *__restrict__ snodes, const f4 *__restrict__ scull, const ObjRec *__restrict__ objects,
                                                 const int *__restrict__ objMesh, SceneView S, PacketArgs A) {
     __shared__ unsigned frames[4 * PK_LEVELS * PK_FRAME_WORDS];
@@ -329,7 +345,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
             // the lanes inside the root box of an interior root (MO:265; lane_begin left them in ST_NODE with mask 1 -- a root that is a
             // leaf is k_intersect's business: packet_supported)
             const unsigned long long lanes0 = mr.rootBlock < 0 ? 0ull : __ballot(valid && L.state == ST_NODE && L.mask != 0);
-            pk_walk(blocks, refT, leafNB, leafTB, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]),
+            pk_walk(blocks, refT, leafNB, leafTB, runBase, runTB, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]),
                     mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]), lanes0);
             L.mesh = mesh;
             if (valid) {
@@ -450,7 +466,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
                             } else {
                                 const unsigned long long lanes0 = __ballot(inRoot);
                                 if (lanes0 != 0ull)
-                                    pk_walk(blocks, refT, leafNB, leafTB, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]),
+                                    pk_walk(blocks, refT, leafNB, leafTB, runBase, runTB, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]),
                                             mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]), lanes0);
                             }
                             if (L.mfound) {   // OSM:370-378
@@ -493,11 +509,11 @@ int packet_blocks_per_cu(int mode) {
 void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     dim3 g((unsigned)gridBlocks), b(256);
     if (A.mode == MODE_MESH)
-        hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
+        hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.runBase, S.runTB, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
     else if (A.mode == MODE_SCENE)
-        hipExtLaunchKernelGGL((k_packet<MODE_SCENE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
+        hipExtLaunchKernelGGL((k_packet<MODE_SCENE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.runBase, S.runTB, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
     else
-        hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
+        hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.runBase, S.runTB, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
 }
 
 }  // namespace xrt

@@ -8,8 +8,8 @@
 namespace xrt {
 
 size_t SceneArrays::bytes() const {
-    return (blocks.size() + refN.size() + snodes.size() + shade.size() + leafNB.size() + leafTB.size() + scull.size()) * sizeof(f4) + refT.size() * sizeof(float) + refG.size() * sizeof(g3) +
-           (childDfs.size() + srefs.size() + objMesh.size()) * sizeof(int) + meshes.size() * sizeof(MeshRec) +
+    return (blocks.size() + refN.size() + snodes.size() + shade.size() + leafNB.size() + leafTB.size() + scull.size() + runTB.size()) * sizeof(f4) + refT.size() * sizeof(float) + refG.size() * sizeof(g3) +
+           (childDfs.size() + srefs.size() + objMesh.size() + runBase.size()) * sizeof(int) + meshes.size() * sizeof(MeshRec) +
            objects.size() * sizeof(ObjRec) + materials.size() * sizeof(MaterialRec) + texels.size() * sizeof(uint32_t);
 }
 
@@ -149,6 +149,41 @@ static void object_cull_box(const HostObject &o, const std::vector<HostMesh> &me
     r.cullOk = 1;
 }
 
+// Tight-box record of the triangles t.leafRefs[b0 .. b1) of mesh m (xrt_core.h leaf_certainly_missed; DESIGN.md §3 "Tight leaf boxes"):
+// [0] = (vertex box min, K = C u0 max_t |E1||E2|/|E1 x E2| * safety), [1] = (vertex box max, longest edge), [2] = (min of the unit geometric
+// normals, ok), [3] = (their max, -), all rounded outwards.  The bound behind it holds for ANY set of triangles -- a leaf, or a run of
+// consecutive references of a leaf.  rec stays zero (ok = 0: never skipped) when a triangle is outside the magnitudes the analysis assumes.
+static void tight_box_record(const HostMesh &m, const std::vector<int> &leafRefs, int b0, int b1, double safety, f4 rec[4]) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, nlo[3] = {2, 2, 2}, nhi[3] = {-2, -2, -2};
+    double aMax = 0, eMax = 0;
+    bool ok = b1 > b0;
+    for (int r = b0; r < b1 && ok; r++) {
+        const float *p = &m.v[(size_t)leafRefs[r] * 9];
+        const float e1f[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]}, e2f[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};   // RE:54-55, as stored in refG
+        const double e1[3] = {e1f[0], e1f[1], e1f[2]}, e2[3] = {e2f[0], e2f[1], e2f[2]};
+        const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+        const double ln = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        // magnitudes the error analysis assumes (no overflow, no subnormal products)
+        if (!(l1 >= 1e-9 && l2 >= 1e-9 && l1 <= 1e12 && l2 <= 1e12 && ln > 0 && l1 * l2 / ln <= 1e6)) { ok = false; break; }
+        aMax = std::fmax(aMax, l1 * l2 / ln);
+        eMax = std::fmax(eMax, std::fmax(l1, l2));
+        for (int k = 0; k < 3; k++) {
+            const double v[3] = {(double)p[k], (double)p[k] + e1[k], (double)p[k] + e2[k]};
+            for (double x : v) { if (!(std::fabs(x) <= 1e12)) ok = false; lo[k] = std::fmin(lo[k], x); hi[k] = std::fmax(hi[k], x); }
+            nlo[k] = std::fmin(nlo[k], n[k] / ln); nhi[k] = std::fmax(nhi[k], n[k] / ln);
+        }
+    }
+    if (ok && safety > 0.0) {
+        auto down = [](double x) { return std::nextafterf((float)x, -INFINITY); };
+        auto up = [](double x) { return std::nextafterf((float)x, INFINITY); };
+        rec[0] = f4{down(lo[0]), down(lo[1]), down(lo[2]), up((double)LEAF_CULL_C * std::ldexp(1.0, -24) * aMax * safety)};
+        rec[1] = f4{up(hi[0]), up(hi[1]), up(hi[2]), up(eMax)};
+        rec[2] = f4{down(nlo[0] - 1e-6), down(nlo[1] - 1e-6), down(nlo[2] - 1e-6), 1.0f};
+        rec[3] = f4{up(nhi[0] + 1e-6), up(nhi[1] + 1e-6), up(nhi[2] + 1e-6), 0.0f};
+    }
+}
+
 bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
     if (meshThreshold <= 0) meshThreshold = 50;    // MO:42
     if (sceneThreshold <= 0) sceneThreshold = 20;  // OSM:50
@@ -195,38 +230,23 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
                 // ... and the tight box of the leaf (xrt_core.h leaf_certainly_missed): vertex box, box of the unit geometric normals,
                 // K = C u0 max |E1||E2|/|E1 x E2| and the longest edge, all rounded outwards
                 f4 rec[4] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
+                int runFirst = -1;
                 if (!((masks >> c) & 1)) {
                     const int b0 = lref + off(c), b1 = lref + (c == 7 ? total : off(c + 1));
-                    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, nlo[3] = {2, 2, 2}, nhi[3] = {-2, -2, -2};
-                    double aMax = 0, eMax = 0;
-                    bool ok = b1 > b0;
-                    for (int r = b0; r < b1 && ok; r++) {
-                        const float *p = &m.v[(size_t)t.leafRefs[r] * 9];
-                        const float e1f[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]}, e2f[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};   // RE:54-55, as stored in refG
-                        const double e1[3] = {e1f[0], e1f[1], e1f[2]}, e2[3] = {e2f[0], e2f[1], e2f[2]};
-                        const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-                        const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
-                        const double ln = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                        // magnitudes the error analysis assumes (no overflow, no subnormal products)
-                        if (!(l1 >= 1e-9 && l2 >= 1e-9 && l1 <= 1e12 && l2 <= 1e12 && ln > 0 && l1 * l2 / ln <= 1e6)) { ok = false; break; }
-                        aMax = std::fmax(aMax, l1 * l2 / ln);
-                        eMax = std::fmax(eMax, std::fmax(l1, l2));
-                        for (int k = 0; k < 3; k++) {
-                            const double v[3] = {(double)p[k], (double)p[k] + e1[k], (double)p[k] + e2[k]};
-                            for (double x : v) { if (!(std::fabs(x) <= 1e12)) ok = false; lo[k] = std::fmin(lo[k], x); hi[k] = std::fmax(hi[k], x); }
-                            nlo[k] = std::fmin(nlo[k], n[k] / ln); nhi[k] = std::fmax(nhi[k], n[k] / ln);
+                    tight_box_record(m, t.leafRefs, b0, b1, leafCullSafety, rec);
+                    // ... and the same record for every run of LEAF_RUN consecutive references of a leaf of at least LEAF_RUN_MIN (the
+                    // bound holds for any set of triangles): a ray that reaches the leaf's box still tests only the runs it can reach
+                    if (b1 - b0 >= LEAF_RUN_MIN) {
+                        runFirst = (int)(A.runTB.size() / 4);
+                        for (int ra = b0; ra < b1; ra += LEAF_RUN) {
+                            f4 rr[4] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
+                            tight_box_record(m, t.leafRefs, ra, ra + LEAF_RUN < b1 ? ra + LEAF_RUN : b1, leafCullSafety, rr);
+                            for (const f4 &q : rr) A.runTB.push_back(q);
                         }
-                    }
-                    if (ok && leafCullSafety > 0.0) {
-                        auto down = [](double x) { return std::nextafterf((float)x, -INFINITY); };
-                        auto up = [](double x) { return std::nextafterf((float)x, INFINITY); };
-                        rec[0] = f4{down(lo[0]), down(lo[1]), down(lo[2]), up((double)LEAF_CULL_C * std::ldexp(1.0, -24) * aMax * leafCullSafety)};
-                        rec[1] = f4{up(hi[0]), up(hi[1]), up(hi[2]), up(eMax)};
-                        rec[2] = f4{down(nlo[0] - 1e-6), down(nlo[1] - 1e-6), down(nlo[2] - 1e-6), 1.0f};
-                        rec[3] = f4{up(nhi[0] + 1e-6), up(nhi[1] + 1e-6), up(nhi[2] + 1e-6), 0.0f};
                     }
                 }
                 for (const f4 &q : rec) A.leafTB.push_back(q);
+                A.runBase.push_back(runFirst);
             }
         }
         for (int tri : t.leafRefs) {   // leaf references in leaf order: normal stream + geometry stream
@@ -311,6 +331,8 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
     if (A.blocks.empty()) A.blocks.assign(2, f4{0, 0, 0, 0});
     if (A.leafNB.empty()) A.leafNB.assign(16, f4{0, 0, 0, 0});
     if (A.leafTB.empty()) A.leafTB.assign(32, f4{0, 0, 0, 0});
+    if (A.runBase.empty()) A.runBase.assign(8, -1);
+    for (int k = 0; k < 8; k++) A.runTB.push_back(f4{0, 0, 0, 0});   // (padding: the packet kernel may request the record after a leaf's last run)
     if (A.childDfs.empty()) A.childDfs.assign(8, -1);
     built = true;
     return true;
@@ -424,7 +446,7 @@ bool HostScene::load(const char *path, std::string &err) {
 SceneView HostScene::host_view() const {
     SceneView S;
     const SceneArrays &A = arrays;
-    S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data(); S.leafNB = A.leafNB.data(); S.leafTB = A.leafTB.data(); S.refT = A.refT.data();
+    S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data(); S.leafNB = A.leafNB.data(); S.leafTB = A.leafTB.data(); S.runBase = A.runBase.data(); S.runTB = A.runTB.data(); S.refT = A.refT.data();
     S.refN = A.refN.data(); S.refG = A.refG.data(); S.meshes = A.meshes.data();
     S.snodes = A.snodes.data(); S.srefs = A.srefs.data(); S.scull = A.scull.data(); S.objects = A.objects.data(); S.objMesh = A.objMesh.data();
     S.nMeshes = (int)meshes.size(); S.nObjects = (int)objects.size();

@@ -17,6 +17,8 @@ constexpr int SHADE_F4 = 6;   // f4 per triangle shading record:
 struct SceneArrays {
     std::vector<f4> blocks, refN, snodes, shade, leafNB;   // leafNB: 2 per node: component-wise min / max of the leaf's surface normals
     std::vector<float> refT;                               // refN + refG as one 13-word record per reference, 16 words of padding at the end
+    std::vector<f4> runTB;                                 // 4 per run of LEAF_RUN references of a big leaf: the run's tight box (same record as leafTB)
+    std::vector<int> runBase;                              // per node: index of the leaf's first run in runTB / 4, or -1 (small leaf, interior, empty)
     std::vector<f4> scull;                                 // 4 per scene leaf reference (traverse.h SceneView::scull)
     std::vector<f4> leafTB;                                // 4 per node: the leaf's tight box (xrt_core.h leaf_certainly_missed)
     std::vector<g3> refG;

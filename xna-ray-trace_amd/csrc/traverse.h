@@ -22,6 +22,8 @@ struct SceneView {
     const int *childDfs;    // 8 per block: DFS pre-order index of child c
     const f4 *leafNB;       // 2 per node: component-wise min / max of the leaf's surface normals
     const f4 *leafTB;       // 4 per node: the leaf's tight box (xrt_core.h leaf_certainly_missed)
+    const int *runBase;     // per node: first run record of a leaf of >= LEAF_RUN_MIN references (index into runTB / 4), else -1
+    const f4 *runTB;        // 4 per run of LEAF_RUN consecutive references: the run's tight box (same form as leafTB)
     const f4 *refN;         // per leaf reference: (surfaceNormal.xyz, global triangle id)
     const g3 *refG;         // 3 per leaf reference: v1, E1, E2
     const float *refT;      // the same two streams as one record of TRI_REC_WORDS words per reference (k_packet's scalar loads)

@@ -262,6 +262,9 @@ XRT_HD bool tri_test_front(v3 O, v3 D, v3 v1, v3 E1, v3 E2, float &u, float &v, 
 // this evaluation itself.  kappa = inf (a ray in a triangle's plane, a degenerate triangle) grows the box over everything.
 // Record: [0] = (lo.xyz, K = C u0 max_t |E1||E2|/|N|), [1] = (hi.xyz, Emax), [2] = (nlo.xyz, ok), [3] = (nhi.xyz, -).
 constexpr float LEAF_CULL_C = 192.0f;
+// Leaves of at least LEAF_RUN_MIN references also carry one such record per run of LEAF_RUN consecutive references (SceneView::runTB):
+// the octree stops splitting at MO:42's 50 triangles, and a ray that reaches a leaf's box usually comes near only a few of them.
+constexpr int LEAF_RUN = 8, LEAF_RUN_MIN = 16;
 constexpr int TRI_REC_WORDS = 13, TRI_REC_BYTES = 52;   // refT: (surface normal, global triangle id, v1, E1, E2)
 struct RayCull {
     float d2;    // |D|_2, or 0 when the ray takes no part (a component of D below 2^-40 |D| or non-finite, |O| above 2^40)
