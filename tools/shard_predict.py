@@ -61,6 +61,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("configs", nargs="*", default=["C4", "C5"])
     ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--n", default="2,4,8", help="shard counts")
     ap.add_argument("--out", default=os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "shard_predict.json"))
     args = ap.parse_args()
     out = {"what": "one-GPU PREDICTION of image-tile strong scaling: every shard rendered alone on one MI355X; not a multi-GPU measurement",
@@ -73,7 +74,7 @@ def main():
         t_whole, st_whole, p_whole = timed(tracer.PrepareDevice(whole.data_ptr()), args.reps)
         cfg = {"width": W, "height": H, "t_whole_ms": round(t_whole, 4), "period_whole_ms": round(p_whole, 4), "rays_whole": int(st_whole["rays_closest"] + st_whole["rays_shadow"]),
                "rays_traversed_whole": int(st_whole["rays_traversed"]), "shards": {}}
-        for n in (2, 4, 8):
+        for n in [int(x) for x in args.n.split(",")]:
             tx, ty, tpr = xrt.dist.shard_layout(W, H, n)
             count = tpr * 512
             gathered = torch.zeros(n * count, dtype=torch.int32, device="cuda")

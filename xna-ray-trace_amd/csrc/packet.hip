@@ -43,6 +43,15 @@ constexpr int PK_SLEVELS = 12;       // scene octree levels a packet can stack (
 constexpr int PK_SFRAME_WORDS = 4;   // scene block, pending children, lanes (2)
 constexpr int PK_SGPRS = 112;        // SGPR allocation the kernel may reach (checked against the ISA in tests/test_numerics_contract.py)
 
+// make variant NAME=cnt DEFS=-DXRT_PK_COUNTERS: event counts of the shared walk (development aid; tools/pk_counters.py reads them through
+// xrt_debug_packet_counters, which exists only in such a build)
+#ifdef XRT_PK_COUNTERS
+__device__ unsigned long long g_pkCounters[16];
+#define PKC(i) (pkc[i]++)
+#else
+#define PKC(i) ((void)0)
+#endif
+
 struct PkUniform {   // wave-uniform cursor
     int blk, p, dm0;
     unsigned long long lanes;
@@ -95,6 +104,11 @@ __device__ __forceinline__ void pk_scan_leaf(const float *__restrict__ refT, int
 __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const float *__restrict__ refT, const f4 *__restrict__ leafNB,
                                         const f4 *__restrict__ leafTB, const int *__restrict__ runBase, const f4 *__restrict__ runTB, const SceneView &S, int cullMin, unsigned *stk, int lane, Lane &L,
                                         const RayCull &RC, bool fastL, int rootBlock, v3 rmin, v3 rmax, unsigned long long lanes0) {
+#ifdef XRT_PK_COUNTERS
+    unsigned pkc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    pkc[0] = 1;
+    pkc[12] = (unsigned)__popcll(lanes0);
+#endif
     PkUniform U;
     U.blk = rootBlock;
     U.bmin = rmin;
@@ -114,6 +128,7 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
     while (U.lanes != 0ull) {
         const bool in = ((U.lanes >> lane) & 1ull) != 0;
         if (entering) {
+            PKC(1);
             const f4 lo = blocks[2 * (size_t)U.blk], hi = blocks[2 * (size_t)U.blk + 1];
             d0 = f2i(lo.x); d1 = f2i(lo.y); d2 = f2i(lo.z); d3 = f2i(lo.w);
             offLo = (unsigned long long)(unsigned)f2i(hi.x) | ((unsigned long long)(unsigned)f2i(hi.y) << 32);
@@ -138,6 +153,7 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
         if (U.p == 0) {   // block exhausted: back to the level above
             if (sp == 0) break;
             sp--;
+            PKC(10);
             const unsigned *f = stk + sp * PK_FRAME_WORDS;
             U.blk = rfl((int)f[0]); U.p = rfl((int)f[1]); U.dm0 = rfl((int)f[2]);
             U.lanes = (unsigned long long)(unsigned)rfl((int)f[3]) | ((unsigned long long)(unsigned)rfl((int)f[4]) << 32);
@@ -153,6 +169,7 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
         }
         const int c = (int)__builtin_ctz((unsigned)U.p) ^ U.dm0;
         U.p &= U.p - 1;
+        PKC(2);
         const bool inC = in && ((cb >> c) & 1);
         v3 cmin, cmax;
         child_box(U.bmin, U.half, c, cmin, cmax);
@@ -168,11 +185,17 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
         const bool keyed = anyFound;   // wave-uniform
         float key = 0.0f;
         if (keyed && inC) key = entry_key();
+#ifdef XRT_PK_COUNTERS
+        if (keyed) pkc[11]++;
+        pkc[13] += (unsigned)__popcll(__ballot(inC));
+#endif
         const int node = U.blk * 8 + c;
         if (!((d2 >> c) & 1)) {   // ---- leaf (non-empty): MO:288-304 for the lanes the bucket rule lets in ----
+            PKC(3);
             const f4 nlo = leafNB[2 * (size_t)node], nhi = leafNB[2 * (size_t)node + 1];
             bool go = inC && !(L.mfound && key > L.mKey) && !all_back_facing(nlo, nhi, L.r.d);
             if (!__any(go)) continue;
+            PKC(4);
             const int r0 = d1 + child_ref_offset(offLo, offHi, c);
             const int r1 = d1 + ((c == 7) ? d3 : child_ref_offset(offLo, offHi, c + 1));
             if (r1 - r0 >= cullMin) {   // lanes whose ray cannot reach any triangle of the leaf (xrt_core.h leaf_certainly_missed) stay out of it
@@ -180,6 +203,7 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
                 go = go && !leaf_certainly_missed(L.r, RC, tb[0], tb[1], tb[2], tb[3]);
                 if (!__any(go)) continue;
             }
+            PKC(5);
             // A leaf of LEAF_RUN_MIN references or more is scanned run by run (LEAF_RUN references each, SceneView::runTB): every run has a
             // tight box of its own and a run no lane can reach is passed over -- the octree stops splitting at 50 triangles (MO:42) and a
             // coherent packet comes near only a few of them.  Smaller leaves are one run.
@@ -191,9 +215,15 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
                 if (rb >= 0) {
                     ra = r0 + LEAF_RUN * jr; rz = min(ra + LEAF_RUN, r1);
                     const f4 *tb = runTB + 4 * (size_t)(rb + jr);
+                    PKC(6);
                     goR = go && !leaf_certainly_missed(L.r, RC, tb[0], tb[1], tb[2], tb[3]);
                     if (!__any(goR)) continue;
                 }
+                PKC(7);
+#ifdef XRT_PK_COUNTERS
+                pkc[8] += (unsigned)(rz - ra);
+                pkc[14] += (unsigned)(rz - ra) * (unsigned)__popcll(__ballot(goR));
+#endif
                 if (goR) {   // the lanes of this run, selected once for all its triangles
                     L.leafKey = key; L.leafNode = node;
                     // (kept inline: as a function of its own the same loop costs 13 more VGPRs, i.e. the sixth wave per SIMD)
@@ -250,6 +280,9 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
         U.lanes = LL;
         entering = true;
     }
+#ifdef XRT_PK_COUNTERS
+    if (lane == 0) for (int i = 0; i < 16; i++) if (pkc[i]) atomicAdd(&g_pkCounters[i], (unsigned long long)pkc[i]);
+#endif
 }
 
 // Scene mode: what a lane keeps for the whole query but touches only between mesh walks -- the world ray and its scene-level best
@@ -302,12 +335,20 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
     // slower for shadow and reflection packets; runs of 8 packets scattered over the image -- 20 % slower, the cache locality
     // between neighbouring waves is worth more than the balance.)  The grid is sized to be resident at once (packet_blocks_per_cu).
     const int nWaves = (int)gridDim.x * 4, waveId = (int)blockIdx.x * 4 + wave;
-    const int staticPer = A.staticDiv > 0 ? nPk / (nWaves * A.staticDiv) : 0, qBase = nWaves * staticPer;
+    // (a launch of few packets per wave -- a tile shard of a frame, a later generation -- still hands every wave its FIRST packet without
+    // an atomic: 6144 waves asking one queue word at once are served at ~12 ns each, the last of them 70 us into a 350 us launch)
+    int staticPer = A.staticDiv > 0 ? nPk / (nWaves * A.staticDiv) : 0;
+    if (staticPer == 0) staticPer = 1;
+    const int qBase = min(nWaves * staticPer, nPk);
     int sNext = 0, dNext = 0, dEnd = 0, left = nPk - qBase;
     for (;;) {
         int pk;
-        if (sNext < staticPer) { pk = sNext * nWaves + waveId; sNext++; }
+        if (sNext < staticPer) {
+            pk = sNext * nWaves + waveId; sNext++;
+            if (pk >= nPk) { if (qBase >= nPk) break; continue; }   // (only where the static share is the one packet per wave above)
+        }
         else {
+            if (qBase >= nPk) break;
             if (dNext >= dEnd) {
                 int want = left / (nWaves * 2);
                 want = want < 1 ? 1 : (want > A.grabMax ? A.grabMax : want);
@@ -505,6 +546,14 @@ int packet_blocks_per_cu(int mode) {
     if (nb > bySgpr) nb = bySgpr;
     return nb > 8 ? 8 : nb;
 }
+
+#ifdef XRT_PK_COUNTERS
+extern "C" int xrt_debug_packet_counters(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pkCounters), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pkCounters), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     dim3 g((unsigned)gridBlocks), b(256);
