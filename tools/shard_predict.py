@@ -10,8 +10,9 @@ frames), its rays and the rays that reach the traversal kernels.  Reported per c
     predicted_strong_scaling       t_whole / max_r t_shard[r]           (what N devices would give if nothing else cost time)
     balance                        mean_r t_shard / max_r t_shard       (1 = perfectly even tiles)
     fixed_ms                       per-frame costs that do not shrink with N: the de-tile kernel over the gathered buffers (measured
-                                   here) and the gather itself, ESTIMATED as (N-1)/N of the frame's bytes over one xGMI link at
-                                   153 GB/s plus 10 us of launch latency (MI355X_MICROARCH.md has no measured RCCL figure)
+                                   here) and the gather itself, ESTIMATED as one rank's tile buffer over one xGMI link at 153 GB/s (every rank
+                                   has a link of its own to rank 0, the transfers run side by side) plus 10 us of launch latency
+                                   (MI355X_MICROARCH.md has no measured RCCL figure)
     predicted_with_fixed           t_whole / (max_r t_shard[r] + fixed_ms)
     period_*, predicted_throughput_scaling[_with_fixed]   the same with the frame PERIOD of two frames in flight (what bench.py --gpus N times)
 A shard of 1/N of the tiles is NOT 1/N of the time: launches of persistent waves have a floor (5-6 us each, ten per frame) and a
@@ -75,7 +76,10 @@ def main():
         cfg = {"width": W, "height": H, "t_whole_ms": round(t_whole, 4), "period_whole_ms": round(p_whole, 4), "rays_whole": int(st_whole["rays_closest"] + st_whole["rays_shadow"]),
                "rays_traversed_whole": int(st_whole["rays_traversed"]), "shards": {}}
         for n in [int(x) for x in args.n.split(",")]:
-            tx, ty, tpr = xrt.dist.shard_layout(W, H, n)
+            import ctypes as C
+            c_tpr = C.c_int32()
+            xrt.abi.check(xrt.abi.lib().xrt_shard_layout(W, H, n, None, None, C.byref(c_tpr)))   # (the library's own layout: variants may differ)
+            tpr = c_tpr.value
             count = tpr * 512
             gathered = torch.zeros(n * count, dtype=torch.int32, device="cuda")
             ts, ps, rays, trav = [], [], [], []
@@ -94,7 +98,7 @@ def main():
                 dts.append(e0.elapsed_time(e1))
             assert torch.equal(final, whole), "sharded frame differs from the whole frame"
             detile_ms = statistics.median(dts)
-            gather_ms = (n - 1) / n * (W * H * 4) / (XGMI_LINK_GBS * 1e9) * 1e3 + 0.010   # every rank sends over its own link; rank 0 receives n-1 buffers
+            gather_ms = (count * 4) / (XGMI_LINK_GBS * 1e9) * 1e3 + 0.010   # every rank sends its tile buffer over its OWN link to rank 0 (point-to-point xGMI): the n-1 transfers run side by side
             fixed = detile_ms + gather_ms
             cfg["shards"][str(n)] = {"t_shard_ms": [round(t, 4) for t in ts], "period_shard_ms": [round(t, 4) for t in ps],
                                      "predicted_throughput_scaling": round(p_whole / max(ps), 3),

@@ -554,7 +554,7 @@ void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long
 __device__ __forceinline__ bool path_pixel(const RayGenParams &g, long long pix, int &x, int &y) {
     long long slot = pix >> 9;
     int within = (int)(pix & 511);
-    long long t = slot * g.shardCount + g.shardRank;
+    long long t = shard_tile(slot, g.shardRank, g.shardCount, g.tilesX);
     if (t >= (long long)g.tilesX * g.tilesY) return false;
     const unsigned ti = (unsigned)t;   // tilesX * tilesY < 2^31: one 32-bit division instead of two 64-bit ones
     const int ty = (int)(ti / (unsigned)g.tilesX), tx = (int)(ti - (unsigned)ty * (unsigned)g.tilesX);
@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(256) void k_detile(int width, int height, int shard
         }
         long long slot = rem >> 9;
         int within = (int)(rem & 511);
-        long long t = slot * shardCount + rank;
+        long long t = shard_tile(slot, rank, shardCount, tilesX);
         if (t >= (long long)tilesX * tilesY) continue;
         const unsigned ti = (unsigned)t, tyq = ti / (unsigned)tilesX;
         int wx, wy;

@@ -521,7 +521,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const int R = opts->max_reflections;
     const int nL = nLights;
     const long long totalTiles = (long long)g.tilesX * g.tilesY;
-    const long long myTiles = (totalTiles + g.shardCount - 1) / g.shardCount;   // tiles_per_rank (slots, some may be past the end)
+    const long long myTiles = shard_tiles_per_rank(totalTiles, g.shardCount, g.tilesX);   // tiles_per_rank (slots, some may be past the end)
     const long long totalPixels = myTiles * 512;
     if (adaptive && totalPixels * 4 > 0x7fffffffLL) return fail(XRT_E_UNSUPPORTED, "frame too large for adaptive supersampling");
     const long long framePaths = totalPixels * g.samples;   // the whole frame (this shard)
@@ -927,7 +927,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     validPixels = 0;
     const long long slot0 = partStart / (512LL * g.samples), slot1 = (partStart + firstPaths + 512LL * g.samples - 1) / (512LL * g.samples);   // tile slots of this part
     for (long long sl = slot0; sl < slot1; sl++) {
-        const long long t = sl * g.shardCount + g.shardRank;
+        const long long t = shard_tile(sl, g.shardRank, g.shardCount, g.tilesX);
         if (t >= totalTiles) break;
         int tx = (int)(t % g.tilesX), ty = (int)(t / g.tilesX);
         int w = g.width - tx * XRT_TILE_W; if (w > XRT_TILE_W) w = XRT_TILE_W;
@@ -1768,7 +1768,7 @@ int xrt_shard_layout(int32_t width, int32_t height, int32_t shard_count, int32_t
     int tx = (width + XRT_TILE_W - 1) / XRT_TILE_W, ty = (height + XRT_TILE_H - 1) / XRT_TILE_H;
     if (tiles_x_out) *tiles_x_out = tx;
     if (tiles_y_out) *tiles_y_out = ty;
-    if (tiles_per_rank_out) *tiles_per_rank_out = (int)(((long long)tx * ty + shard_count - 1) / shard_count);
+    if (tiles_per_rank_out) *tiles_per_rank_out = (int)shard_tiles_per_rank((long long)tx * ty, shard_count, tx);
     return XRT_OK;
 }
 

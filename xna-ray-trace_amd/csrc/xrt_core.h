@@ -117,6 +117,26 @@ struct LightRec {       // 64 B
     int    pad0, pad1;
 };
 
+// Image-tile shards: the frame's 64x8-pixel tiles are numbered row-major and dealt to the ranks in GROUPS of consecutive
+// tiles, group q -> rank q % N.  Slot s of rank r (its s-th tile, in tile order) is tile ((s / G) * N + r) * G + s % G.
+// XRT_SHARD_GROUP: G; 0 = one group per tile row.  G = 1 (single tiles round-robin) is the ABI (xrt.h); groups of 4 or 15 tiles and whole
+// tile rows measured the same per-shard frame period on C4 and C5 at eight shards (profiles/r03/shard_group_experiment.txt).
+#ifndef XRT_SHARD_GROUP
+#define XRT_SHARD_GROUP 1
+#endif
+XRT_HD int shard_group(int tilesX) { return XRT_SHARD_GROUP > 0 ? XRT_SHARD_GROUP : tilesX; }
+XRT_HD long long shard_tile(long long slot, int rank, int count, int tilesX) {
+    const int G = shard_group(tilesX);
+    if (count <= 1 || G == 1) return slot * count + rank;
+    const long long q = slot / G;
+    return (q * count + rank) * G + (slot - q * G);
+}
+XRT_HD long long shard_tiles_per_rank(long long totalTiles, int count, int tilesX) {
+    const int G = shard_group(tilesX);
+    const long long groups = (totalTiles + G - 1) / G;
+    return ((groups + count - 1) / count) * G;
+}
+
 // Position of path slot `within` (0..511) inside its 64x8-pixel tile.  A wavefront takes 64 consecutive slots; laid out as
 // eight 8x8-pixel blocks side by side (Z-order inside a block) they cover a square patch of the image instead of a 64-pixel line, so the 64 rays of a
 // wave stay close together in the scene (fewer distinct octree leaves per wave, for the per-lane and the wave-packet kernel
