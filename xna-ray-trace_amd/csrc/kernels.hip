@@ -745,24 +745,30 @@ __device__ __forceinline__ v3 lookup_uv(const ShadeView &V, const MaterialRec &M
 //   part A, generation k   : the closest-hit answers.  Misses end their path (RT:729-733); every hit takes a slot, emits one
 //                            shadow ray per light (RT:535-537 -> RT:482-485) and -- the reflected / refracted directions
 //                            depend on the hit alone, not on the lighting -- the rays of generation k+1 (RT:545-559,
-//                            RT:656-698).  Launch #k+1 traces both sets together.
-//   part B, generation k-1 : the shadow answers of launch #k: light accumulation (RT:534-542), surface colour
-//                            (RT:568-581 / 711-724) and the level record the return path (k_compose) needs.
+//                            RT:656-698); and everything else that depends on the hit alone goes into the level record
+//                            now: fragment normal, surface colour (RT:568-581 / 711-724), Reflectiveness.  Launch #k+1 traces
+//                            both ray sets together.
+//   part B, generation k-1 : the shadow answers of launch #k: light accumulation (RT:534-542) into the level record the return
+//                            path (k_compose) needs.  It reads 48 bytes per hit (slot, parked normal, world position) where it
+//                            used to read the 48-byte hit, the material and the shading record a second time.
 __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V, ShadeArgs X) {
     __shared__ int ldsCounts[17];
     const int stride = (int)(gridDim.x * blockDim.x);
     const int tid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const size_t P = (size_t)X.P;
     if (X.doB) {
+        // Generation k-1: everything that depends on the hit alone (fragment normal, surface colour, Reflectiveness) was computed by
+        // part A of the previous step and waits in the level record; what is left is the light sum, which needs the shadow answers:
+        // 16 + 16 + 16 bytes in (slot, record, world position) instead of the 48-byte hit, the material and the shading record again.
         int n = *X.scntPrev;
         if (n > X.shadowCap) n = X.shadowCap;
         for (int s = tid; s < n; s += stride) {
             const SlotRec rec = X.slotPrev[s];
-            int hit, object, mesh, tri; float u, v, d; v3 w;
-            load_hit(X.hitsPrev + rec.ray, hit, object, mesh, tri, u, v, d, w);
-            const int gtri = V.meshes[mesh].triBase + tri;
-            const MaterialRec M = V.materials[V.meshes[mesh].material];
-            const v3 normal = fragment_normal(V, gtri, M.flags, u, v);
+            const size_t at = (size_t)rec.node * P + (size_t)rec.path;
+            const f4 nr = X.lvlA[at];   // (normal.xyz, Reflectiveness), left by part A
+            const v3 normal = mk(nr.x, nr.y, nr.z);
+            const Hit16 hw = reinterpret_cast<const Hit16 *>(X.hitsPrev + rec.ray)[2];
+            const v3 w = mk(i2f(hw.i0), i2f(hw.i1), i2f(hw.i2));
             v3 lightResult = mk(0, 0, 0);
             for (int l = 0; l < V.nLights; l++) {
                 const LightRec &Lt = V.lights[l];
@@ -779,23 +785,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
                 }
                 if (lightAmount != 1.0f) lightResult = add(lightResult, scale(light_for_fragment(Lt, w, normal), 1.0f - lightAmount));   // RT:538-541
             }
-            v3 surf;
-            const f4 *sr = V.shade + (size_t)gtri * 6;
-            if (M.flags & MAT_TEXTURE) {   // RT:568-575
-                f4 s0 = sr[0], s1 = sr[1], s2 = sr[2], s4 = sr[4];
-                float uv1x = s0.w, uv1y = s1.w, uv2x = s2.w, uv2y = s4.x, uv3x = s4.y, uv3y = s4.z;
-                float ax = uv2x - uv1x, ay = uv2y - uv1y, bx = uv3x - uv1x, by = uv3y - uv1y;
-                float ix = (uv1x + ax * u) + bx * v, iy = (uv1y + ay * u) + by * v;
-                surf = lookup_uv(V, M, ix, iy);
-            } else {
-                f4 c = sr[3];
-                surf = mk(c.x, c.y, c.z);
-            }
-            const bool transparent = (M.flags & MAT_TRANSPARENT) != 0;
-            const size_t at = (size_t)rec.node * P + (size_t)rec.path;
-            X.lvlA[at] = f4{lightResult.x, lightResult.y, lightResult.z, M.reflectiveness};
-            X.lvlB[at] = f4{surf.x, surf.y, surf.z, i2f(FLAG_HIT | (transparent ? FLAG_TRANSPARENT : 0))};
-            if (X.heap) X.lvlAlpha[at] = sr[3].w;   // triangle.color.W (RT:699)
+            X.lvlA[at] = f4{lightResult.x, lightResult.y, lightResult.z, nr.w};
         }
     }
     if (!X.doA) return;
@@ -829,9 +819,31 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
                 light_dir(V.lights[l], w, dir, dist);
                 store_ray(X.shadowRays + (size_t)slot * V.nLights + l, w, dir, mesh, tri);   // ignore = shaded triangle (RT:485)
             }
+            // the hit's own share of RT:516-581: fragment normal (RT:520-531), surface colour (RT:568-581 / 711-724), Reflectiveness -- final in
+            // lvlB, and (normal, Reflectiveness) parked in lvlA until part B of the next step has the shadow answers for the light sum
+            const int gtri = V.meshes[mesh].triBase + tri;
+            const MaterialRec M = V.materials[V.meshes[mesh].material];
+            const v3 normal = fragment_normal(V, gtri, M.flags, u, v);
+            {
+                v3 surf;
+                const f4 *sr = V.shade + (size_t)gtri * 6;
+                if (M.flags & MAT_TEXTURE) {   // RT:568-575
+                    f4 s0 = sr[0], s1 = sr[1], s2 = sr[2], s4 = sr[4];
+                    float uv1x = s0.w, uv1y = s1.w, uv2x = s2.w, uv2y = s4.x, uv3x = s4.y, uv3y = s4.z;
+                    float ax = uv2x - uv1x, ay = uv2y - uv1y, bx = uv3x - uv1x, by = uv3y - uv1y;
+                    float ix = (uv1x + ax * u) + bx * v, iy = (uv1y + ay * u) + by * v;
+                    surf = lookup_uv(V, M, ix, iy);
+                } else {
+                    f4 c = sr[3];
+                    surf = mk(c.x, c.y, c.z);
+                }
+                const bool transparent = (M.flags & MAT_TRANSPARENT) != 0;
+                const size_t at = (size_t)node * P + (size_t)p;
+                X.lvlA[at] = f4{normal.x, normal.y, normal.z, M.reflectiveness};
+                X.lvlB[at] = f4{surf.x, surf.y, surf.z, i2f(FLAG_HIT | (transparent ? FLAG_TRANSPARENT : 0))};
+                if (X.heap) X.lvlAlpha[at] = sr[3].w;   // triangle.color.W (RT:699)
+            }
             if (emitNext) {
-                const MaterialRec M = V.materials[V.meshes[mesh].material];
-                const v3 normal = fragment_normal(V, V.meshes[mesh].triBase + tri, M.flags, u, v);
                 v3 o, dd; int im, itri;
                 load_ray(X.rays + i, o, dd, im, itri);
                 rdir = normalize(reflect(dd, normal));   // RT:549-550
