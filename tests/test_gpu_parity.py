@@ -315,6 +315,60 @@ def test_adaptive_supersampling(xrt, orc, quality):
             assert tracer.last_stats[k] == o_st[k], (k, tracer.last_stats[k], o_st[k])
 
 
+@pytest.mark.parametrize("quality", [0, 1, 3])
+def test_adaptive_frames_in_flight(xrt, orc, monkeypatch, quality):
+    """Adaptive supersampling without host round trips (RT:128-168 RenderAsync over RT:170-311): the size of every
+    deeper quadrant level stays on the device, so an adaptive frame takes a ticket like a plain one -- two in flight, to device
+    and to host memory, every frame the oracle's, the ray accounting the oracle's (no counting pass: the level sizes come back
+    with the frame's counters).  A level that does not fit its optimistically sized buffers (XRT_ADAPTIVE_CAP forces that) makes
+    the frame render again the careful way -- same pixels -- and XRT_ADAPTIVE_FAST=0 is the careful way from the start."""
+    import torch
+    for spec in (xrt.configs.crate_grid_scene(96, 54), xrt.configs.heightfield_scene(80, 45, m=64)):
+        spec.multisampling, spec.multisample_quality = xrt.abi.MS_ADAPTIVE, quality
+        o_rgba, _, o_st = orc.OracleScene(spec).render(nthreads=8, want_float=False)
+        scene, tracer = xrt.configs.build_product(spec)
+        got = tracer.Render().copy()            # no counting pass: the whole frame is enqueued at once
+        assert np.array_equal(got, o_rgba)
+        for k in ("rays_closest", "rays_shadow", "shaded_hits", "pixels"):
+            assert tracer.last_stats[k] == o_st[k], (k, tracer.last_stats[k], o_st[k])
+        n = spec.width * spec.height
+        outs = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(2)]
+        frs = [tracer.PrepareDevice(o.data_ptr()) for o in outs]
+        for rep in range(3):
+            t0 = frs[0].begin()
+            t1 = frs[1].begin()                 # the second adaptive frame is enqueued while the first is in flight
+            st0 = frs[0].end(t0)
+            st1 = frs[1].end(t1)
+            for o in outs:
+                assert np.array_equal(o.cpu().numpy().view(np.uint32), o_rgba), rep
+                o.zero_()
+            assert st0["rays_closest"] == st1["rays_closest"] == o_st["rays_closest"]
+        hosts = [np.zeros(n, dtype=np.uint32) for _ in range(2)]
+        hfr = [tracer.PrepareHost(h) for h in hosts]
+        t0, t1 = hfr[0].begin(), hfr[1].begin()
+        hfr[0].end(t0); hfr[1].end(t1)
+        for h in hosts:
+            assert np.array_equal(h, o_rgba)
+        if quality > 0:
+            monkeypatch.setenv("XRT_ADAPTIVE_CAP", "8")   # eight quadrants per deeper level: overflows, the frame is rendered again
+            _, tr_small = xrt.configs.build_product(spec)
+            monkeypatch.delenv("XRT_ADAPTIVE_CAP")
+            for _ in range(2):   # (the second frame takes the careful way from the start)
+                assert np.array_equal(tr_small.Render(), o_rgba)
+                assert tr_small.last_stats["rays_closest"] == o_st["rays_closest"]
+            h2 = np.zeros(n, dtype=np.uint32)
+            monkeypatch.setenv("XRT_ADAPTIVE_CAP", "8")
+            _, tr_small2 = xrt.configs.build_product(spec)
+            monkeypatch.delenv("XRT_ADAPTIVE_CAP")
+            f2 = tr_small2.PrepareHost(h2)      # the redo of a host-output frame copies the right pixels again
+            f2.end(f2.begin())
+            assert np.array_equal(h2, o_rgba)
+        monkeypatch.setenv("XRT_ADAPTIVE_FAST", "0")
+        _, tr_careful = xrt.configs.build_product(spec)
+        monkeypatch.delenv("XRT_ADAPTIVE_FAST")
+        assert np.array_equal(tr_careful.Render(), o_rgba)
+
+
 @pytest.mark.parametrize("address", [0, 1, 2])
 @pytest.mark.parametrize("filtering", [0, 1])
 def test_texture_address_modes_and_filters(xrt, orc, address, filtering):

@@ -137,6 +137,7 @@ struct FrameEpilogue {
     int *hostCnt = nullptr;
     int cntWords = 0, zeroWords = 0;
     int *flagSrc = nullptr;
+    int zeroFrom = 0;   // words [zeroFrom, zeroWords) are cleared (an adaptive frame keeps its level counts for the fold kernels)
 };
 void launch_compose_tree(const f4 *lvlA, const f4 *lvlB, const float *lvlAlpha, int count, int P, int maxReflections, uint32_t *sampleColor,
                          float *sampleF32, const StampFold &stamps, const FrameEpilogue &epilogue, hipStream_t st);
@@ -151,16 +152,17 @@ struct ResolveArgs {
     // zeroWords counter / queue words are cleared for the next frame -- no copy or fill commands on the stream
     int *cntSrc = nullptr;
     int *hostCnt = nullptr;
-    int cntWords = 0, zeroWords = 0;
+    int cntWords = 0, zeroWords = 0, zeroFrom = 0;
     StampFold stamps;
 };
 void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P /* level stride */, int maxReflections, uint32_t *sampleColor, float *sampleF32,
                     const ResolveArgs &RA, hipStream_t st, hipEvent_t stopEvent = nullptr);
 void launch_resolve(const RayGenParams &g, const uint32_t *sampleColor, const float *sampleF32, int pixels, long long pixelBase,
-                    uint32_t *out, float *outF32, hipStream_t st);
+                    uint32_t *out, float *outF32, hipStream_t st, int *zeroPtr = nullptr, int zeroN = 0);
 void launch_ms_decide(const RayGenParams &g, const uint32_t *quadColor, const int *nQuadsDev, int nQuadsHost, long long pixelBase, int *childBase,
-                      int *childMask, float *nextCx, float *nextCy, int *nextCount, hipStream_t st);
-void launch_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *childBase, const int *childMask, int n, hipStream_t st);
+                      int *childMask, float *nextCx, float *nextCy, int *nextCount, hipStream_t st, int nextCap = 0, int *overflow = nullptr);
+void launch_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *childBase, const int *childMask, int n, hipStream_t st,
+                    const int *nDev = nullptr);
 void launch_detile(int width, int height, int shardCount, int tilesPerRank, const uint32_t *gathered, long long rankStride, uint32_t *out,
                    hipStream_t st);
 

@@ -570,9 +570,10 @@ __device__ __forceinline__ bool path_pixel(const RayGenParams &g, long long pix,
 // One global atomic per list covers RG_ROUNDS x 1024 consecutive paths of a block (2025 atomics on one word were 20 of
 // the kernel's 21 us on a 1080p frame): the rays are written first, the list slots afterwards.
 constexpr int RG_ROUNDS = 4;
-__global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneView S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P,
+__global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneView S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int Phost,
                                                          long long pathBase, HeavyArgs H) {
     __shared__ int ldsLive[RG_ROUNDS * 16], ldsHeavy[RG_ROUNDS * 16];
+    const int P = pass_paths(g, Phost);
     const f4 rlo = S.snodes[0], rhi = S.snodes[1];
     const int span = RG_ROUNDS * APPEND_BLOCK;
     const int groups = (P + span - 1) / span;
@@ -902,7 +903,7 @@ __device__ __forceinline__ void frame_epilogue(const FrameEpilogue &E) {
         for (int i = (int)threadIdx.x; i < E.zeroWords; i += (int)blockDim.x) {
             const int v = E.cntSrc[i];
             if (i < E.cntWords) E.hostCnt[i] = v;
-            E.cntSrc[i] = 0;
+            if (i >= E.zeroFrom) E.cntSrc[i] = 0;
         }
         if (E.flagSrc && threadIdx.x == 0) { E.hostCnt[E.cntWords] = *E.flagSrc; *E.flagSrc = 0; }
         __threadfence_system();
@@ -936,11 +937,12 @@ __device__ __forceinline__ void fold_stamps(const StampFold &F) {
 }
 
 // The return path of the CastRay recursion: deepest generation first, one RGBA8 quantisation per level.
-__global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32,
+__global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB, int countHost, int P, int maxReflections, uint32_t *sampleColor, float *sampleF32,
                                                  ResolveArgs RA) {
+    const int count = pass_paths(RA.g, countHost);   // (read before the epilogue below may clear the word it comes from)
     {
         FrameEpilogue E;
-        E.cntSrc = RA.cntSrc; E.hostCnt = RA.hostCnt; E.cntWords = RA.cntWords; E.zeroWords = RA.zeroWords;
+        E.cntSrc = RA.cntSrc; E.hostCnt = RA.hostCnt; E.cntWords = RA.cntWords; E.zeroWords = RA.zeroWords; E.zeroFrom = RA.zeroFrom;
         frame_epilogue(E);
     }
     fold_stamps(RA.stamps);
@@ -1061,7 +1063,9 @@ void launch_compose(const f4 *lvlA, const f4 *lvlB, int count, int P, int maxRef
 // Supersample averaging (RT:309: mean of four quantised colours, re-quantised, twice for 16 samples) and the
 // framebuffer write renderTargetData[y*W + x] = color (RT:425) — or the shard's tile-contiguous buffer.
 __global__ __launch_bounds__(256) void k_resolve(RayGenParams g, const uint32_t *sampleColor, const float *sampleF32, int pixels, long long pixelBase,
-                                                 uint32_t *out, float *outF32) {
+                                                 uint32_t *out, float *outF32, int *zeroPtr, int zeroN) {
+    // (an adaptive frame in flight: the quadrant-level counts its fold kernels read are cleared here, by the frame's last kernel)
+    if (zeroPtr && blockIdx.x == 0) for (int i = (int)threadIdx.x; i < zeroN; i += (int)blockDim.x) zeroPtr[i] = 0;
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < pixels; i += (int)(gridDim.x * blockDim.x)) {
         long long pix = pixelBase + i;
         int x, y;
@@ -1097,10 +1101,10 @@ __global__ __launch_bounds__(256) void k_resolve(RayGenParams g, const uint32_t 
     }
 }
 void launch_resolve(const RayGenParams &g, const uint32_t *sampleColor, const float *sampleF32, int pixels, long long pixelBase, uint32_t *out,
-                    float *outF32, hipStream_t st) {
+                    float *outF32, hipStream_t st, int *zeroPtr, int zeroN) {
     int blocks = (pixels + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_resolve, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, g, sampleColor, sampleF32, pixels, pixelBase, out, outF32);
+    hipLaunchKernelGGL(k_resolve, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, g, sampleColor, sampleF32, pixels, pixelBase, out, outF32, zeroPtr, zeroN);
 }
 
 // ---- adaptive supersampling (RT:170-311) ------------------------------------------------------------------------
@@ -1110,9 +1114,10 @@ void launch_resolve(const RayGenParams &g, const uint32_t *sampleColor, const fl
 // to the next level.  Children of one quadrant are appended together, in corner order.
 __global__ __launch_bounds__(APPEND_BLOCK) void k_ms_decide(RayGenParams g, const uint32_t *quadColor, const int *nQuadsDev, int nQuadsHost,
                                                             long long pixelBase, int *childBase, int *childMask, float *nextCx, float *nextCy,
-                                                            int *nextCount) {
+                                                            int *nextCount, int nextCap, int *overflow) {
     __shared__ int ldsCounts[17];
-    const int n = nQuadsDev ? *nQuadsDev : nQuadsHost;
+    int n = nQuadsDev ? *nQuadsDev : nQuadsHost;
+    if (nQuadsDev && n > nQuadsHost) n = nQuadsHost;   // (nQuadsHost: this level's capacity when the count is the device's)
     const int stride = (int)(gridDim.x * blockDim.x);
     const int rounds = (n + stride - 1) / stride;
     for (int it = 0; it < rounds; it++) {
@@ -1152,7 +1157,10 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_ms_decide(RayGenParams g, cons
         __syncthreads();
         const int base = ldsCounts[16] + ldsCounts[wave] + (incl - cnt);
         __syncthreads();
-        if (q < n) {
+        if (q < n && nextCap > 0 && base + cnt > nextCap) {   // the next level's buffers are sized optimistically: the host renders the frame again the careful way
+            *overflow = 1;
+            childBase[q] = 0; childMask[q] = 0;
+        } else if (q < n) {
             childBase[q] = base;
             childMask[q] = mask;
             const float quarter = g.quadSize * 0.25f;
@@ -1167,14 +1175,17 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_ms_decide(RayGenParams g, cons
     }
 }
 void launch_ms_decide(const RayGenParams &g, const uint32_t *quadColor, const int *nQuadsDev, int nQuadsHost, long long pixelBase, int *childBase,
-                      int *childMask, float *nextCx, float *nextCy, int *nextCount, hipStream_t st) {
+                      int *childMask, float *nextCx, float *nextCy, int *nextCount, hipStream_t st, int nextCap, int *overflow) {
     hipLaunchKernelGGL(k_ms_decide, dim3(1024), dim3(APPEND_BLOCK), 0, st, g, quadColor, nQuadsDev, nQuadsHost, pixelBase, childBase, childMask, nextCx,
-                       nextCy, nextCount);
+                       nextCy, nextCount, nextCap, overflow);
 }
 // Fold the results of level l+1 into level l, in the order the recursion assigns them (RT:288-306): UL, UR, LL
 // replace their own corner; the LOWER-RIGHT recursion writes `out urColor` (RT:305), i.e. slot 1, after the
 // upper-right one, and the lower-right corner keeps its first-pass colour.
-__global__ __launch_bounds__(256) void k_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *childBase, const int *childMask, int n) {
+__global__ __launch_bounds__(256) void k_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *childBase, const int *childMask, int nHost,
+                                                 const int *nDev) {
+    int n = nHost;   // (with nDev: the level's capacity)
+    if (nDev) { n = *nDev; if (n > nHost) n = nHost; }
     for (int q = (int)(blockIdx.x * blockDim.x + threadIdx.x); q < n; q += (int)(gridDim.x * blockDim.x)) {
         const int mask = childMask[q];
         if (!mask) continue;
@@ -1189,10 +1200,10 @@ __global__ __launch_bounds__(256) void k_ms_fold(uint32_t *quadColor, const uint
             }
     }
 }
-void launch_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *childBase, const int *childMask, int n, hipStream_t st) {
+void launch_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *childBase, const int *childMask, int n, hipStream_t st, const int *nDev) {
     int blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_ms_fold, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, quadColor, childColor, childBase, childMask, n);
+    hipLaunchKernelGGL(k_ms_fold, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, quadColor, childColor, childBase, childMask, n, nDev);
 }
 
 // rank-major gathered tiles -> W*H frame (rank 0 after the RCCL gather)

@@ -225,6 +225,9 @@ struct xrt_scene {
         DevBuf<uint32_t> sampleColor;
         DevBuf<float> sampleF32;
         DevBuf<LightRec> lights;
+        // adaptive supersampling in flight (RT:170-311 without host round trips): the quadrant levels' buffers belong to the frame context
+        struct Level { DevBuf<uint32_t> color; DevBuf<int> childBase, childMask; DevBuf<float> cx, cy; } levels[8];
+        bool levelWordsClean = false;           // the level-count words at the head of cnts are zero (k_resolve cleared them)
         bool heapFlagClean = false;
         bool cntsClean = false;                 // cnts is all zero (the previous frame's epilogue cleared what it counted)
         std::vector<LightRec> lightsOnDevice;   // what `lights` holds
@@ -236,6 +239,7 @@ struct xrt_scene {
             path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); stamps.release(); hitFlags0.release(); hitFlags1.release(); shadowFlags.release();
             node0.release(); node1.release(); heapFlag.release(); ref0.release(); ref1.release(); lvlAlpha.release(); slot0.release(); slot1.release();
             lvlA.release(); lvlB.release(); sampleColor.release(); sampleF32.release(); lights.release();
+            for (auto &l : levels) { l.color.release(); l.childBase.release(); l.childMask.release(); l.cx.release(); l.cy.release(); }
             if (stream) (void)hipStreamDestroy(stream);
             stream = nullptr;
         }
@@ -266,6 +270,8 @@ struct xrt_scene {
         int *pinnedDev = nullptr;    // device view of `pinned`
         long long framePaths = 0;    // paths of the frame (part) this context holds: key of the grid hints
         bool heap = false, redone = false;   // a ray-tree frame; ... that overflowed on the optimistic way and was rendered again
+        bool adaptiveFast = false;           // an adaptive frame enqueued without host round trips (level sizes stay on the device)
+        int cntBase = 0, levelCap = 0, quality = 0;   // words in front of the per-pass counters in `pinned`; quadrant capacity of a deeper level
         xrt_camera redoCam; xrt_render_opts redoOpts; std::vector<xrt_light> redoLights;
         uint32_t *redoOut = nullptr; float *redoOutF32 = nullptr; hipStream_t redoSt = nullptr;
         int stampRows = 0;           // traversal launches of the frame that timed themselves (device_util.h)
@@ -291,6 +297,8 @@ struct xrt_scene {
     int splitMode = 0, splitParts = 2;
     bool launchEvents = false;   // XRT_LAUNCH_EVENTS=1: single-chunk frames time their traversal launches with events on the dispatch packets, too
     int maxStampRows = MAX_STAMP_ROWS;   // XRT_STAMP_ROWS=<n> (tests): launches of a frame beyond the n-th carry events instead
+    bool adaptiveFastOk = true;  // adaptive frames are enqueued whole (level buffers sized optimistically) until a level overflows; XRT_ADAPTIVE_FAST=0
+    long long adaptiveCap = 0;   // XRT_ADAPTIVE_CAP=<quadrants> (tests): capacity of the deeper levels instead of one quadrant per pixel
     bool heapFastOk = true;      // single-chunk ray-tree frames go the optimistic way (no host round trip) until one overflows; XRT_HEAP_FAST=0
     bool noGridHints = false;    // XRT_GRID_HINTS=0: every launch is sized for the whole chip
     bool noLaunchTiming = false; // XRT_LAUNCH_TIMING=0: single-chunk frames do not time their traversal launches (xrt_stats.ms_intersect = 0)
@@ -445,6 +453,7 @@ int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g
     g.quadLevel = -1; g.quadCx = nullptr; g.quadCy = nullptr; g.quadSize = 1.0f;
     g.cullX0 = 0; g.cullY0 = 0; g.cullX1 = g.width - 1; g.cullY1 = g.height - 1;
     g.cullSkipsRecord = 0;
+    g.pathsDev = nullptr; g.pathsMul = 1; g.pathsCap = 0;
     if (g.shardRank < 0 || g.shardRank >= g.shardCount) return fail(XRT_E_INVALID_ARG, "shard_rank out of range");
     if (rootBox) {
         // Screen rectangle of the scene's root box.  A ray through pixel (x, y) that reaches the box at a point P has P
@@ -586,15 +595,22 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // ray-tree frames take that way from the start.  Not where something is enqueued behind the frame that a redo cannot recall
     // (the in-library gather of n_gpus > 1).
     const bool heapFast = heap && heapFastAllowed && s->heapFastOk && nParts == 1;
-    const bool fast = !adaptive && (!heap || heapFast) && firstPaths <= chunkPaths && !opts->collect_stats;
+    // ... and an adaptive frame (RT:170-311) whose passes are one chunk each: the sizes of the deeper quadrant levels stay on the device
+    // (k_ms_decide counts, the next level's kernels read the count), the level buffers are sized optimistically -- one quadrant per
+    // pixel and level -- and a level that does not fit sets the same kind of word.
+    const bool adaptiveFast = adaptive && !heap && heapFastAllowed && s->adaptiveFastOk && nParts == 1 && !opts->collect_stats && totalPixels * 4 <= chunkPaths &&
+                              (quality + 2) * (R + 2) * 2 + 2 <= MAX_STAMP_ROWS;
+    const bool fast = (adaptive ? adaptiveFast : (!heap || heapFast)) && firstPaths <= chunkPaths && !opts->collect_stats;
     F.fast = fast;
     F.heap = heap;
     F.redone = false;
-    if (heapFast && fast) {   // what a redo needs
+    F.adaptiveFast = adaptiveFast && fast;
+    F.cntBase = 0;
+    if ((heapFast || adaptiveFast) && fast) {   // what a redo needs
         F.redoCam = *cam; F.redoOpts = *opts; F.redoLights.assign(lights, lights + nLights);
         F.redoOut = d_out; F.redoOutF32 = d_outF32; F.redoSt = st;
     }
-    F.framePaths = nParts == 1 ? firstPaths : -1;
+    F.framePaths = (nParts == 1 && !adaptive) ? firstPaths : -1;
     // the traversal launches time themselves on the device clock instead of carrying events (device_util.h); a frame of more
     // than MAX_STAMP_ROWS launches (many chunks or supersampling levels) goes on with events
     const bool useStamps = !s->launchEvents && !s->noLaunchTiming && s->wallClockKHz > 0;
@@ -627,7 +643,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const int pkAuto = s->sceneMode == MODE_SCENE ? ((long long)g.width * g.height * g.samples >= (6LL << 20) ? 23 : 7) : (g.samples >= 16 ? 7 : 0);
     const int pkMask = (s->packetOk && !heap) ? (s->packetMask >= 0 ? s->packetMask : pkAuto) : 0;
     const bool laneClosest = (pkMask & 5) != 5;   // some closest-hit generation is traced ray by ray: the long-ray feedback has a reader
-    const bool wantFeedback = fast && !heap && s->deepMeshes && !s->noFeedback && laneClosest;
+    const bool wantFeedback = fast && !heap && !adaptive && s->deepMeshes && !s->noFeedback && laneClosest;   // (the paths of a deeper quadrant level are a list: no stable key)
     {   // The other context's frame may still be running on another stream.  Two single-chunk frames share nothing they
         // write except scheduling hints; anything else (counting pass, supersampling levels, ray tree, a cost map
         // about to be reallocated or released) runs alone.
@@ -701,7 +717,11 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // Intersect launch #k traces the closest-hit rays of generation k together with the shadow rays of generation k-1
     // (both exist once k_shade has looked at the hits of generation k-1); k_shade #k then shades generation k-1 with the
     // shadow answers and turns the hits of generation k into shadow rays and the rays of generation k+1.
-    auto enqueue_chunk = [&](const RayGenParams &gp, int *cnt, unsigned *q, int Pc, long long pathBase) -> int {
+    bool startEvent = fast;   // the frame's first raygen launch carries its start event (fast frames put nothing but kernels on the stream)
+    // (sampleOut: where the chunk's quantised colours go -- the context's sample buffer, or a quadrant level's colour array; epi: the
+    // frame epilogue this chunk's compose kernel carries, if any)
+    auto enqueue_chunk = [&](const RayGenParams &gp, int *cnt, unsigned *q, int Pc, long long pathBase, uint32_t *sampleOut = nullptr,
+                             const FrameEpilogue *epi = nullptr) -> int {
         int *scnt = cnt + (R + 2), *hcnt = cnt + 2 * (R + 2);
         const int chunkRow0 = F.stampRows;
         // "long ray first" (kernels.hip): the producer of generation k lists its long rays, launch #k takes them first
@@ -722,7 +742,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             return H;
         };
         // cnt[0] counts the primary rays that reach the scene's root box; index0 lists them
-        { Range r("xrt raygen"); launch_raygen(gp, S, rays[0], W.lvlB.p, W.index0.p, cnt, Pc, pathBase, heavy_for(0), st, fast ? e0 : nullptr); }
+        { Range r("xrt raygen"); launch_raygen(gp, S, rays[0], W.lvlB.p, W.index0.p, cnt, Pc, pathBase, heavy_for(0), st, startEvent ? e0 : nullptr); startEvent = false; }
         xrt_hit *hitsOf[2] = {W.hits.p, W.hits1.p};
         int *flagsOf[2] = {W.hitFlags0.p, W.hitFlags1.p};
         SlotRec *slotOf[2] = {W.slot0.p, W.slot1.p};
@@ -813,8 +833,9 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             ResolveArgs RA;
             RA.fused = fuseResolve ? 1 : 0; RA.g = gp; RA.pixelBase = pathBase; RA.out = d_out; RA.outF32 = d_outF32;
             RA.stamps = fold;
-            if (fast) { RA.cntSrc = cnt; RA.hostCnt = F.pinnedDev; RA.cntWords = cntStride; RA.zeroWords = cntStride + qStride; }
-            launch_compose(W.lvlA.p, W.lvlB.p, Pc, P, R, W.sampleColor.p, (wantF32 && !fuseResolve) ? W.sampleF32.p : nullptr, RA, st,
+            if (epi) { RA.cntSrc = epi->cntSrc; RA.hostCnt = epi->hostCnt; RA.cntWords = epi->cntWords; RA.zeroWords = epi->zeroWords; RA.zeroFrom = epi->zeroFrom; }
+            else if (fast && !adaptive) { RA.cntSrc = cnt; RA.hostCnt = F.pinnedDev; RA.cntWords = cntStride; RA.zeroWords = cntStride + qStride; }
+            launch_compose(W.lvlA.p, W.lvlB.p, Pc, P, R, sampleOut ? sampleOut : W.sampleColor.p, (wantF32 && !fuseResolve) ? W.sampleF32.p : nullptr, RA, st,
                            (fast && fuseResolve) ? e1 : nullptr);
         }
         return XRT_OK;
@@ -942,8 +963,59 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             return XRT_OK;
         }, 0.0f, 1.0f, true);
         if (rc != XRT_OK) return rc;
+    } else if (F.adaptiveFast) {
+        // RenderFirstPass / GetColorForQuadrant (RT:170-311) without a host round trip: every level's pass is enqueued now.  Level 0 has
+        // one quadrant per pixel; how many quadrants a deeper level has only the device knows (k_ms_decide counts them into lvlCnt[l],
+        // the level's ray generation, compose and fold kernels read that word; the traversal and shading kernels follow the ray
+        // counts as always).  Deeper levels get room for one quadrant per pixel (XRT_ADAPTIVE_CAP); a level that needs more sets the
+        // overflow word and frame_finish renders the frame again the careful way below.
+        const int nPass = quality + 1;
+        constexpr int LW = 16;   // words in front of the per-pass counters: lvlCnt[0 .. quality], overflow word at LW - 1
+        const long long capDeep = s->adaptiveCap > 0 ? std::min(s->adaptiveCap, totalPixels) : totalPixels;
+        auto cap_of = [&](int l) { return l == 0 ? totalPixels : capDeep; };
+        const size_t words = (size_t)LW + (size_t)nPass * cntStride + (size_t)nPass * qStride;
+        const int *cntsBefore = W.cnts.p;
+        if ((rc = W.cnts.ensure(words)) || (rc = ensure_pinned(((size_t)LW + (size_t)nPass * cntStride) * sizeof(int) + 64))) return rc;
+        if (!W.cntsClean || W.cnts.p != cntsBefore) HIPCHECK(hipMemsetAsync(W.cnts.p, 0, W.cnts.cap * sizeof(int), st));
+        W.cntsClean = false;
+        for (int l = 0; l <= quality; l++) {
+            auto &Lv = W.levels[l];
+            const size_t c = (size_t)cap_of(l);
+            if ((rc = Lv.color.ensure(c * 4))) return rc;
+            if (l < quality && ((rc = Lv.childBase.ensure(c)) || (rc = Lv.childMask.ensure(c)))) return rc;
+            if (l > 0 && ((rc = Lv.cx.ensure(c)) || (rc = Lv.cy.ensure(c)))) return rc;
+        }
+        int *const lvlCnt = W.cnts.p, *const ovf = W.cnts.p + LW - 1;
+        int *const cnt0 = W.cnts.p + LW;
+        unsigned *const q0 = reinterpret_cast<unsigned *>(cnt0 + (size_t)nPass * cntStride);
+        float size = 1.0f;
+        for (int l = 0; l <= quality; l++) {
+            auto &Lv = W.levels[l];
+            RayGenParams gl = g;
+            gl.quadLevel = l; gl.quadSize = size; gl.quadCx = Lv.cx.p; gl.quadCy = Lv.cy.p;
+            if (l > 0) { gl.pathsDev = lvlCnt + l; gl.pathsMul = 4; gl.pathsCap = (int)cap_of(l); }
+            FrameEpilogue E;
+            const bool last = l == quality;
+            if (last) { E.cntSrc = W.cnts.p; E.hostCnt = F.pinnedDev; E.cntWords = LW + nPass * cntStride; E.zeroWords = (int)words; E.zeroFrom = LW; }
+            if ((rc = enqueue_chunk(gl, cnt0 + (size_t)l * cntStride, q0 + (size_t)l * qStride, (int)(cap_of(l) * 4), 0, Lv.color.p, last ? &E : nullptr))) return rc;
+            if (l < quality) {   // RT:279-306
+                auto &Nx = W.levels[l + 1];
+                launch_ms_decide(gl, Lv.color.p, l > 0 ? lvlCnt + l : nullptr, (int)cap_of(l), 0, Lv.childBase.p, Lv.childMask.p, Nx.cx.p, Nx.cy.p, lvlCnt + l + 1, st,
+                                 (int)cap_of(l + 1), ovf);
+                size = size / 2.0f;   // RT:290
+            }
+        }
+        for (int l = quality - 1; l >= 0; l--)
+            launch_ms_fold(W.levels[l].color.p, W.levels[l + 1].color.p, W.levels[l].childBase.p, W.levels[l].childMask.p, (int)cap_of(l), st, l > 0 ? lvlCnt + l : nullptr);
+        RayGenParams g0 = g;
+        g0.quadLevel = 0; g0.quadSize = 1.0f;
+        launch_resolve(g0, W.levels[0].color.p, nullptr, (int)totalPixels, 0, d_out, d_outF32, st, lvlCnt, LW);   // ... and clears the level words for the next frame
+        HIPCHECK(hipEventRecord(e1, st));
+        W.cntsClean = true;
+        F.tallyChunks = nPass; F.cntBase = LW; F.levelCap = (int)capDeep; F.quality = quality;
     } else {
-        // RenderFirstPass / GetColorForQuadrant (RT:170-311): level 0 quadrants are the pixels (size 1); a level's
+        // RenderFirstPass / GetColorForQuadrant (RT:170-311), the careful way (a host read-back of every level's size): level 0
+        // quadrants are the pixels (size 1); a level's
         // quadrants each cast four rays; corners that deviate are subdivided into the next level, down to
         // MultisampleQuality; results fold back up.
         struct Level { DevBuf<uint32_t> color; DevBuf<int> childBase, childMask; DevBuf<float> cx, cy; long long n = 0; };
@@ -1015,6 +1087,26 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
         if (FILE *f = fopen(s->stampDumpPath.c_str(), "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
     }
     const int R = F.R;
+    if (F.fast && F.adaptiveFast && ((const int *)F.pinned)[F.cntBase - 1] != 0) {
+        // A quadrant level of the adaptive frame did not fit its optimistically sized buffers: the frame is rendered again the careful
+        // way (a host read-back per level, exact sizes), and so are this scene's later adaptive frames from the start.
+        s->adaptiveFastOk = false;
+        F.tallyChunks = 0;
+        F.adaptiveFast = false;
+        const std::vector<xrt_light> lights = F.redoLights;
+        const xrt_camera cam = F.redoCam;
+        const xrt_render_opts opts = F.redoOpts;
+        int rc = frame_begin(s, F, &cam, lights.data(), (int)lights.size(), &opts, F.redoOut, F.redoOutF32, F.redoSt);
+        if (rc != XRT_OK) return rc;
+        rc = frame_finish(s, F, stats);
+        F.redone = true;
+        return rc;
+    }
+    if (F.fast && F.adaptiveFast) {   // rays of the frame: four per level-0 pixel and four per quadrant of every deeper level
+        const int *lw = (const int *)F.pinned;
+        F.livePaths = F.validPixels * 4ull;
+        for (int l = 1; l <= F.quality; l++) F.livePaths += 4ull * (unsigned long long)std::min(lw[l], F.levelCap);
+    }
     if (F.fast && F.heap && F.tallyChunks == 1 && ((const int *)F.pinned)[F.cntStride] != 0) {
         // A generation of the ray tree did not fit the optimistically sized buffers: the frame is rendered again the careful way
         // (chunks, overflow checks, retries with fewer paths), and so are this scene's later ray-tree frames from the start.
@@ -1032,7 +1124,7 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
     if (F.tallyChunks > 0) {   // single-pass frame: the read-back was left in flight
         const size_t nb = (size_t)F.tallyChunks * F.cntStride * sizeof(int);
         for (int c = 0; c < F.tallyChunks; c++) {
-            const int *hc = (const int *)F.pinned + (size_t)c * F.cntStride;
+            const int *hc = (const int *)F.pinned + F.cntBase + (size_t)c * F.cntStride;
             for (int k = 0; k <= R; k++) {
                 F.shaded += (unsigned long long)hc[(R + 2) + k];
                 if (k > 0) F.closestDeep += (unsigned long long)(F.heap ? hc[k] : hc[(R + 2) + k - 1]);   // reflection chain: one ray per parent hit
@@ -1130,7 +1222,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) r->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (hipDeviceGetAttribute(&r->wallClockKHz, hipDeviceAttributeWallClockRate, r->device) != hipSuccess) { r->wallClockKHz = 0; (void)hipGetLastError(); }
-        r->launchEvents = s->launchEvents; r->noLaunchTiming = s->noLaunchTiming; r->noGridHints = s->noGridHints; r->heapFastOk = s->heapFastOk; r->maxStampRows = s->maxStampRows;
+        r->launchEvents = s->launchEvents; r->noLaunchTiming = s->noLaunchTiming; r->noGridHints = s->noGridHints; r->heapFastOk = s->heapFastOk; r->maxStampRows = s->maxStampRows; r->adaptiveFastOk = s->adaptiveFastOk; r->adaptiveCap = s->adaptiveCap;
         HIPCHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
         int rc = scene_upload(r.get());
         if (rc != XRT_OK) return rc;
@@ -1512,6 +1604,8 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
     if (const char *e = getenv("XRT_LAUNCH_EVENTS")) s->launchEvents = atoi(e) != 0;
     if (const char *e = getenv("XRT_HEAP_FAST")) s->heapFastOk = atoi(e) != 0;
+    if (const char *e = getenv("XRT_ADAPTIVE_FAST")) s->adaptiveFastOk = atoi(e) != 0;
+    if (const char *e = getenv("XRT_ADAPTIVE_CAP")) { const long long v = atoll(e); if (v >= 1) s->adaptiveCap = v; }
     if (const char *e = getenv("XRT_GRID_HINTS")) s->noGridHints = atoi(e) == 0;
     if (const char *e = getenv("XRT_STAMP_ROWS")) { const int v = atoi(e); if (v >= 0 && v <= MAX_STAMP_ROWS) s->maxStampRows = v; }
     if (const char *e = getenv("XRT_LAUNCH_TIMING")) s->noLaunchTiming = atoi(e) == 0;

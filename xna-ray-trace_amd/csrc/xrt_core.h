@@ -400,7 +400,17 @@ struct RayGenParams {
     // (OSM:318-320) without building their rays.
     int   cullX0, cullY0, cullX1, cullY1;
     int   cullSkipsRecord;         // k_compose knows the rectangle too: no generation-0 record is written or read for those pixels
+    // A pass whose size only the device knows (the deeper quadrant levels of an adaptive frame in flight): the pass has
+    // min(*pathsDev, pathsCap) * pathsMul paths; null: the host's count
+    const int *pathsDev;
+    int   pathsMul, pathsCap;
 };
+XRT_HD int pass_paths(const RayGenParams &g, int hostCount) {
+    if (!g.pathsDev) return hostCount;
+    int n = *g.pathsDev;
+    if (n > g.pathsCap) n = g.pathsCap;
+    return n < 0 ? 0 : n * g.pathsMul;
+}
 
 // One Viewport.Unproject (RT:415 / RT:419) given the hoisted inverse matrix.
 XRT_HD v3 unproject(const RayGenParams &g, float sx, float sy, float sz) {
