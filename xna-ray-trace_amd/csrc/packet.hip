@@ -336,7 +336,11 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
     // between neighbouring waves is worth more than the balance.)  The grid is sized to be resident at once (packet_blocks_per_cu).
     const int nWaves = (int)gridDim.x * 4, waveId = (int)blockIdx.x * 4 + wave;
     // (a launch of few packets per wave -- a tile shard of a frame, a later generation -- still hands every wave its FIRST packet without
-    // an atomic: 6144 waves asking one queue word at once are served at ~12 ns each, the last of them 70 us into a 350 us launch)
+    // an atomic: 6144 waves asking one queue word at once are served at ~12 ns each, the last of them 70 us into a 350 us launch.
+    // The ONE queue word stays: with four or eight heads, each over a contiguous share of the packets and with stealing, every frame
+    // got slower the more heads there were -- C5 5.98 / 6.26 / 6.93 ms, C3 1.75 / 1.97 / 2.39 ms with 1 / 4 / 8 heads,
+    // profiles/r03/packet_queue_heads.txt: all waves of the chip working through one narrow window of neighbouring packets is worth
+    // more than the atomics cost)
     int staticPer = A.staticDiv > 0 ? nPk / (nWaves * A.staticDiv) : 0;
     if (staticPer == 0) staticPer = 1;
     const int qBase = min(nWaves * staticPer, nPk);
