@@ -635,12 +635,11 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     }
     // which ray populations the wave-packet kernel traces this frame (packet.hip): bit 0 primary rays, 1 shadow rays, 2 closest-hit
     // rays of later generations
-    // (two-level scenes: at any sample count -- what a packet shares there is the scene walk, the bodies' records and the mesh walk of
-    // a body, and an 8x8-pixel block of a 1-sample frame sees one or two bodies: C3 2.28 -> 1.78 ms, C4 6.64 -> 5.0 ms per pipelined
-    // frame; with 8 M sub-rays in the whole image or more (what counts is how close neighbouring rays are, not how many a shard
-    // holds) the packets of the later generations are still coherent enough to pay as well (bit 4: C4
-    // 5.61 -> 5.26 ms per blocking frame, C3 at 2 M paths 2.46 -> 2.67); one-body scenes: only with 16 sub-rays, see above)
-    const int pkAuto = s->sceneMode == MODE_SCENE ? ((long long)g.width * g.height * g.samples >= (6LL << 20) ? 23 : 7) : (g.samples >= 16 ? 7 : 0);
+    // (two-level scenes: at any sample count and in every generation -- what a packet shares there is the scene walk, the bodies'
+    // records and the mesh walk of a body, and an 8x8-pixel block of a 1-sample frame sees one or two bodies: C3 2.28 -> 1.57 ms,
+    // C4 6.64 -> 4.37 ms per pipelined frame (packets for the first two generations only: 1.78 / 5.0, profiles/r03/packet_masks.txt);
+    // one-body scenes: only with 16 sub-rays, and only the first two generations, see above)
+    const int pkAuto = s->sceneMode == MODE_SCENE ? 23 : (g.samples >= 16 ? 7 : 0);
     const int pkMask = (s->packetOk && !heap) ? (s->packetMask >= 0 ? s->packetMask : pkAuto) : 0;
     const bool laneClosest = (pkMask & 5) != 5;   // some closest-hit generation is traced ray by ray: the long-ray feedback has a reader
     const bool wantFeedback = fast && !heap && !adaptive && s->deepMeshes && !s->noFeedback && laneClosest;   // (the paths of a deeper quadrant level are a list: no stable key)
