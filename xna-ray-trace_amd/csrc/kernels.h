@@ -71,7 +71,7 @@ struct PacketArgs {
     const int *index = nullptr;   // optional compact list of ray indices
     const int *nDev = nullptr;    // when non-null the ray count is (*nDev) * nMul, else n
     int nMul = 1, n = 0, nCap = 0;
-    unsigned *queue = nullptr;    // zeroed work-queue word of this launch
+    unsigned *queue = nullptr;    // PACKET_QUEUE_WORDS zeroed work-queue heads of this launch (packet.hip: interleaved)
     int mode = MODE_SINGLE, meshId = 0;
     int unmark = 0;               // rays may carry the long-ray mark of their producer (device_util.h)
     int staticDiv = 4;            // 1/staticDiv of the packets are dealt statically (0: none)
@@ -80,6 +80,8 @@ struct PacketArgs {
     int cullMin = 4;              // leaves of at least this many references are tested against their tight box first (the test costs about two triangles)
     unsigned long long *stamps = nullptr;   // this launch's row of device-clock stamps (device_util.h), or null
 };
+constexpr int PACKET_QUEUE_HEADS = 8, PACKET_HEAD_STRIDE = 64;   // every head on a 256-byte line of its own: atomics on one line serialise whatever the word
+constexpr int PACKET_QUEUE_WORDS = PACKET_QUEUE_HEADS * PACKET_HEAD_STRIDE;
 bool packet_supported(int mode, int meshDepth, int sceneDepth);
 int  packet_blocks_per_cu(int mode);
 void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);

@@ -41,6 +41,11 @@ constexpr int PK_LEVELS = 24;        // deeper octrees than this fall back to k_
 constexpr int PK_FRAME_WORDS = 12;   // blk, next child position, order mask, lanes (2), parent box min (3), half (3), pad
 constexpr int PK_SLEVELS = 12;       // scene octree levels a packet can stack (deeper scene trees: k_intersect)
 constexpr int PK_SFRAME_WORDS = 4;   // scene block, pending children, lanes (2)
+#ifndef XRT_PK_QUEUES
+#define XRT_PK_QUEUES 8
+#endif
+constexpr int PK_QUEUES = XRT_PK_QUEUES;   // interleaved heads of the packet queue (PacketArgs::queue points at PACKET_QUEUE_WORDS zeroed words)
+static_assert(PK_QUEUES >= 1 && PK_QUEUES <= PACKET_QUEUE_HEADS, "the host zeroes PACKET_QUEUE_WORDS heads per packet launch");
 constexpr int PK_SGPRS = 112;        // SGPR allocation the kernel may reach (checked against the ISA in tests/test_numerics_contract.py)
 
 // make variant NAME=cnt DEFS=-DXRT_PK_COUNTERS: event counts of the shared walk (development aid; tools/pk_counters.py reads them through
@@ -336,15 +341,24 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
     // between neighbouring waves is worth more than the balance.)  The grid is sized to be resident at once (packet_blocks_per_cu).
     const int nWaves = (int)gridDim.x * 4, waveId = (int)blockIdx.x * 4 + wave;
     // (a launch of few packets per wave -- a tile shard of a frame, a later generation -- still hands every wave its FIRST packet without
-    // an atomic: 6144 waves asking one queue word at once are served at ~12 ns each, the last of them 70 us into a 350 us launch.
-    // The ONE queue word stays: with four or eight heads, each over a contiguous share of the packets and with stealing, every frame
-    // got slower the more heads there were -- C5 5.98 / 6.26 / 6.93 ms, C3 1.75 / 1.97 / 2.39 ms with 1 / 4 / 8 heads,
-    // profiles/r03/packet_queue_heads.txt: all waves of the chip working through one narrow window of neighbouring packets is worth
-    // more than the atomics cost)
+    // an atomic: 6144 waves asking one queue word at once are served at ~12 ns each, the last of them 70 us into a 350 us launch)
     int staticPer = A.staticDiv > 0 ? nPk / (nWaves * A.staticDiv) : 0;
     if (staticPer == 0) staticPer = 1;
     const int qBase = min(nWaves * staticPer, nPk);
-    int sNext = 0, dNext = 0, dEnd = 0, left = nPk - qBase;
+    // The dynamic packets are handed out by PK_QUEUES counters, INTERLEAVED: head h owns the packets qBase + PK_QUEUES * t + h
+    // (t = 0, 1, ..), a wave draws from head waveId % PK_QUEUES and, when that has run out, from the next ones.  All heads advance
+    // together, so the chip still works through ONE narrow window of neighbouring packets (contiguous shares per head -- eight windows
+    // -- were 5-40 % slower), but a head is asked by an eighth of the waves: after the static packets of a small launch 6144 waves no
+    // longer queue at one word for ~12 ns each (an eighth tile shard of C5: 0.96-1.22 -> 0.81-0.97 ms per frame, two in flight; whole
+    // frames unchanged).  Every head sits on a 256-byte line of its own (PACKET_HEAD_STRIDE): atomics on ONE line serialise whatever
+    // the word -- with the heads in adjacent words the same scheme was 4-19 % SLOWER than one head.  Only the value an atomic RETURNS
+    // says that a head has run out (a load may be served by this XCD's L2, which other XCDs' atomics do not update: a version that
+    // looked before asking kept retrying heads long empty).  Measurements: profiles/r03/packet_queue_heads.txt.
+    const int dynTotal = nPk - qBase;
+    unsigned dead = 0u;   // heads this wave knows to have run out
+    for (int h = 0; h < PK_QUEUES; h++) if (dynTotal - h <= 0) dead |= 1u << h;
+    int cur = waveId % PK_QUEUES, seen = 0, curR = cur;   // the head this wave draws from, the last ticket it saw there; curR: head of the range in hand
+    int sNext = 0, dNext = 0, dEnd = 0;   // dNext .. dEnd: tickets of head curR
     for (;;) {
         int pk;
         if (sNext < staticPer) {
@@ -354,16 +368,27 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
         else {
             if (qBase >= nPk) break;
             if (dNext >= dEnd) {
-                int want = left / (nWaves * 2);
-                want = want < 1 ? 1 : (want > A.grabMax ? A.grabMax : want);
-                unsigned g = 0;
-                if (lane == 0) g = atomicAdd(A.queue, (unsigned)want);
-                dNext = qBase + rfl((int)g);
-                if (dNext >= nPk || dNext < qBase) break;
-                dEnd = min(dNext + want, nPk);
-                left = nPk - dEnd;
+                bool got = false;
+                while (dead != (1u << PK_QUEUES) - 1u) {   // at most PK_QUEUES failed requests per wave and launch
+                    if ((dead >> cur) & 1u) {
+                        const unsigned alive = ~dead & ((1u << PK_QUEUES) - 1u);
+                        const unsigned rot = ((alive >> cur) | (alive << (PK_QUEUES - cur))) & ((1u << PK_QUEUES) - 1u);
+                        cur = (cur + (int)__builtin_ctz(rot)) % PK_QUEUES;
+                        seen = 0;
+                    }
+                    const int len = (dynTotal - cur + PK_QUEUES - 1) / PK_QUEUES;   // tickets of this head
+                    int want = (len - seen) / (nWaves / PK_QUEUES * 2 + 1);   // guided: a share of what is left of this head's tickets
+                    want = want < 1 ? 1 : (want > A.grabMax ? A.grabMax : want);
+                    unsigned g = 0;
+                    if (lane == 0) g = atomicAdd(A.queue + cur * PACKET_HEAD_STRIDE, (unsigned)want);
+                    const int head = rfl((int)g);
+                    if (head >= 0 && head < len) { dNext = head; dEnd = min(head + want, len); seen = dEnd; curR = cur; got = true; break; }
+                    dead |= 1u << cur;
+                }
+                if (!got) break;
             }
-            pk = dNext++;
+            pk = qBase + PK_QUEUES * dNext + curR;
+            dNext++;
         }
         // ---- the packet's 64 rays ------------------------------------------------------------------------------------
         const int w = pk * 64 + lane;

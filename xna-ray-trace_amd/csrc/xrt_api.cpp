@@ -586,7 +586,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         return rc;
     if (wantF32 && (rc = W.sampleF32.ensure((size_t)P * 3))) return rc;
     const int cntStride = 3 * (R + 2);          // per chunk: cnt[R+2], scnt[R+2], then the long-ray list lengths [R+2]
-    constexpr int QW = 3;   // per launch step k: the lane kernel's queue word and one for each packet launch (closest, shadow)
+    constexpr int QW = 1 + 2 * PACKET_QUEUE_WORDS;   // per launch step k: the lane kernel's queue word and the heads of each packet launch (closest, shadow)
     const int qStride = QW * (R + 2);
     // The common frame (one chunk, no supersampling levels, no ray tree, no counting pass) puts nothing but its kernels
     // on the stream: counters come back through k_compose's epilogue and the frame's events ride on raygen / compose.
@@ -767,7 +767,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             auto launch_pk = [&](const IntersectArgs &I, int word, long long nHost) -> int {
                 PacketArgs PA;
                 PA.rays = I.rays; PA.hits = I.hits; PA.flags = I.flags; PA.index = I.index; PA.nDev = I.nDev; PA.nMul = I.nMul; PA.n = I.n; PA.nCap = I.nCap;
-                PA.queue = q + QW * k + 1 + word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv; PA.grabMax = s->packetGrabMax; PA.cullMin = s->packetCullMin;
+                PA.queue = q + QW * k + 1 + PACKET_QUEUE_WORDS * word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv; PA.grabMax = s->packetGrabMax; PA.cullMin = s->packetCullMin;
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 int grid = s->numCUs * s->blocksPerCUPacket;
@@ -1445,13 +1445,13 @@ int close_frame(xrt_scene *s, int slot, xrt_stats *stats) {
 int queue_word_for(xrt_scene *s, hipStream_t st, unsigned **word) {
     constexpr size_t MAX_STREAMS = 1024;
     int rc;
-    if ((rc = s->queues.ensure(MAX_STREAMS * 2))) return rc;
+    if ((rc = s->queues.ensure(MAX_STREAMS * (1 + PACKET_QUEUE_WORDS)))) return rc;
     auto it = s->queueOfStream.find(st);
     if (it == s->queueOfStream.end()) {
         if (s->queueOfStream.size() >= MAX_STREAMS) return fail(XRT_E_UNSUPPORTED, "xrt_scene_intersect_device: more than %zu distinct streams on one scene", MAX_STREAMS);
         it = s->queueOfStream.emplace(st, (int)s->queueOfStream.size()).first;
     }
-    *word = s->queues.p + (size_t)it->second * 2;   // word 0: k_intersect's queue head, word 1: k_packet's
+    *word = s->queues.p + (size_t)it->second * (1 + PACKET_QUEUE_WORDS);   // word 0: k_intersect's queue head, then k_packet's heads
     return XRT_OK;
 }
 
@@ -1464,7 +1464,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
     if ((rc = queue_word_for(s, st, &queue)) || (rc = s->counters.ensure(2 * C_COUNT + 8))) return rc;
     // the reference-work counters are shared with the frames' counting pass: exact counts need the scene to itself
     if (stats && in_flight(s)) return fail(XRT_E_BUSY, "xrt_scene_intersect with stats while a render is in flight");
-    HIPCHECK(hipMemsetAsync(queue, 0, 2 * sizeof(unsigned), st));
+    HIPCHECK(hipMemsetAsync(queue, 0, (1 + PACKET_QUEUE_WORDS) * sizeof(unsigned), st));
     IntersectArgs A;
     A.rays = d_rays; A.hits = d_hits; A.index = nullptr; A.nDev = nullptr; A.nMul = 1; A.n = (int)n; A.nCap = 0; A.queue = queue; A.mode = mode; A.meshId = meshId;
     A.refillMin = s->tune[0]; A.nodeBurst = s->tune[1]; A.leafBurst = s->tune[2]; A.coopMax = s->tune[3]; A.batchMax = s->batchMax; A.heavyShift = s->heavyShift; A.batchMin = s->batchMin; A.spreadMin = s->spreadMin; A.firstBatch = s->firstBatch;
