@@ -79,6 +79,13 @@ struct PacketArgs {
     int *flags = nullptr;         // inside a frame: hit / miss word per ray, no record for a miss (IntersectArgs::flags)
     int cullMin = 4;              // leaves of at least this many references are tested against their tight box first (the test costs about two triangles)
     unsigned long long *stamps = nullptr;   // this launch's row of device-clock stamps (device_util.h), or null
+    // optional second segment traced by the same launch (the shadow rays of generation k-1 beside the closest-hit rays of generation k, as
+    // IntersectArgs::rays2): packets nPk1 .. are rays2[0 .. (*nDev2) * nMul2) -> hits2 / flags2 (no index list); one launch's tail instead of two
+    const xrt_ray *rays2 = nullptr;
+    xrt_hit *hits2 = nullptr;
+    int *flags2 = nullptr;
+    const int *nDev2 = nullptr;
+    int nMul2 = 0, nCap2 = 0;
 };
 constexpr int PACKET_QUEUE_HEADS = 8, PACKET_HEAD_STRIDE = 64;   // every head on a 256-byte line of its own: atomics on one line serialise whatever the word
 constexpr int PACKET_QUEUE_WORDS = PACKET_QUEUE_HEADS * PACKET_HEAD_STRIDE;

@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
     unsigned *const stk = &frames[wave * PK_LEVELS * PK_FRAME_WORDS];
     int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
     if (A.nCap > 0 && n > A.nCap) n = A.nCap;
-    const int nPk = (n + 63) >> 6;
+    int n2 = A.nDev2 ? (*A.nDev2) * A.nMul2 : 0;   // second segment (PacketArgs::rays2)
+    if (n2 > A.nCap2) n2 = A.nCap2;
+    const int nPk1 = (n + 63) >> 6, nPk = nPk1 + ((n2 + 63) >> 6);   // (a packet never mixes the two populations)
     // Work distribution.  A quarter (PacketArgs::staticDiv) of the packets are dealt statically and strided -- wave w takes packets w, w + nWaves, .. -- so that
     // every wave sees a fair sample of the image (rays skimming the surface near the horizon cost tens of times the average) while
     // neighbouring waves work on neighbouring packets at the same time (their leaves are in cache); the rest comes from a
@@ -391,8 +393,12 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
             dNext++;
         }
         // ---- the packet's 64 rays ------------------------------------------------------------------------------------
-        const int w = pk * 64 + lane;
-        const bool valid = w < n;
+        const bool seg2 = pk >= nPk1;   // wave-uniform
+        const int w = (seg2 ? pk - nPk1 : pk) * 64 + lane;
+        const bool valid = w < (seg2 ? n2 : n);
+        const xrt_ray *const raysS = seg2 ? A.rays2 : A.rays;
+        xrt_hit *const hitsS = seg2 ? A.hits2 : A.hits;
+        int *const flagsS = seg2 ? A.flags2 : A.flags;
         Lane L;
         L.state = ST_FINISH; L.mfound = 0; L.cost = 0; L.rayIndex = 0; L.mesh = 0; L.weird = 0; L.dmask = 0; L.ignoreId = -1; L.mask = 0;
         L.r = make_ray(mk(0, 0, 0), mk(1, 1, 1));
@@ -400,8 +406,8 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
         v3 o = mk(0, 0, 0), d = mk(0, 0, 0);
         int im = DEAD_RAY, it = -1;
         if (valid) {
-            idx = A.index ? A.index[w] : w;
-            load_ray(A.rays + idx, o, d, im, it);
+            idx = (A.index && !seg2) ? A.index[w] : w;
+            load_ray(raysS + idx, o, d, im, it);
             if (A.unmark && heavy_marked(it)) it ^= HEAVY_BIT;
         }
         if constexpr (M != MODE_SCENE) {
@@ -420,8 +426,8 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
             L.mesh = mesh;
             if (valid) {
                 const HitOut h = lane_result(L, C, S, M);
-                if (A.flags) A.flags[idx] = h.hit;
-                if (!A.flags || h.hit) store_hit(A.hits + idx, h);
+                if (flagsS) flagsS[idx] = h.hit;
+                if (!flagsS || h.hit) store_hit(hitsS + idx, h);
             }
         } else {
             // ---- OSM:312-455, wave-uniform: scene octree in DFS order, bodies and meshes in list order ---------------------------
@@ -551,8 +557,8 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
             if (valid) {
                 L.mfound = 0;
                 const HitOut h = lane_result(L, C, S, M);
-                if (A.flags) A.flags[idx] = h.hit;
-                if (!A.flags || h.hit) store_hit(A.hits + idx, h);
+                if (flagsS) flagsS[idx] = h.hit;
+                if (!flagsS || h.hit) store_hit(hitsS + idx, h);
             }
         }
     }

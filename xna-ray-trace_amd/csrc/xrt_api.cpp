@@ -198,6 +198,7 @@ struct xrt_scene {
     int spreadMin = 4;
     int heavyShift = 3;        // listed long rays are dealt one in 2^n work items (0: 64 to a wave); scene_upload: 0 for two-level scenes; XRT_HEAVY_SHIFT
     bool heavyShiftGiven = false;
+    bool packetMerge = true;   // the closest-hit and the shadow packets of a step share one launch (XRT_PK_MERGE=0: two launches, as round 2)
     int packetCullMin = 4;     // XRT_PK_CULL_MIN (development): leaves with fewer references skip the tight-box test
     int packetGrabMax = 2;     // XRT_PK_GRAB (development): 8 -> 2 shortened the tail of a launch (C5 blocking 9.0 -> 7.8 ms); 1 loses to contention on the queue word
     int packetStaticDiv = 4;   // XRT_PK_STATIC (development): 1/2 .. 1/8 measured within 2 % of each other on C5
@@ -764,9 +765,11 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             }
             // segments of coherent rays go to the wave-packet kernel, the others (together, one launch) to the per-lane kernel
             const bool pkC = hasClosest && packet_closest(k), pkB = hasShadow && packet_shadow(k);
-            auto launch_pk = [&](const IntersectArgs &I, int word, long long nHost) -> int {
+            // (I2: a second ray population for the same launch -- the shadow rays beside the closest-hit rays -- or null)
+            auto launch_pk = [&](const IntersectArgs &I, int word, long long nHost, const IntersectArgs *I2 = nullptr) -> int {
                 PacketArgs PA;
                 PA.rays = I.rays; PA.hits = I.hits; PA.flags = I.flags; PA.index = I.index; PA.nDev = I.nDev; PA.nMul = I.nMul; PA.n = I.n; PA.nCap = I.nCap;
+                if (I2) { PA.rays2 = I2->rays; PA.hits2 = I2->hits; PA.flags2 = I2->flags; PA.nDev2 = I2->nDev; PA.nMul2 = I2->nMul; PA.nCap2 = I2->nCap; }
                 PA.queue = q + QW * k + 1 + PACKET_QUEUE_WORDS * word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv; PA.grabMax = s->packetGrabMax; PA.cullMin = s->packetCullMin;
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
@@ -779,8 +782,12 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 return XRT_OK;
             };
             Range ri("xrt intersect #%d", k);
-            if (pkC && (rc = launch_pk(C, 0, k == 0 ? Pc : hint(s->genRays, k)))) return rc;
-            if (pkB && (rc = launch_pk(B, 1, hint(s->genRays, k)))) return rc;
+            // both populations of a step in ONE packet launch where both go to the packet kernel: one launch's tail instead of two
+            if (pkC && pkB && s->packetMerge) { if ((rc = launch_pk(C, 0, hint(s->genRays, k), &B))) return rc; }
+            else {
+                if (pkC && (rc = launch_pk(C, 0, k == 0 ? Pc : hint(s->genRays, k)))) return rc;
+                if (pkB && (rc = launch_pk(B, 1, hint(s->genRays, k)))) return rc;
+            }
             const bool laneC = hasClosest && !pkC, laneB = hasShadow && !pkB;
             if (laneC || laneB) {
                 IntersectArgs A = laneC ? C : B;
@@ -1215,7 +1222,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->packetCullMin = s->packetCullMin; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->packetCullMin = s->packetCullMin; r->packetMerge = s->packetMerge; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1611,6 +1618,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_SPLIT_MS")) s->splitMinMs = (float)atof(e);
     if (const char *e = getenv("XRT_SPLIT_PARTS")) { const int v = atoi(e); if (v >= 2 && v <= 4) s->splitParts = v; }
     if (const char *e = getenv("XRT_PK_CULL_MIN")) s->packetCullMin = atoi(e);
+    if (const char *e = getenv("XRT_PK_MERGE")) s->packetMerge = atoi(e) != 0;
 #ifdef XRT_DEV   // (make DEV=1) the two margin factors are the only switches that can change a result: below their proven values the skips
                  // are no longer exact.  A shipped library does not read them from the environment of its host process.
     if (const char *e = getenv("XRT_LEAF_CULL")) { const double v = atof(e); if (v >= 0.0 && v <= 1e6) s->hs.leafCullSafety = v; }   // 0 = no tight leaf boxes, 1 = the proven margin
