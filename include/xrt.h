@@ -166,7 +166,9 @@ typedef struct xrt_stats {
     double   ms_intersect;        /* summed durations of the traversal kernel launches: first wave's start to last wave's end on the
                                      device clock for plain single-chunk frames (an event on a dispatch packet costs ~5 us, so those
                                      launches carry none; ~4 us per launch less than a profiler's dispatch-level duration), HIP events
-                                     on the launches otherwise, or always with XRT_LAUNCH_EVENTS=1 */
+                                     on the launches otherwise, or always with XRT_LAUNCH_EVENTS=1.  The start stamp is the clock of
+                                     workgroup 0's first wave, which need not be the first wave of the launch to start (a 1024-block
+                                     grid starts first to last within ~0.3-0.7 us): the figure may be short by that much per launch */
     uint32_t intersect_launches;
     uint32_t pieces;              /* the frame was rendered in this many concurrent pieces (halves on two streams, GPUs); 1 otherwise */
     uint64_t rays_traversed;      /* queries (of rays_closest + rays_shadow) that were handed to the traversal kernels: all of them except
