@@ -182,6 +182,7 @@ struct xrt_scene {
     // XRT_PACKET=<mask> forces it: bit 0 primary rays, 1 shadow rays, 2 closest-hit rays of later generations, 3 seam-1 batches,
     // 4 bits 1 and 2 also apply beyond generation 1 (default: the first two generations and the first shadow rays only).
     int packetMask = -1;
+    int packetMaskHeap = -1;   // the same for ray-tree frames (XRT_PACKET_HEAP; -1: by image size)
     // Largest guided batch of k_intersect (XRT_BATCH_MAX).  Round 1 let a wave reserve up to 512 rays per atomic; per-wave clocks
     // (make WAVE_TIMES=1, tools/wave_times.py) showed the median wave of a C3 / C4 launch leaving at 57 % of the launch and the
     // tail growing with the frame size -- waves stuck with eight expensive rays per lane while the queue was empty.  64: C3 3.9 ->
@@ -641,7 +642,11 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // C4 6.64 -> 4.37 ms per pipelined frame (packets for the first two generations only: 1.78 / 5.0, profiles/r03/packet_masks.txt);
     // one-body scenes: only with 16 sub-rays, and only the first two generations, see above)
     const int pkAuto = s->sceneMode == MODE_SCENE ? 23 : (g.samples >= 16 ? 7 : 0);
-    const int pkMask = (s->packetOk && !heap) ? (s->packetMask >= 0 ? s->packetMask : pkAuto) : 0;
+    // (ray-tree frames -- Transparent materials -- of two-level scenes: the first two generations and the first shadow rays, where the image
+    // is big enough for a launch to be more than its floor: G2 at 720p 1.12 -> 0.97 ms, the reference's default scene at 512x512 0.31 ->
+    // 0.40 with packets, so not there; packets in every generation of a ray tree are 1.5-3 x slower (profiles/r03/packet_masks_ray_trees.txt))
+    const int pkHeap = s->packetMaskHeap >= 0 ? s->packetMaskHeap : ((s->sceneMode == MODE_SCENE && (long long)g.width * g.height * g.samples >= 600000LL) ? 7 : 0);
+    const int pkMask = !s->packetOk ? 0 : (heap ? pkHeap : (s->packetMask >= 0 ? s->packetMask : pkAuto));
     const bool laneClosest = (pkMask & 5) != 5;   // some closest-hit generation is traced ray by ray: the long-ray feedback has a reader
     const bool wantFeedback = fast && !heap && !adaptive && s->deepMeshes && !s->noFeedback && laneClosest;   // (the paths of a deeper quadrant level are a list: no stable key)
     {   // The other context's frame may still be running on another stream.  Two single-chunk frames share nothing they
@@ -1222,7 +1227,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->packetCullMin = s->packetCullMin; r->packetMerge = s->packetMerge; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->packetMerge = s->packetMerge; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1607,6 +1612,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_PK_GRAB")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->packetGrabMax = v; }
     if (const char *e = getenv("XRT_PK_STATIC")) { const int v = atoi(e); if (v >= 0 && v <= 64) s->packetStaticDiv = v; }
     if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 31) s->packetMask = v; }
+    if (const char *e = getenv("XRT_PACKET_HEAP")) { const int v = atoi(e); if (v >= -1 && v <= 31) s->packetMaskHeap = v; }
     if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
     if (const char *e = getenv("XRT_LAUNCH_EVENTS")) s->launchEvents = atoi(e) != 0;
     if (const char *e = getenv("XRT_HEAP_FAST")) s->heapFastOk = atoi(e) != 0;
