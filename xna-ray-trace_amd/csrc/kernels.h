@@ -129,7 +129,7 @@ void launch_intersect(const SceneView &S, const IntersectArgs &A, int stackNeede
 int  intersect_blocks_per_cu(int stackNeeded, int mode);
 void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long *counters, hipStream_t st);
 void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase,
-                   const HeavyArgs &H, hipStream_t st, hipEvent_t startEvent = nullptr);
+                   const HeavyArgs &H, hipStream_t st, hipEvent_t startEvent = nullptr, int liveCap = 0x7fffffff);
 void launch_shade(const SceneView &S, const ShadeView &V, const ShadeArgs &X, hipStream_t st, int blocks = 1024, int threads = 1024);   // (any grid is correct: grid-stride loops)
 // Frame epilogue of the compose kernels: the clock stamps of traversal launches row0 .. row1-1 are folded into (start, latest
 // end) pairs in host-visible memory (device_util.h)

@@ -570,8 +570,12 @@ __device__ __forceinline__ bool path_pixel(const RayGenParams &g, long long pix,
 // One global atomic per list covers RG_ROUNDS x 1024 consecutive paths of a block (2025 atomics on one word were 20 of
 // the kernel's 21 us on a 1080p frame): the rays are written first, the list slots afterwards.
 constexpr int RG_ROUNDS = 4;
+// With a live list (`index`, inside frames) the rays are COMPACT: the ray of the j-th live path sits at rays[j] and index[j] names its path
+// -- what the traversal kernels read is one contiguous run, and every per-ray array of generation 0 needs room for the live rays only
+// (at most the paths inside the root box's screen rectangle, known on the host: `liveCap`), not for every path of the frame.  Without
+// a list (xrt_generate_primary_rays) ray p sits at rays[p].
 __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneView S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int Phost,
-                                                         long long pathBase, HeavyArgs H) {
+                                                         long long pathBase, HeavyArgs H, int liveCap) {
     __shared__ int ldsLive[RG_ROUNDS * 16], ldsHeavy[RG_ROUNDS * 16];
     const int P = pass_paths(g, Phost);
     const f4 rlo = S.snodes[0], rhi = S.snodes[1];
@@ -580,10 +584,12 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
     for (int grp = (int)blockIdx.x; grp < groups; grp += (int)gridDim.x) {
         int liveAt[RG_ROUNDS], heavyAt[RG_ROUNDS];   // rank among the flagged lanes of the wave, -1: not flagged
+        v3 keepO[RG_ROUNDS], keepD[RG_ROUNDS];       // the live rays of this thread, written once their places in the list are known
 #pragma unroll
         for (int r = 0; r < RG_ROUNDS; r++) {
             const int p = grp * span + r * APPEND_BLOCK + (int)threadIdx.x;
             bool live = false, heavy = false, record = true;
+            keepO[r] = mk(0, 0, 0); keepD[r] = mk(0, 0, 0);
             if (p < P) {
                 long long gp = pathBase + p;
                 const int sshift = g.samples == 16 ? 4 : (g.samples == 4 ? 2 : 0);   // samples is 1, 4 or 16
@@ -615,7 +621,8 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
                         live = slab(w, rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, key);   // OSM:460 on the root
                     }
                     heavy = live && H.list && long_ray(S, H, p, nearP, dir);
-                    if (live || !index) store_ray(rays + p, nearP, dir, -1, heavy ? (-1 ^ HEAVY_BIT) : -1);   // a culled ray is never read again
+                    if (!index) store_ray(rays + p, nearP, dir, -1, -1);
+                    keepO[r] = nearP; keepD[r] = dir;   // (a culled ray is never read: it gets no place)
                 }
                 if (index && !live && record) lvlB0[p] = f4{0, 0, 0, i2f(FLAG_MISS)};   // generation 0 ends here (RT:729-733)
             }
@@ -640,19 +647,25 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
 #pragma unroll
         for (int r = 0; r < RG_ROUNDS; r++) {
             const int p = grp * span + r * APPEND_BLOCK + (int)threadIdx.x;
-            if (liveAt[r] >= 0) index[ldsLive[r * 16 + wave] + liveAt[r]] = p;
-            if (heavyAt[r] >= 0) H.list[ldsHeavy[r * 16 + wave] + heavyAt[r]] = p;
+            if (liveAt[r] >= 0) {
+                const int slot = ldsLive[r * 16 + wave] + liveAt[r];
+                if (slot < liveCap) {   // (liveCap bounds the live rays by construction: the guard is against a wrong bound, not a code path)
+                    index[slot] = p;
+                    store_ray(rays + slot, keepO[r], keepD[r], -1, heavyAt[r] >= 0 ? (-1 ^ HEAVY_BIT) : -1);
+                    if (heavyAt[r] >= 0) H.list[ldsHeavy[r * 16 + wave] + heavyAt[r]] = slot;
+                }
+            }
         }
         __syncthreads();   // the cells are reused by the next group
     }
 }
 void launch_raygen(const RayGenParams &g, const SceneView &S, xrt_ray *rays, f4 *lvlB0, int *index, int *count, int P, long long pathBase,
-                   const HeavyArgs &H, hipStream_t st, hipEvent_t startEvent) {
+                   const HeavyArgs &H, hipStream_t st, hipEvent_t startEvent, int liveCap) {
     static_assert(RG_ROUNDS * 16 == 64, "one wave scans the block's cells");
     int blocks = (P + RG_ROUNDS * APPEND_BLOCK - 1) / (RG_ROUNDS * APPEND_BLOCK);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipExtLaunchKernelGGL(k_raygen, dim3(blocks), dim3(APPEND_BLOCK), 0, st, startEvent, nullptr, 0, g, S, rays, lvlB0, index, count, P, pathBase, H);
+    hipExtLaunchKernelGGL(k_raygen, dim3(blocks), dim3(APPEND_BLOCK), 0, st, startEvent, nullptr, 0, g, S, rays, lvlB0, index, count, P, pathBase, H, liveCap);
 }
 
 // ---- shading ----------------------------------------------------------------------------------------------------------

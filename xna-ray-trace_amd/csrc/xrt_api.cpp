@@ -561,6 +561,14 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const long long chunkPaths = firstPaths < maxPaths ? firstPaths : maxPaths;
     const int P = (int)chunkPaths;
     size_t rayCap = (size_t)P;
+    // The per-ray arrays hold LIVE rays only (k_raygen compacts them): a live primary ray belongs to a pixel inside the screen rectangle
+    // of the scene's root box, so a plain or 16-sub-ray frame of one chunk needs room for the rectangle's paths, not for every path
+    // (C5: 52 % of the image); later generations have fewer rays than the one before.  (Adaptive frames: the deeper quadrant levels are
+    // lists of up to a quadrant per pixel; ray trees: sized below.)
+    if (!heap && !adaptive && firstPaths <= chunkPaths) {
+        const long long rectPaths = (long long)std::max(0, g.cullX1 - g.cullX0 + 1) * (long long)std::max(0, g.cullY1 - g.cullY0 + 1) * g.samples + 64;
+        if (rectPaths < (long long)rayCap) rayCap = (size_t)rectPaths;
+    }
     if (heap) {
         const size_t capL = (size_t)std::min<long long>(s->heapRayCap, lightBound);   // (>= 8192 >= ... see above; P <= lightBound as well)
         rayCap = (R < 20 && ((size_t)P << R) < capL) ? ((size_t)P << R) : capL;
@@ -574,7 +582,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     if ((rc = W.rays0.ensure(rayCap)) || (rc = W.rays1.ensure(rayCap)) || (rc = W.hits.ensure(rayCap)) || (rc = W.path0.ensure(rayCap)) ||
         (rc = W.path1.ensure(rayCap)) || (rc = W.hits1.ensure(rayCap)) || (rc = W.hitFlags0.ensure(rayCap)) || (rc = W.hitFlags1.ensure(rayCap)) ||
         (rc = W.shadowFlags.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = W.slot0.ensure(rayCap)) ||
-        (rc = W.slot1.ensure(rayCap)) || (rc = W.index0.ensure(P)) || (rc = W.heavyList.ensure(rayCap)) || (rc = W.shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
+        (rc = W.slot1.ensure(rayCap)) || (rc = W.index0.ensure(rayCap)) || (rc = W.heavyList.ensure(rayCap)) || (rc = W.shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
         (rc = W.shadowHits.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = W.lvlA.ensure((size_t)P * nodes)) ||
         (rc = W.lvlB.ensure((size_t)P * nodes)) || (rc = W.sampleColor.ensure(P)) || (rc = W.lights.ensure(nL > 0 ? nL : 1)) ||
         (rc = s->counters.ensure(2 * C_COUNT + 8)))
@@ -747,7 +755,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             return H;
         };
         // cnt[0] counts the primary rays that reach the scene's root box; index0 lists them
-        { Range r("xrt raygen"); launch_raygen(gp, S, rays[0], W.lvlB.p, W.index0.p, cnt, Pc, pathBase, heavy_for(0), st, startEvent ? e0 : nullptr); startEvent = false; }
+        { Range r("xrt raygen"); launch_raygen(gp, S, rays[0], W.lvlB.p, W.index0.p, cnt, Pc, pathBase, heavy_for(0), st, startEvent ? e0 : nullptr, (int)rayCap); startEvent = false; }
         xrt_hit *hitsOf[2] = {W.hits.p, W.hits1.p};
         int *flagsOf[2] = {W.hitFlags0.p, W.hitFlags1.p};
         SlotRec *slotOf[2] = {W.slot0.p, W.slot1.p};
@@ -757,7 +765,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             // a reflection chain keeps the ray of generation k at its parent's slot: their number is scnt[k-1]
             const int *nClosest = (k == 0 || heap) ? cnt + k : scnt + (k - 1);
             IntersectArgs C, B;   // closest-hit segment, shadow segment
-            C.rays = rays[cur]; C.hits = hitsOf[cur]; C.index = k == 0 ? W.index0.p : nullptr; C.nDev = nClosest; C.nMul = 1; C.n = Pc;
+            C.rays = rays[cur]; C.hits = hitsOf[cur]; C.index = nullptr; C.nDev = nClosest; C.nMul = 1; C.n = Pc;   // (generation 0: cnt[0] live rays, compact)
             C.nCap = (int)rayCap;
             C.flags = flagsOf[cur]; B.flags = W.shadowFlags.p;
             C.missRecords = (feedback && !packet_closest(k)) ? 1 : 0;   // k_shade #k reads the cost word of every ray of the generation
@@ -817,7 +825,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             X.level = k; X.doA = hasClosest ? 1 : 0; X.doB = k >= 1 ? 1 : 0;
             X.maxReflections = R; X.P = P; X.heap = heap ? 1 : 0; X.overflow = overflowFlag;
             X.rays = rays[cur]; X.hits = hitsOf[cur]; X.hitFlags = flagsOf[cur]; X.shadowFlags = W.shadowFlags.p; X.nDev = nClosest; X.nHost = Pc; X.cap = (int)rayCap;
-            X.index = k == 0 ? W.index0.p : nullptr; X.rayPath = k == 0 ? nullptr : paths[cur];
+            X.index = nullptr; X.rayPath = k == 0 ? W.index0.p : paths[cur];   // (generation 0: the j-th live ray belongs to path index0[j])
             X.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; X.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
             X.slotOut = slotOf[cur]; X.scnt = scnt + k; X.shadowCap = (int)shadowCap; X.shadowRays = W.shadowRays.p;
             X.nextRays = rays[prv]; X.nextPath = paths[prv]; X.nextNode = heap ? nodesOf[prv] : nullptr; X.nextRef = heap ? refOf[prv] : nullptr;
