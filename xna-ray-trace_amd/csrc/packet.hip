@@ -67,6 +67,66 @@ struct alignas(4) TriWords { float w[16]; };   // a 13-word record of refT and t
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float rflf(float v) { return i2f(__builtin_amdgcn_readfirstlane(f2i(v))); }
 
+// The triangle test of a packet, shaped for the SCALAR unit: every `if` on a per-lane condition costs the wave two or three scalar
+// instructions and a branch whether or not a lane takes it (the nested early rejections of xrt_core.h tri_stage_a / tri_stage_b and
+// traverse.h leaf_candidate were 53 scalar instructions and 13 branches per triangle that some lane hits; this form is 17 and 4), and the
+// scalar unit is the busier of this kernel's two.  RE:42-75 as TWO predicates: the certainly_negative() tests become sign-bit arithmetic
+// on the operands' bit patterns (vector instructions) and are OR-ed into one word with the ignored-triangle test; the lanes that pass
+// both divide exactly as RE:66-74 does.  (All of it as ONE predicate -- both cross products for every lane -- was measured too: C5 1 %
+// slower than this, C3 / C4 3 % slower than the nested form; profiles/r03/packet_triangle_test_forms.txt.)
+//   cn_bits(a, det): sign bit set iff certainly_negative(a, det) -- opposite signs, |a| >= 2^-60, |det| <= 2^60.  (A NaN `a` counts as large
+//   here and as small there: either way the triangle is rejected, there by the comparisons after the division, which are false for NaNs.)
+__device__ __forceinline__ int cn_bits(float a, int detBits, int detSmall) {
+    const int ia = f2i(a);
+    return (ia ^ detBits) & ~((ia & 0x7fffffff) - 0x21800000 /* 2^-60 */) & detSmall;
+}
+// Two predicates: (1) front-facing, not the ignored triangle, u not certainly negative -- the first cross product and two dot products,
+// which reject most triangles for every lane of a packet; (2) for the lanes that are left, everything else at once.
+struct PkTriMid { v3 T; float det, row2; };
+__device__ __forceinline__ bool pk_tri_pre(const TriWords &q, const Lane &L, PkTriMid &m) {
+    const v3 O = L.r.o, D = L.r.d;
+    const v3 v1 = mk(q.w[4], q.w[5], q.w[6]), E1 = mk(q.w[7], q.w[8], q.w[9]), E2 = mk(q.w[10], q.w[11], q.w[12]);
+    const float fc = facing(mk(q.w[0], q.w[1], q.w[2]), D);   // RE:48-51
+    m.T = mk(O.x - v1.x, O.y - v1.y, O.z - v1.z);            // RE:46
+    const v3 P = cross(D, E2);                                // RE:58
+    m.det = dot(P, E1);                                       // RE:66 (the divisor)
+    m.row2 = dot(P, m.T);                                     // RE:63
+    const int db = f2i(m.det), detSmall = ~(0x5d800000 /* 2^60 */ - (db & 0x7fffffff));
+    const int x = f2i(q.w[3]) ^ L.ignoreId;                   // MO:290: (x - 1) & ~x has its sign bit set iff x == 0, the ignored triangle
+    int bad = cn_bits(m.row2, db, detSmall) | ((x - 1) & ~x); // u < 0, certainly
+    bad = fc > 0.0f ? -1 : bad;                               // RE:50
+    return bad >= 0;
+}
+// RE:59-74 and MO:293-294 for a lane that passed pk_tri_pre: v < 0 or distance < 0 certainly (sign bits), else the reference's division and
+// u >= 0, v >= 0, distance >= 0, u + v <= 1, distance < float.MaxValue.  A NaN among the three fails u + v <= 1 or distance < MaxValue (as it
+// fails the reference's comparisons), so the three sign tests may be one minimum, whatever it makes of a NaN.
+__device__ __forceinline__ bool pk_tri_hit(const TriWords &q, const Lane &L, const PkTriMid &m, float &u, float &v, float &t) {
+    const v3 D = L.r.d, E1 = mk(q.w[7], q.w[8], q.w[9]), E2 = mk(q.w[10], q.w[11], q.w[12]);
+    const v3 Q = cross(m.T, E1);                              // RE:59
+    const float row3 = dot(Q, D);                             // RE:64
+    const float row1 = dot(Q, E2);                            // RE:62
+    const int db = f2i(m.det), detSmall = ~(0x5d800000 - (db & 0x7fffffff));
+    const int bad = cn_bits(row3, db, detSmall) | cn_bits(row1, db, detSmall);
+    const float inv = 1.0f / m.det;                           // RE:66
+    t = row1 * inv; u = m.row2 * inv; v = row3 * inv;
+    const float s0 = bad >= 0 ? fminf(fminf(u, v), t) : -1.0f;
+    const float s = s0 >= 0.0f ? u + v : 2.0f;
+    const float d = s <= 1.0f ? t : FLT_MAX;
+    return d < FLT_MAX;
+}
+// leaf_candidate (traverse.h) for a lane whose triangle passed, without nested branches: the bucket rule's comparison is evaluated as one
+// predicate; only an exact tie of key AND distance (two leaves holding the same triangle) goes to memory for the leaves' DFS numbers.
+__device__ __forceinline__ void pk_candidate(Lane &L, const SceneView &S, int r, float u, float v, float t) {
+    const bool eq = L.leafKey == L.mKey;
+    bool better = (L.mfound == 0) | (L.leafKey < L.mKey) | (eq & (t < L.mDist));
+    if (eq & (t == L.mDist)) {   // (rare)
+        if ((L.mfound != 0) & (L.leafNode != L.mLeaf)) better = node_dfs(S, L.leafNode) < node_dfs(S, L.mLeaf);
+    }
+    L.mfound = 1;   // (every lane here has a candidate now, its old one or this)
+    L.mKey = better ? L.leafKey : L.mKey; L.mDist = better ? t : L.mDist; L.mU = better ? u : L.mU; L.mV = better ? v : L.mV;
+    L.mRef = better ? r : L.mRef; L.mLeaf = better ? L.leafNode : L.mLeaf;
+}
+
 // MO:288-304 for the lanes selected by the caller (exec), over the references r0 .. r1-1 of one leaf.  The triangle is the same
 // for every lane: normals and geometry come through the scalar cache.  Two register sets take turns, and a triangle's 52 bytes are
 // requested before the previous one's arithmetic starts (the records of a leaf are back to back; the arrays end in two dummy
@@ -78,15 +138,12 @@ template <class KeyFn>
 __device__ __forceinline__ void pk_scan_leaf(const float *__restrict__ refT, int r0, int r1, Lane &L, const SceneView &S, bool keyed, KeyFn entry_key) {
     const char *pt = reinterpret_cast<const char *>(refT) + (size_t)r0 * TRI_REC_BYTES;
     auto test = [&](const TriWords &q, int r) {
-        const bool f = !(facing(mk(q.w[0], q.w[1], q.w[2]), L.r.d) > 0.0f) & (f2i(q.w[3]) != L.ignoreId);   // RE:48-51, MO:290
-        v3 T; float det, row2;
-        const v3 gb = mk(q.w[7], q.w[8], q.w[9]), gc = mk(q.w[10], q.w[11], q.w[12]);
-        const bool sA = tri_stage_a(L.r.o, L.r.d, mk(q.w[4], q.w[5], q.w[6]), gb, gc, T, det, row2) & f;
-        if (sA) {   // one wave-level branch per triangle (s_cbranch_execz): most are rejected by the sign of u for every lane
-            float u, v, t;
-            if (tri_stage_b(L.r.d, gb, gc, T, det, row2, u, v, t)) {
+        float u, v, t;
+        PkTriMid m;
+        if (pk_tri_pre(q, L, m)) {
+            if (pk_tri_hit(q, L, m, u, v, t)) {
                 if (!keyed) L.leafKey = entry_key();
-                leaf_candidate(L, S, r, -2, true, u, v, t);   // (the ignored triangle was filtered above: -2 matches no id)
+                pk_candidate(L, S, r, u, v, t);
             }
         }
     };
@@ -234,15 +291,12 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
                     // (kept inline: as a function of its own the same loop costs 13 more VGPRs, i.e. the sixth wave per SIMD)
                     const char *pt = reinterpret_cast<const char *>(refT) + (size_t)ra * TRI_REC_BYTES;
                     auto test = [&](const TriWords &q, int r) {
-                        const bool f = !(facing(mk(q.w[0], q.w[1], q.w[2]), L.r.d) > 0.0f) & (f2i(q.w[3]) != L.ignoreId);   // RE:48-51, MO:290
-                        v3 T; float det, row2;
-                        const v3 gb = mk(q.w[7], q.w[8], q.w[9]), gc = mk(q.w[10], q.w[11], q.w[12]);
-                        const bool sA = tri_stage_a(L.r.o, L.r.d, mk(q.w[4], q.w[5], q.w[6]), gb, gc, T, det, row2) & f;
-                        if (sA) {   // one wave-level branch per triangle (s_cbranch_execz): most are rejected by the sign of u for every lane
-                            float u, v, t;
-                            if (tri_stage_b(L.r.d, gb, gc, T, det, row2, u, v, t)) {
+                        float u, v, t;
+                        PkTriMid m;
+                        if (pk_tri_pre(q, L, m)) {   // one wave-level branch per triangle (s_cbranch_execz): most are rejected here for every lane
+                            if (pk_tri_hit(q, L, m, u, v, t)) {
                                 if (!keyed) L.leafKey = entry_key();
-                                leaf_candidate(L, S, r, -2, true, u, v, t);   // (the ignored triangle was filtered above: -2 matches no id)
+                                pk_candidate(L, S, r, u, v, t);
                             }
                         }
                     };
