@@ -100,7 +100,9 @@ constexpr int FLAG_MISS = 0, FLAG_HIT = 1, FLAG_TRANSPARENT = 2;
 
 // One shaded hit of a generation: which ray found it, the path (pixel sample) it belongs to and its node in the
 // ray tree (== generation for a plain reflection chain).
-struct alignas(16) SlotRec { int ray, path, node, pad; };
+// What part B of k_shade needs of a shaded hit, left by part A at the hit's slot (the slots of a generation are dense, so both sides stream
+// 32 bytes per hit; the level record lvlA[node][path] is written once, by part B): world position, path, fragment normal, Reflectiveness.
+struct alignas(16) SlotRec { float wx, wy, wz; int path; float nx, ny, nz, refl; };
 
 // k_shade: part A works on generation `level`, part B on generation level-1 (kernels.hip).
 struct ShadeArgs {
@@ -111,10 +113,10 @@ struct ShadeArgs {
     const xrt_ray *rays; const xrt_hit *hits;
     const int *nDev; int nHost, cap;
     const int *index, *rayPath, *rayNode; const float *rayRef;
-    SlotRec *slotOut; int *scnt; int shadowCap; xrt_ray *shadowRays;
+    SlotRec *slotOut; int *slotNodeOut; int *scnt; int shadowCap; xrt_ray *shadowRays;   // slotNodeOut: ray-tree frames only (a chain's node is its level)
     xrt_ray *nextRays; int *nextPath, *nextNode; float *nextRef; int *nextCnt; int nextCap;
     // part B
-    const xrt_hit *hitsPrev; const SlotRec *slotPrev; const int *scntPrev; const xrt_hit *shadowHits;
+    const SlotRec *slotPrev; const int *slotNodePrev; const int *scntPrev; const xrt_hit *shadowHits;
     f4 *lvlA, *lvlB; float *lvlAlpha;
     HeavyArgs heavy;   // for the rays of generation level+1
     unsigned *costOut = nullptr;   // cost map of generation `level` (part A writes what its rays cost), tagged with `epoch`

@@ -763,8 +763,8 @@ __device__ __forceinline__ v3 lookup_uv(const ShadeView &V, const MaterialRec &M
 //                            now: fragment normal, surface colour (RT:568-581 / 711-724), Reflectiveness.  Launch #k+1 traces
 //                            both ray sets together.
 //   part B, generation k-1 : the shadow answers of launch #k: light accumulation (RT:534-542) into the level record the return
-//                            path (k_compose) needs.  It reads 48 bytes per hit (slot, parked normal, world position) where it
-//                            used to read the 48-byte hit, the material and the shading record a second time.
+//                            path (k_compose) needs.  It reads the hit's 32-byte slot record (world position, path, normal, Reflectiveness:
+//                            left by part A) where it used to read the 48-byte hit, the material and the shading record a second time.
 __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V, ShadeArgs X) {
     __shared__ int ldsCounts[17];
     const int stride = (int)(gridDim.x * blockDim.x);
@@ -772,17 +772,15 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
     const size_t P = (size_t)X.P;
     if (X.doB) {
         // Generation k-1: everything that depends on the hit alone (fragment normal, surface colour, Reflectiveness) was computed by
-        // part A of the previous step and waits in the level record; what is left is the light sum, which needs the shadow answers:
-        // 16 + 16 + 16 bytes in (slot, record, world position) instead of the 48-byte hit, the material and the shading record again.
+        // part A of the previous step; what is left is the light sum, which needs the shadow answers: one dense 32-byte slot record in
+        // (kernels.h SlotRec) and one 16-byte level record out, instead of the 48-byte hit, the material and the shading record again.
         int n = *X.scntPrev;
         if (n > X.shadowCap) n = X.shadowCap;
         for (int s = tid; s < n; s += stride) {
-            const SlotRec rec = X.slotPrev[s];
-            const size_t at = (size_t)rec.node * P + (size_t)rec.path;
-            const f4 nr = X.lvlA[at];   // (normal.xyz, Reflectiveness), left by part A
-            const v3 normal = mk(nr.x, nr.y, nr.z);
-            const Hit16 hw = reinterpret_cast<const Hit16 *>(X.hitsPrev + rec.ray)[2];
-            const v3 w = mk(i2f(hw.i0), i2f(hw.i1), i2f(hw.i2));
+            const SlotRec rec = X.slotPrev[s];   // left by part A of the previous step
+            const int node = X.heap ? X.slotNodePrev[s] : X.level - 1;
+            const size_t at = (size_t)node * P + (size_t)rec.path;
+            const v3 normal = mk(rec.nx, rec.ny, rec.nz), w = mk(rec.wx, rec.wy, rec.wz);
             v3 lightResult = mk(0, 0, 0);
             for (int l = 0; l < V.nLights; l++) {
                 const LightRec &Lt = V.lights[l];
@@ -799,7 +797,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
                 }
                 if (lightAmount != 1.0f) lightResult = add(lightResult, scale(light_for_fragment(Lt, w, normal), 1.0f - lightAmount));   // RT:538-541
             }
-            X.lvlA[at] = f4{lightResult.x, lightResult.y, lightResult.z, nr.w};
+            X.lvlA[at] = f4{lightResult.x, lightResult.y, lightResult.z, rec.refl};
         }
     }
     if (!X.doA) return;
@@ -827,14 +825,13 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
         const int slot = block_append(X.scnt, hit != 0, ldsCounts);
         if (hit && slot >= X.shadowCap) { *X.overflow = 1; hit = 0; }   // more rays than the chunk's buffers hold: the host retries with fewer paths
         if (hit) {
-            X.slotOut[slot] = SlotRec{i, p, node, 0};
             for (int l = 0; l < V.nLights; l++) {
                 v3 dir; float dist;
                 light_dir(V.lights[l], w, dir, dist);
                 store_ray(X.shadowRays + (size_t)slot * V.nLights + l, w, dir, mesh, tri);   // ignore = shaded triangle (RT:485)
             }
-            // the hit's own share of RT:516-581: fragment normal (RT:520-531), surface colour (RT:568-581 / 711-724), Reflectiveness -- final in
-            // lvlB, and (normal, Reflectiveness) parked in lvlA until part B of the next step has the shadow answers for the light sum
+            // the hit's own share of RT:516-581: fragment normal (RT:520-531), surface colour (RT:568-581 / 711-724), Reflectiveness -- the colour final
+            // in lvlB, (normal, Reflectiveness) in the slot record until part B of the next step has the shadow answers for the light sum
             const int gtri = V.meshes[mesh].triBase + tri;
             const MaterialRec M = V.materials[V.meshes[mesh].material];
             const v3 normal = fragment_normal(V, gtri, M.flags, u, v);
@@ -853,7 +850,8 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
                 }
                 const bool transparent = (M.flags & MAT_TRANSPARENT) != 0;
                 const size_t at = (size_t)node * P + (size_t)p;
-                X.lvlA[at] = f4{normal.x, normal.y, normal.z, M.reflectiveness};
+                X.slotOut[slot] = SlotRec{w.x, w.y, w.z, p, normal.x, normal.y, normal.z, M.reflectiveness};
+                if (X.heap) X.slotNodeOut[slot] = node;
                 X.lvlB[at] = f4{surf.x, surf.y, surf.z, i2f(FLAG_HIT | (transparent ? FLAG_TRANSPARENT : 0))};
                 if (X.heap) X.lvlAlpha[at] = sr[3].w;   // triangle.color.W (RT:699)
             }

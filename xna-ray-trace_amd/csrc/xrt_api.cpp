@@ -223,6 +223,7 @@ struct xrt_scene {
         DevBuf<int> hitFlags0, hitFlags1, shadowFlags;   // hit / miss word per ray of hits, hits1, shadowHits (a miss has no record)
         DevBuf<unsigned long long> stamps;      // device-clock stamps of the traversal launches (device_util.h), STAMP_STRIDE per launch
         DevBuf<SlotRec> slot0, slot1;
+        DevBuf<int> slotNode0, slotNode1;   // ray-tree frames: the node of a slot's hit
         DevBuf<f4> lvlA, lvlB;
         DevBuf<uint32_t> sampleColor;
         DevBuf<float> sampleF32;
@@ -239,7 +240,7 @@ struct xrt_scene {
         void release() {
             rays0.release(); rays1.release(); shadowRays.release(); hits.release(); hits1.release(); shadowHits.release();
             path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); stamps.release(); hitFlags0.release(); hitFlags1.release(); shadowFlags.release();
-            node0.release(); node1.release(); heapFlag.release(); ref0.release(); ref1.release(); lvlAlpha.release(); slot0.release(); slot1.release();
+            node0.release(); node1.release(); heapFlag.release(); ref0.release(); ref1.release(); lvlAlpha.release(); slot0.release(); slot1.release(); slotNode0.release(); slotNode1.release();
             lvlA.release(); lvlB.release(); sampleColor.release(); sampleF32.release(); lights.release();
             for (auto &l : levels) { l.color.release(); l.childBase.release(); l.childMask.release(); l.cx.release(); l.cy.release(); }
             if (stream) (void)hipStreamDestroy(stream);
@@ -592,6 +593,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         HIPCHECK(hipMemset(s->waveTimes.p, 0, (size_t)16 * 3 * 8192 * sizeof(unsigned long long)));
     }
     if (heap && ((rc = W.node0.ensure(rayCap)) || (rc = W.node1.ensure(rayCap)) || (rc = W.ref0.ensure(rayCap)) || (rc = W.ref1.ensure(rayCap)) ||
+                 (rc = W.slotNode0.ensure(rayCap)) || (rc = W.slotNode1.ensure(rayCap)) ||
                  (rc = W.lvlAlpha.ensure((size_t)P * nodes))))
         return rc;
     if (wantF32 && (rc = W.sampleF32.ensure((size_t)P * 3))) return rc;
@@ -759,6 +761,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         xrt_hit *hitsOf[2] = {W.hits.p, W.hits1.p};
         int *flagsOf[2] = {W.hitFlags0.p, W.hitFlags1.p};
         SlotRec *slotOf[2] = {W.slot0.p, W.slot1.p};
+        int *slotNodeOf[2] = {W.slotNode0.p, W.slotNode1.p};
         for (int k = 0; k <= R + 1; k++) {
             const int cur = k & 1, prv = cur ^ 1;
             const bool hasClosest = k <= R, hasShadow = k >= 1 && nL > 0;
@@ -827,10 +830,10 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             X.rays = rays[cur]; X.hits = hitsOf[cur]; X.hitFlags = flagsOf[cur]; X.shadowFlags = W.shadowFlags.p; X.nDev = nClosest; X.nHost = Pc; X.cap = (int)rayCap;
             X.index = nullptr; X.rayPath = k == 0 ? W.index0.p : paths[cur];   // (generation 0: the j-th live ray belongs to path index0[j])
             X.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; X.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
-            X.slotOut = slotOf[cur]; X.scnt = scnt + k; X.shadowCap = (int)shadowCap; X.shadowRays = W.shadowRays.p;
+            X.slotOut = slotOf[cur]; X.slotNodeOut = heap ? slotNodeOf[cur] : nullptr; X.scnt = scnt + k; X.shadowCap = (int)shadowCap; X.shadowRays = W.shadowRays.p;
             X.nextRays = rays[prv]; X.nextPath = paths[prv]; X.nextNode = heap ? nodesOf[prv] : nullptr; X.nextRef = heap ? refOf[prv] : nullptr;
             X.nextCnt = cnt + k + 1; X.nextCap = (int)rayCap;
-            X.hitsPrev = hitsOf[prv]; X.slotPrev = slotOf[prv]; X.scntPrev = k >= 1 ? scnt + (k - 1) : nullptr; X.shadowHits = W.shadowHits.p;
+            X.slotPrev = slotOf[prv]; X.slotNodePrev = heap ? slotNodeOf[prv] : nullptr; X.scntPrev = k >= 1 ? scnt + (k - 1) : nullptr; X.shadowHits = W.shadowHits.p;
             X.lvlA = W.lvlA.p; X.lvlB = W.lvlB.p; X.lvlAlpha = heap ? W.lvlAlpha.p : nullptr;
             if (k < R) X.heavy = heavy_for(k + 1);
             if (feedback && hasClosest && !packet_closest(k)) { X.costOut = s->costMap.p + (size_t)k * (size_t)framePaths + (size_t)partStart; X.epoch = s->epoch & 0xffffu; }
