@@ -39,6 +39,8 @@ namespace xrt {
 
 constexpr int PK_LEVELS = 24;        // deeper octrees than this fall back to k_intersect (scene_build limits depth to 20)
 constexpr int PK_FRAME_WORDS = 12;   // blk, next child position, order mask, lanes (2), parent box min (3), half (3), pad
+// a wave's stack: PK_LEVELS frames, then per level one byte per lane -- which children of that level's block the lane's own box tests accepted
+constexpr int PK_STACK_WORDS = PK_LEVELS * (PK_FRAME_WORDS + 16);
 constexpr int PK_SLEVELS = 12;       // scene octree levels a packet can stack (deeper scene trees: k_intersect)
 constexpr int PK_SFRAME_WORDS = 4;   // scene block, pending children, lanes (2)
 #ifndef XRT_PK_QUEUES
@@ -177,8 +179,7 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
     U.half = half_of(rmin, rmax);
     U.lanes = lanes0;
     U.p = 0; U.dm0 = 0;
-    // per lane: for every level of the shared stack, which children of that level's block the lane's own box tests accepted
-    unsigned long long cbLo = 0, cbMid = 0, cbHi = 0;
+    unsigned char *const cbOf = reinterpret_cast<unsigned char *>(stk + PK_LEVELS * PK_FRAME_WORDS) + lane;   // [level * 64]: this lane's byte
     int sp = 0;
     bool entering = true, anyFound = false;   // anyFound: some lane of the wave has a candidate
     int d0 = 0, d1 = 0, d2 = 0, d3 = 0;
@@ -198,18 +199,16 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
             cb = 0;
             if (in) cb = fastL ? hit8_fast_children(L.r, L.dmask, U.bmin, U.half) : hit8_slow_children(L.r, U.bmin, U.half);
             cb &= 0xff & ~((d2 >> 8) & 0xff);   // empty leaves can never hit (Q4)
-            {   // remember it for the return to this level
-                const int sh = (sp & 7) * 8;
-                const unsigned long long m = ~(0xffull << sh), v = (unsigned long long)(unsigned)cb << sh;
-                if (sp < 8) cbLo = (cbLo & m) | v; else if (sp < 16) cbMid = (cbMid & m) | v; else cbHi = (cbHi & m) | v;
-            }
             U.dm0 = __builtin_amdgcn_readlane(L.dmask, (int)__builtin_ctzll(U.lanes));   // front-to-back order of the first lane
-            // children some lane entered, in that order: bit p <-> child (p ^ dm0)
-            int un = wave_or(cb);
-            if (U.dm0 & 4) un = ((un & 0xf0) >> 4) | ((un & 0x0f) << 4);
-            if (U.dm0 & 2) un = ((un & 0xcc) >> 2) | ((un & 0x33) << 2);
-            if (U.dm0 & 1) un = ((un & 0xaa) >> 1) | ((un & 0x55) << 1);
-            U.p = un;
+            // children some lane entered, in that order: bit p <-> child (p ^ dm0).  The xor moves a bit by 4, 2 and 1 places; each lane
+            // moves its own bits (vector shifts by wave-uniform amounts: 0 leaves the byte as it is) before the wave's OR, which costs the
+            // scalar unit three instructions where permuting the OR's result cost it twenty-four.
+            const int a4 = U.dm0 & 4, a2 = U.dm0 & 2, a1 = U.dm0 & 1;
+            int q = cb;
+            q = ((q << a4) | (q >> a4)) & 0xff;
+            q = ((q & 0x33) << a2) | ((q & 0xcc) >> a2);
+            q = ((q & 0x55) << a1) | ((q & 0xaa) >> a1);
+            U.p = wave_or(q);
             entering = false;
         }
         if (U.p == 0) {   // block exhausted: back to the level above
@@ -225,8 +224,7 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
             d0 = f2i(lo.x); d1 = f2i(lo.y); d2 = f2i(lo.z); d3 = f2i(lo.w);
             offLo = (unsigned long long)(unsigned)f2i(hi.x) | ((unsigned long long)(unsigned)f2i(hi.y) << 32);
             offHi = (unsigned long long)(unsigned)f2i(hi.z) | ((unsigned long long)(unsigned)f2i(hi.w) << 32);
-            const int sh = (sp & 7) * 8;
-            cb = (int)(((sp < 8 ? cbLo : (sp < 16 ? cbMid : cbHi)) >> sh) & 0xffull);
+            cb = (int)cbOf[sp * 64];
             continue;
         }
         const int c = (int)__builtin_ctz((unsigned)U.p) ^ U.dm0;
@@ -255,7 +253,8 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
         if (!((d2 >> c) & 1)) {   // ---- leaf (non-empty): MO:288-304 for the lanes the bucket rule lets in ----
             PKC(3);
             const f4 nlo = leafNB[2 * (size_t)node], nhi = leafNB[2 * (size_t)node + 1];
-            bool go = inC && !(L.mfound && key > L.mKey) && !all_back_facing(nlo, nhi, L.r.d);
+            bool go = inC & !all_back_facing(nlo, nhi, L.r.d);
+            if (keyed) go = go & !((L.mfound != 0) & (key > L.mKey));   // (wave-uniform branch: nobody has a candidate before `keyed`)
             if (!__any(go)) continue;
             PKC(4);
             const int r0 = d1 + child_ref_offset(offLo, offHi, c);
@@ -317,11 +316,13 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
             continue;
         }
         // ---- interior child: a lane prunes it by key only where that is a proven lower bound (safe bit) ----
-        const bool go = inC && !(L.mfound && ((d2 >> (16 + c)) & 1) && key > L.mKey);
+        bool go = inC;
+        if (keyed && ((d2 >> (16 + c)) & 1)) go = go & !((L.mfound != 0) & (key > L.mKey));   // (wave-uniform branch)
         const unsigned long long LL = __ballot(go);
         if (LL == 0ull) continue;
         if (sp >= PK_LEVELS - 1) continue;   // (cannot happen: packet_supported checks the depth)
         if (U.p != 0) {   // something is left to do at this level: come back
+            cbOf[sp * 64] = (unsigned char)cb;   // (every lane: its own accepted children of this level's block)
             if (lane == 0) {
                 unsigned *f = stk + sp * PK_FRAME_WORDS;
                 f[0] = (unsigned)U.blk; f[1] = (unsigned)U.p; f[2] = (unsigned)U.dm0;
@@ -377,12 +378,12 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
                                                 const f4 *__restrict__ runTB, const MeshRec *__restrict__ meshes,
                                                 const f4 *__restrict__ snodes, const f4 *__restrict__ scull, const ObjRec *__restrict__ objects,
                                                 const int *__restrict__ objMesh, SceneView S, PacketArgs A) {
-    __shared__ unsigned frames[4 * PK_LEVELS * PK_FRAME_WORDS];
+    __shared__ unsigned frames[4 * PK_STACK_WORDS];
     unsigned *const sframesAll = scene_frames<M>();
     unsigned *const parkAll = scene_park<M>();
     stamp_begin(A.stamps);
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    unsigned *const stk = &frames[wave * PK_LEVELS * PK_FRAME_WORDS];
+    unsigned *const stk = &frames[wave * PK_STACK_WORDS];
     int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
     if (A.nCap > 0 && n > A.nCap) n = A.nCap;
     int n2 = A.nDev2 ? (*A.nDev2) * A.nMul2 : 0;   // second segment (PacketArgs::rays2)
