@@ -207,8 +207,12 @@ def time_frames(tracer, outs, steps, warmup, rank, world, width, height, gathere
 
 def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=True, n_gpus_in_library=1):
     spec = xrt.configs.config(name, scale)
+    torch.cuda.synchronize()
+    mem0 = torch.cuda.mem_get_info()[0]   # free bytes of the device before the scene exists (hipMemGetInfo: everything on the card counts)
     t0 = time.perf_counter()
     scene, tracer = xrt.configs.build_product(spec, device=local_rank)
+    torch.cuda.synchronize()
+    mem1 = torch.cuda.mem_get_info()[0]
     tracer.NumGpus = n_gpus_in_library   # > 1: every frame below is ONE xrt_render_device call that the library spreads over that many devices
     build_s = time.perf_counter() - t0
     W, H = spec.width, spec.height
@@ -216,11 +220,15 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
     n_out = tpr * 512 if world > 1 else W * H
     outs = [torch.zeros(n_out, dtype=torch.int32, device="cuda") for _ in range(2)]   # two frames are in flight (one per frame context / stream)
     final = torch.zeros(W * H, dtype=torch.int32, device="cuda") if (world > 1 and rank == 0) else None
+    torch.cuda.synchronize()
+    mem1b = torch.cuda.mem_get_info()[0]   # (the output buffers above are not work buffers)
     # untimed: exact reference-work counters of this rank's shard (algorithmic bytes, ray counts)
     tracer.collect_stats = with_stats
     st0 = tracer.RenderDevice(outs[0].data_ptr(), shard_rank=rank, shard_count=world)
     tracer.collect_stats = False
     dt, ms_int, launches = time_frames(tracer, outs, steps, warmup, rank, world, W, H, final)
+    torch.cuda.synchronize()
+    mem2 = torch.cuda.mem_get_info()[0]   # after two frames in flight: both frame contexts hold their work buffers
     # the pixels the timed loop's own render objects produced last (read back after the timed region): what main() compares with the oracle
     last_frame = outs[(steps - 1) % 2].cpu().numpy().view(np.uint32).copy() if (world == 1 and steps > 0) else None
     if world > 1 and rank == 0 and os.environ.get("XRT_BENCH_VERIFY"):   # rehearsals: the gathered, de-tiled frame is the unsharded one
@@ -230,7 +238,9 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
         assert torch.equal(whole, final), "gathered frame differs from the unsharded render"
         print("bench.py: gathered frame verified against the unsharded render", file=sys.stderr)
     rays = st0["rays_closest"] + st0["rays_shadow"]
-    res = dict(rays=rays, seconds=dt, ms_intersect=ms_int, launches=launches, stats=st0, build_s=build_s, width=W, height=H, last_frame=last_frame,
+    device_memory = {"scene_GB": round((mem0 - mem1) / 1e9, 3), "frame_work_buffers_GB": round((mem1b - mem2) / 1e9, 3),
+                     "what": "hipMemGetInfo differences: scene arrays after the build; work buffers of BOTH frame contexts (two frames in flight) after the timed frames, output buffers excluded"}
+    res = dict(rays=rays, seconds=dt, ms_intersect=ms_int, launches=launches, stats=st0, build_s=build_s, width=W, height=H, last_frame=last_frame, device_memory=device_memory,
                tris=sum(m[0].ntri for m in spec.meshes), instances=len(spec.objects), overlapped=False)
     if world == 1 and dt / max(steps, 1) * 1e3 >= 0.04:
         # The frames of the timed region overlapped pairwise on the GPU (two streams), so a launch's duration includes time
@@ -478,7 +488,7 @@ def main():
                        "rays_traversed_per_frame": int(trav_frame),
                        "rays_answered_by_raygen_per_frame": int(rays_frame - trav_frame),
                        "parallelism": ("image tiles 64x8 round-robin x%d, one process: xrt_render_opts.n_gpus (in-library RCCL send/recv gather)" % args.gpus) if in_library
-                                      else "image tiles 64x8 round-robin x%d" % world, "scene_build_s": round(res["build_s"], 3)},
+                                      else "image tiles 64x8 round-robin x%d" % world, "scene_build_s": round(res["build_s"], 3), "device_memory": res["device_memory"]},
             "Mrays_per_s_traversed": round(trav_frame * args.steps / seconds / 1e6, 3),
             "roofline": roofline_block(args.config if (world == 1 and not in_library) else "(N > 1: no PMC pass)", bytes_per_launch, ms_per_launch, launches // max(args.steps, 1), serial),
         }
