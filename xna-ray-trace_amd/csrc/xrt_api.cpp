@@ -216,11 +216,11 @@ struct xrt_scene {
     // of persistent waves leaves the machine half empty while its last rays finish, and the other frame's launches fill it.
     struct WorkBufs {
         DevBuf<xrt_ray> rays0, rays1, shadowRays;
-        DevBuf<xrt_hit> hits, hits1, shadowHits;
+        DevBuf<xrt_hit> hits, shadowHits;
         DevBuf<int> path0, path1, index0, heavyList, cnts;
         DevBuf<int> node0, node1, heapFlag;     // ray-tree frames: heap node of every ray; heapFlag[0]: a generation overflowed its buffers
         DevBuf<float> ref0, ref1, lvlAlpha;     // ... refraction index of the medium a ray travels in; alpha per level record
-        DevBuf<int> hitFlags0, hitFlags1, shadowFlags;   // hit / miss word per ray of hits, hits1, shadowHits (a miss has no record)
+        DevBuf<int> hitFlags0, shadowFlags;   // hit / miss word per ray of hits, shadowHits (a miss has no record)
         DevBuf<unsigned long long> stamps;      // device-clock stamps of the traversal launches (device_util.h), STAMP_STRIDE per launch
         DevBuf<SlotRec> slot0, slot1;
         DevBuf<int> slotNode0, slotNode1;   // ray-tree frames: the node of a slot's hit
@@ -238,8 +238,8 @@ struct xrt_scene {
         hipStream_t stream = nullptr;           // the context's own stream (used when the caller passes none)
         hipStream_t lastStream = nullptr;       // the stream the context's last frame ran on
         void release() {
-            rays0.release(); rays1.release(); shadowRays.release(); hits.release(); hits1.release(); shadowHits.release();
-            path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); stamps.release(); hitFlags0.release(); hitFlags1.release(); shadowFlags.release();
+            rays0.release(); rays1.release(); shadowRays.release(); hits.release(); shadowHits.release();
+            path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); stamps.release(); hitFlags0.release(); shadowFlags.release();
             node0.release(); node1.release(); heapFlag.release(); ref0.release(); ref1.release(); lvlAlpha.release(); slot0.release(); slot1.release(); slotNode0.release(); slotNode1.release();
             lvlA.release(); lvlB.release(); sampleColor.release(); sampleF32.release(); lights.release();
             for (auto &l : levels) { l.color.release(); l.childBase.release(); l.childMask.release(); l.cx.release(); l.cy.release(); }
@@ -581,7 +581,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const bool fuseResolve = !adaptive && !heap && g.samples == 1;   // k_compose writes the framebuffer itself
     // buffers
     if ((rc = W.rays0.ensure(rayCap)) || (rc = W.rays1.ensure(rayCap)) || (rc = W.hits.ensure(rayCap)) || (rc = W.path0.ensure(rayCap)) ||
-        (rc = W.path1.ensure(rayCap)) || (rc = W.hits1.ensure(rayCap)) || (rc = W.hitFlags0.ensure(rayCap)) || (rc = W.hitFlags1.ensure(rayCap)) ||
+        (rc = W.path1.ensure(rayCap)) || (rc = W.hitFlags0.ensure(rayCap)) ||
         (rc = W.shadowFlags.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = W.slot0.ensure(rayCap)) ||
         (rc = W.slot1.ensure(rayCap)) || (rc = W.index0.ensure(rayCap)) || (rc = W.heavyList.ensure(rayCap)) || (rc = W.shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
         (rc = W.shadowHits.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = W.lvlA.ensure((size_t)P * nodes)) ||
@@ -758,8 +758,10 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         };
         // cnt[0] counts the primary rays that reach the scene's root box; index0 lists them
         { Range r("xrt raygen"); launch_raygen(gp, S, rays[0], W.lvlB.p, W.index0.p, cnt, Pc, pathBase, heavy_for(0), st, startEvent ? e0 : nullptr, (int)rayCap); startEvent = false; }
-        xrt_hit *hitsOf[2] = {W.hits.p, W.hits1.p};
-        int *flagsOf[2] = {W.hitFlags0.p, W.hitFlags1.p};
+        // (one buffer serves every generation: the closest-hit answers of launch #k are read by part A of k_shade #k alone -- part B works from the
+        // slot records -- and launch #k+1 starts after it on the frame's stream)
+        xrt_hit *hitsOf[2] = {W.hits.p, W.hits.p};
+        int *flagsOf[2] = {W.hitFlags0.p, W.hitFlags0.p};
         SlotRec *slotOf[2] = {W.slot0.p, W.slot1.p};
         int *slotNodeOf[2] = {W.slotNode0.p, W.slotNode1.p};
         for (int k = 0; k <= R + 1; k++) {
