@@ -32,9 +32,11 @@ xrt = importlib.import_module("xna-ray-trace_amd")
 XGMI_LINK_GBS = 153.0
 
 
-def timed(fr, reps):
+def timed(frs, reps):
     """Median GPU time of a blocking frame (xrt_stats.ms_total: the latency one call sees) and the period of the same frame rendered the way
-    bench.py times it: two tickets open, frame i+1 enqueued before frame i is waited for (launch tails of one frame fill with the other's work)."""
+    bench.py times it: two tickets open on two render objects with an output buffer each, frame i+1 enqueued before frame i is waited for
+    (launch tails of one frame fill with the other's work)."""
+    fr = frs[0]
     for _ in range(3):
         st = fr()
     ms = []
@@ -42,20 +44,18 @@ def timed(fr, reps):
         st = fr()
         ms.append(st["ms_total"])
     k = max(6, 2 * reps)
-    t_open = fr.begin()
+    for f in frs:   # both frame contexts warm
+        f()
+    t_open = frs[0].begin()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(k):
-        t_next = fr2_begin(fr)
-        fr.end(t_open)
+    for i in range(1, k + 1):
+        t_next = frs[i % 2].begin()
+        frs[(i - 1) % 2].end(t_open)
         t_open = t_next
-    fr.end(t_open)
+    frs[k % 2].end(t_open)
     torch.cuda.synchronize()
     return statistics.median(ms), st, (time.perf_counter() - t0) / (k + 1) * 1e3
-
-
-def fr2_begin(fr):
-    return fr.begin()
 
 
 def main():
@@ -72,7 +72,8 @@ def main():
         scene, tracer = xrt.configs.build_product(spec)
         W, H = spec.width, spec.height
         whole = torch.zeros(W * H, dtype=torch.int32, device="cuda")
-        t_whole, st_whole, p_whole = timed(tracer.PrepareDevice(whole.data_ptr()), args.reps)
+        whole2 = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+        t_whole, st_whole, p_whole = timed([tracer.PrepareDevice(whole.data_ptr()), tracer.PrepareDevice(whole2.data_ptr())], args.reps)
         cfg = {"width": W, "height": H, "t_whole_ms": round(t_whole, 4), "period_whole_ms": round(p_whole, 4), "rays_whole": int(st_whole["rays_closest"] + st_whole["rays_shadow"]),
                "rays_traversed_whole": int(st_whole["rays_traversed"]), "shards": {}}
         for n in [int(x) for x in args.n.split(",")]:
@@ -82,9 +83,12 @@ def main():
             tpr = c_tpr.value
             count = tpr * 512
             gathered = torch.zeros(n * count, dtype=torch.int32, device="cuda")
+            second = torch.zeros(count, dtype=torch.int32, device="cuda")   # output of the other frame in flight
             ts, ps, rays, trav = [], [], [], []
             for r in range(n):
-                t, st, per = timed(tracer.PrepareDevice(gathered[r * count:(r + 1) * count].data_ptr(), shard_rank=r, shard_count=n), args.reps)
+                t, st, per = timed([tracer.PrepareDevice(gathered[r * count:(r + 1) * count].data_ptr(), shard_rank=r, shard_count=n),
+                                    tracer.PrepareDevice(second.data_ptr(), shard_rank=r, shard_count=n)], args.reps)
+                tracer.PrepareDevice(gathered[r * count:(r + 1) * count].data_ptr(), shard_rank=r, shard_count=n)()   # (the shard's pixels for the de-tile check below)
                 ts.append(t); ps.append(per); rays.append(int(st["rays_closest"] + st["rays_shadow"])); trav.append(int(st["rays_traversed"]))
             final = torch.zeros(W * H, dtype=torch.int32, device="cuda")
             torch.cuda.synchronize()
