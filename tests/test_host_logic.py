@@ -369,6 +369,117 @@ def test_fbx_import_of_the_reference_assets(xrt):
     assert np.array_equal(turned.v[..., 1], plain.v[..., 1])
 
 
+def _fbx7_bytes(tree, version):
+    """A minimal binary FBX 7.x writer for the tests (the layout fbx.py documents): 32-bit record headers below 7500, 64-bit from 7500 on;
+    arrays uncompressed on even calls, zlib on odd ones."""
+    import struct
+    import zlib
+    wide = version >= 7500
+    state = {"n": 0}
+
+    def prop(v):
+        if isinstance(v, str):
+            raw = v.encode("latin-1")
+            return b"S" + struct.pack("<I", len(raw)) + raw
+        if isinstance(v, bool):
+            return b"C" + struct.pack("<?", v)
+        if isinstance(v, int):
+            return (b"L" + struct.pack("<q", v)) if abs(v) >= 1 << 31 else (b"I" + struct.pack("<i", v))
+        if isinstance(v, float):
+            return b"D" + struct.pack("<d", v)
+        a = np.asarray(v)
+        code, dt = (b"d", "<f8") if a.dtype.kind == "f" else (b"i", "<i4")
+        raw = a.astype(dt).tobytes()
+        state["n"] += 1
+        if state["n"] % 2:
+            z = zlib.compress(raw)
+            return code + struct.pack("<III", a.size, 1, len(z)) + z
+        return code + struct.pack("<III", a.size, 0, len(raw)) + raw
+
+    def node(name, props, children, at):
+        head = 25 if wide else 13
+        pl = b"".join(prop(x) for x in props)
+        body = b""
+        pos = at + head + len(name) + len(pl)
+        for c in children:
+            cb = node(c[0], c[1], c[2], pos + len(body))
+            body += cb
+        if children:
+            body += bytes(head)   # null record closes a list of children
+        end = pos + len(body)
+        return struct.pack("<QQQ" if wide else "<III", end, len(props), len(pl)) + bytes([len(name)]) + name.encode("latin-1") + pl + body
+
+    out = b"Kaydara FBX Binary  \x00\x1a\x00" + struct.pack("<I", version)
+    assert len(out) == 27
+    for t in tree:
+        out += node(t[0], t[1], t[2], len(out))
+    return out + bytes(25 if wide else 13)
+
+
+def test_fbx_75_records_and_vertex_colours(xrt, tmp_path):
+    """fbx.py beyond the reference's own assets (VERDICT r2 missing #7): binary FBX 7500 (64-bit record headers) reads like 7400, and the
+    processor parameter UseVertexColors (TMP:93-101, 224-227) takes a triangle's colour from the colour channel at the triangle's first
+    index, through an XNA `Color` (bytes, round-half-even) -- from binary 7.x (ByPolygonVertex, IndexToDirect) and ASCII 6.1 (ByVertice, Direct)."""
+    import importlib
+    fbx = importlib.import_module("xna-ray-trace_amd.fbx")
+    verts = [0.0, 0.0, 0.0, 2.0, 0.0, 0.0, 2.0, 2.0, 0.0, 0.0, 2.0, 0.0, 1.0, 1.0, 3.0]
+    pvi = [0, 1, 2, -4, 0, 1, -5]            # a quad and a triangle
+    normals = [0.0, 0.0, 1.0] * 7
+    palette = [1.0, 0.0, 0.0, 1.0, 0.5, 0.1, 0.25, 1.0, 0.0, 0.0, 1.0, 0.5]     # red, an inexact one, half-transparent blue
+    cidx = [1, 0, 0, 0, 2, 0, 0]             # polygon-vertex -> palette entry
+    tree = [("GlobalSettings", [], [("Properties70", [], [("P", ["UpAxis", "int", "Integer", "", 1], [])])]),
+            ("Objects", [], [
+                ("Geometry", [1001, "quadtri\x00\x01Geometry", "Mesh"], [
+                    ("Vertices", [np.array(verts)], []), ("PolygonVertexIndex", [np.array(pvi)], []),
+                    ("LayerElementNormal", [0], [("MappingInformationType", ["ByPolygonVertex"], []), ("ReferenceInformationType", ["Direct"], []),
+                                                 ("Normals", [np.array(normals)], [])]),
+                    ("LayerElementColor", [0], [("MappingInformationType", ["ByPolygonVertex"], []), ("ReferenceInformationType", ["IndexToDirect"], []),
+                                                ("Colors", [np.array(palette)], []), ("ColorIndex", [np.array(cidx)], [])])]),
+                ("Model", [2002, "quadtri\x00\x01Model", "Mesh"], [("Properties70", [], [("P", ["Lcl Translation", "Lcl Translation", "", "A", 1.0, 2.0, 3.0], [])])])]),
+            ("Connections", [], [("C", ["OO", 1001, 2002], [])])]
+    got = {}
+    for version in (7400, 7500):
+        f = tmp_path / ("q%d.fbx" % version)
+        f.write_bytes(_fbx7_bytes(tree, version))
+        ms, up = fbx.load_fbx(str(f))
+        assert up == 1 and len(ms) == 1 and ms[0].translation == (1.0, 2.0, 3.0) and ms[0].polygons == [[0, 1, 2, 3], [0, 1, 4]]
+        got[version] = (fbx.import_mesh(ms[0], up, diffuse_color=(10, 20, 30, 255)), fbx.import_mesh(ms[0], up, diffuse_color=(10, 20, 30, 255), use_vertex_colors=True))
+    for a, b in zip(got[7400], got[7500]):
+        assert np.array_equal(a.v, b.v) and np.array_equal(a.n, b.n) and np.array_equal(a.color, b.color)
+    plain, coloured = got[7500]
+    assert plain.ntri == 3 and np.array_equal(plain.color, np.tile(np.array([10, 20, 30, 255], dtype=np.float32) / np.float32(255.0), (3, 1)))
+    # first polygon-vertex of the quad has palette entry 1: (0.5, 0.1, 0.25, 1) -> bytes (128, 26, 64, 255): 127.5 and 63.75 round to even / nearest
+    q = np.array([128, 26, 64, 255], dtype=np.float32) / np.float32(255.0)
+    t = np.array([0, 0, 255, 128], dtype=np.float32) / np.float32(255.0)   # the triangle's first polygon-vertex: entry 2, alpha 0.5 -> 127.5 -> 128
+    assert np.array_equal(coloured.color, np.stack([q, q, t]))
+    assert fbx.xna_color_bytes((1.5, -0.2, float("nan"), 2.5 / 255.0)) == (255, 0, 0, 2)   # clamped; NaN -> 0; 2.5 -> 2 (to even)
+    wide = _fbx7_bytes(tree, 7500)
+    with pytest.raises(ValueError):
+        fbx.load_binary7(wide[:27] + (10 ** 9).to_bytes(8, "little") + wide[35:])   # a record that ends outside the file
+    # ASCII 6.1, colours by vertex, direct
+    text = """FBXHeaderExtension:  { FBXVersion: 6100 }
+Objects:  {
+    Model: "Model::tri", "Mesh" {
+        Properties60:  { Property: "Lcl Translation", "Lcl Translation", "A+",0,0,0 }
+        Vertices: 0,0,0,1,0,0,0,1,0
+        PolygonVertexIndex: 0,1,-3
+        LayerElementNormal: 0 { MappingInformationType: "ByVertice"
+            ReferenceInformationType: "Direct"
+            Normals: 0,0,1,0,0,1,0,0,1 }
+        LayerElementColor: 0 { MappingInformationType: "ByVertice"
+            ReferenceInformationType: "Direct"
+            Colors: 0.2,0.4,0.6,1,1,1,1,1,0,0,0,1 }
+    }
+}
+"""
+    f = tmp_path / "t.fbx"
+    f.write_text(text)
+    ms, up = fbx.load_fbx(str(f))
+    m = fbx.import_mesh(ms[0], up, use_vertex_colors=True)
+    assert m.ntri == 1 and np.array_equal(m.color[0], np.array([51, 102, 153, 255], dtype=np.float32) / np.float32(255.0))
+    assert np.array_equal(fbx.import_mesh(ms[0], up).color[0], np.ones(4, dtype=np.float32))
+
+
 def test_default_game_scene_traversal(xrt, orc, emul):
     """G1 = the scene of Game1.LoadContent (4 Transparent spheres sharing one Mesh): scene octree, interpolated
     normals and the shared-mesh ignoreTriangle (Q9) through the emulated traversal."""

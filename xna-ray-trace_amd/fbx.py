@@ -1,5 +1,5 @@
-"""Asset ingestion: FBX 6.x (ASCII 6.1 as written by Blender, binary 6100 as written by 3ds Max) and binary 7.1-7.4
--> the triangle arrays a `Mesh` carries, with the semantics of RayTracePipeline/TracerModelProcessor.cs:
+"""Asset ingestion: FBX 6.x (ASCII 6.1 as written by Blender, binary 6100 as written by 3ds Max) and binary 7.x (7100-7400
+with 32-bit record offsets, 7500 and later with 64-bit ones) -> the triangle arrays a `Mesh` carries, with the semantics of RayTracePipeline/TracerModelProcessor.cs:
 vertices are baked with the node's absolute transform (TMP:179-181), normals with its inverse transpose and
 re-normalised (TMP:191-197), surfaceNormal = normalize(cross(v3-v1, v2-v1)) (TMP:199-203), the mesh AABB starts at
 the origin (TMP:244-307), `Scale` is the ModelProcessor parameter of the .contentproj.
@@ -30,6 +30,9 @@ class FbxMesh:
         self.uvs = None               # (k, 2)
         self.uv_index = None
         self.uv_mapping = None
+        self.colors = None            # (c, 4) vertex colour channel (LayerElementColor), or None
+        self.color_index = None
+        self.color_mapping = None     # "ByVertice" | "ByPolygonVertex"
         self.translation = (0.0, 0.0, 0.0)
         self.rotation = (0.0, 0.0, 0.0)   # degrees
         self.scaling = (1.0, 1.0, 1.0)
@@ -100,6 +103,15 @@ def load_ascii(text):
             fm.uvs = np.array(_ascii_array(ub, "UV"), dtype=np.float64).reshape(-1, 2)
             ui = _ascii_array(ub, "UVIndex")
             fm.uv_index = [int(x) for x in ui] if ui else None
+        cm = re.search(r"LayerElementColor:\s*\d+\s*\{", body)
+        if cm:
+            cb = body[cm.end():_ascii_block(body, cm.end())]
+            cols = _ascii_array(cb, "Colors")
+            if cols:
+                fm.color_mapping = re.search(r'MappingInformationType:\s*"([^"]*)"', cb).group(1)
+                fm.colors = np.array(cols, dtype=np.float64).reshape(-1, 4)
+                ci = _ascii_array(cb, "ColorIndex")
+                fm.color_index = [int(x) for x in ci] if ci else None
         meshes.append(fm)
     return meshes, up_axis
 
@@ -153,7 +165,7 @@ def load_binary(b):
     return [fm], (int(up[0]) if up else 1)
 
 
-# ---- binary FBX 7.x (7100-7400: 32-bit record offsets) ---------------------------------------------------------------------
+# ---- binary FBX 7.x (7100-7400: 32-bit record offsets; 7500+: 64-bit) ---------------------------------------------------------------------
 # Header: 21-byte magic, 2 bytes, uint32 version.  Node record: uint32 endOffset, numProperties, propertyListLen; uint8 nameLen; name;
 # properties; nested records up to endOffset (a 13-byte zero record closes a list).  Property: a type byte, then Y int16, C bool,
 # I int32, F float, D double, L int64; S / R: uint32 length + bytes; arrays f d l i b: uint32 count, encoding (1 = zlib), byte
@@ -194,20 +206,24 @@ def _read_prop7(b, pos):
     raise ValueError("FBX 7: unknown property type %r at %d" % (t, pos - 1))
 
 
-def _read_node7(b, pos):
-    end, nprops, _plen = struct.unpack_from("<III", b, pos)
-    nlen = b[pos + 12]
+def _read_node7(b, pos, wide=False):
+    """One node record; `wide`: FBX >= 7500, whose three header fields are uint64 (a 25-byte header and null record instead of 13)."""
+    head = 25 if wide else 13
+    end, nprops, _plen = struct.unpack_from("<QQQ" if wide else "<III", b, pos)
+    nlen = b[pos + head - 1]
     if end == 0:
-        return None, pos + 13
-    name = bytes(b[pos + 13:pos + 13 + nlen]).decode("latin-1")
-    p = pos + 13 + nlen
+        return None, pos + head
+    if end > len(b) or end <= pos:
+        raise ValueError("FBX node record at %d ends at %d in a file of %d bytes" % (pos, end, len(b)))
+    name = bytes(b[pos + head:pos + head + nlen]).decode("latin-1")
+    p = pos + head + nlen
     props = []
     for _ in range(nprops):
         v, p = _read_prop7(b, p)
         props.append(v)
     children = []
     while p < end:
-        c, p = _read_node7(b, p)
+        c, p = _read_node7(b, p, wide)
         if c is None:
             break
         children.append(c)
@@ -215,14 +231,13 @@ def _read_node7(b, pos):
 
 
 def load_binary7(b):
-    """Binary FBX 7.x: Objects/Geometry (Vertices, PolygonVertexIndex, LayerElementNormal, LayerElementUV), the Model each geometry
-    is connected to (Connections "OO") for its Lcl transform, GlobalSettings/UpAxis."""
+    """Binary FBX 7.x: Objects/Geometry (Vertices, PolygonVertexIndex, LayerElementNormal, LayerElementUV, LayerElementColor), the Model each
+    geometry is connected to (Connections "OO") for its Lcl transform, GlobalSettings/UpAxis."""
     version = struct.unpack_from("<I", b, 23)[0]
-    if version >= 7500:
-        raise ValueError("FBX %d: 64-bit record offsets are not read" % version)
+    wide = version >= 7500
     pos, top = 27, []
-    while pos < len(b) - 13:
-        n, pos = _read_node7(b, pos)
+    while pos < len(b) - (25 if wide else 13):
+        n, pos = _read_node7(b, pos, wide)
         if n is None:
             break
         top.append(n)
@@ -266,6 +281,12 @@ def load_binary7(b):
             fm.uv_mapping = lu.first("MappingInformationType").props[0]
             ui = lu.first("UVIndex")
             fm.uv_index = [int(x) for x in ui.props[0]] if ui is not None else None
+        lc = g.first("LayerElementColor")
+        if lc is not None and lc.first("Colors") is not None:
+            fm.colors = np.asarray(lc.first("Colors").props[0], dtype=np.float64).reshape(-1, 4)
+            fm.color_mapping = lc.first("MappingInformationType").props[0]
+            ci = lc.first("ColorIndex")
+            fm.color_index = [int(x) for x in ci.props[0]] if (ci is not None and lc.first("ReferenceInformationType").props[0] == "IndexToDirect") else None
         model = models.get(parent.get(g.props[0]))
         fm.translation = tuple(float(x) for x in p70(model, "Lcl Translation", [0.0, 0.0, 0.0])[:3])
         fm.rotation = tuple(float(x) for x in p70(model, "Lcl Rotation", [0.0, 0.0, 0.0])[:3])
@@ -283,15 +304,29 @@ def load_fbx(path):
     return load_ascii(data.decode("latin-1"))
 
 
+def xna_color_bytes(rgba):
+    """`new Color(Vector4)` of XNA 4: every component times 255, clamped to [0, 255], Math.Round to nearest-even (PackUtils.PackUNorm)."""
+    out = []
+    for c in rgba:
+        v = f32(c) * f32(255.0)
+        v = f32(0.0) if not (v == v) else min(max(v, f32(0.0)), f32(255.0))
+        out.append(int(np.rint(np.float64(v))))
+    return tuple(out)
+
+
 def import_mesh(fm, up_axis=1, scale=1.0, diffuse_color=(255, 255, 255, 255), apply_node_transform=True, flip_v=True,
-                rotation=(0.0, 0.0, 0.0)):
+                rotation=(0.0, 0.0, 0.0), use_vertex_colors=False):
     """FbxMesh -> fixtures.MeshData with TracerModelProcessor semantics (see module docstring).
 
     `scale` and `rotation` (degrees) are the ModelProcessor parameters Scale / RotationX / RotationY / RotationZ of the content
     project (contentproj:116,190,203,224): the base processor transforms the whole scene before TracerModelProcessor bakes the
     absolute transforms into the vertices (TMP:105-107,179-181).  XNA's ModelProcessor is closed source; the build's definition:
     scene transform = CreateScale(Scale) * CreateRotationX * CreateRotationY * CreateRotationZ, applied after the importer's
-    axis conversion; normals take the rotation part (its inverse transpose is itself)."""
+    axis conversion; normals take the rotation part (its inverse transpose is itself).
+
+    `use_vertex_colors` = the processor parameter UseVertexColors (TMP:93-101): when the geometry has a colour channel, a triangle's colour is
+    the channel's value at the triangle's FIRST index, as an XNA `Color` (quantised to bytes) turned back into a Vector4 (TMP:224-225);
+    otherwise DiffuseColor (TMP:227)."""
     if apply_node_transform:
         rad = [f32(np.deg2rad(float(a))) for a in fm.rotation]
         world, _, _ = xna.build_world(fm.scaling, rad, fm.translation, np.zeros(6, dtype=np.float32))
@@ -322,7 +357,8 @@ def import_mesh(fm, up_axis=1, scale=1.0, diffuse_color=(255, 255, 255, 255), ap
         if rotated:
             v = xna.transform(xna.vec3(*[float(c) for c in v]), rot)
         return tuple(float(c) for c in xna.normalize(v))
-    tris, nrms, uvs = [], [], []
+    tris, nrms, uvs, cols = [], [], [], []
+    vertex_colors = use_vertex_colors and fm.colors is not None
     pv = 0   # polygon-vertex counter
     for poly in fm.polygons:
         corner = []
@@ -335,11 +371,20 @@ def import_mesh(fm, up_axis=1, scale=1.0, diffuse_color=(255, 255, 255, 255), ap
                 ui = fm.uv_index[pv + k] if fm.uv_index is not None else pv + k
                 u, w = fm.uvs[ui]
                 uv = (float(f32(u)), float(f32(1.0) - f32(w)) if flip_v else float(f32(w)))
-            corner.append((pos(fm.vertices[vi]), n, uv))
+            rgba = None
+            if vertex_colors:
+                at = pv + k if fm.color_mapping == "ByPolygonVertex" else vi
+                rgba = fm.colors[fm.color_index[at] if fm.color_index is not None else at]
+            corner.append((pos(fm.vertices[vi]), n, uv, rgba))
         pv += len(poly)
         for k in range(1, len(poly) - 1):   # fan (p0, pk, pk+1), reversed to clockwise: (p0, pk+1, pk)
             a, b, c = corner[0], corner[k + 1], corner[k]
             tris.append((a[0], b[0], c[0])); nrms.append((a[1], b[1], c[1])); uvs.append((a[2], b[2], c[2]))
+            if vertex_colors:
+                cols.append([f32(x) / f32(255.0) for x in xna_color_bytes(a[3])])   # ((Color)colors[Indices[i]]).ToVector4() (TMP:225)
     n = len(tris)
-    col = np.tile(np.array([[f32(c) / f32(255.0) for c in diffuse_color]], dtype=np.float32), (n, 1))   # Color.ToVector4 (TMP:228)
+    if vertex_colors:
+        col = np.array(cols, dtype=np.float32).reshape(n, 4)
+    else:
+        col = np.tile(np.array([[f32(c) / f32(255.0) for c in diffuse_color]], dtype=np.float32), (n, 1))   # Color.ToVector4 (TMP:228)
     return MeshData(np.array(tris, dtype=np.float32), np.array(nrms, dtype=np.float32), np.array(uvs, dtype=np.float32), col)
