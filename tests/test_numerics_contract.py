@@ -121,4 +121,5 @@ def test_packet_kernel_resources(isa):
         mode = int(re.search(r"k_packetILi(\d)E", name).group(1))
         # 112 SGPRs allow six waves per SIMD, and so do up to 80 VGPRs (one-body variants); the two-level variant also carries the
         # scene cursor and the body's transform: four waves per SIMD (128 registers), its scene-level answer parked in LDS
-        assert int(sgprs) <= budget and int(vgprs) <= (128 if mode == 0 else 80) and int(scratch) == 0, (name, sgprs, vgprs, scratch)
+        # (round 3: five waves per SIMD -- 96 registers and a few dwords of scratch per lane that are touched once per packet, measured faster than 4 x 106)
+        assert int(sgprs) <= budget and int(vgprs) <= (96 if mode == 0 else 80) and int(scratch) <= (48 if mode == 0 else 0), (name, sgprs, vgprs, scratch)

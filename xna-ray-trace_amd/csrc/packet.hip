@@ -370,7 +370,7 @@ template <int M> __device__ __forceinline__ unsigned *scene_frames() {
 }
 
 #ifndef PK_SCENE_WAVES
-#define PK_SCENE_WAVES 4   // waves per SIMD the scene variant is compiled for (108 VGPRs as it stands; 5 would spill 44 bytes per lane)
+#define PK_SCENE_WAVES 5   // waves per SIMD the scene variant is compiled for: 96 VGPRs + 44 bytes of scratch per lane, touched per packet (not per step): C3 -5 %, C4 -7.5 % against 4 waves at 106 VGPRs (profiles/r03/packet_scene_five_waves.txt; at 111 VGPRs the same switch lost)
 #endif
 template <int M>
 __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k_packet(const f4 *__restrict__ blocks, const float *__restrict__ refT,
