@@ -283,6 +283,7 @@ struct xrt_scene {
         int tallyChunks = 0, cntStride = 0, R = 0, nL = 0;
         bool collect = false;
         unsigned long long shaded = 0, closestDeep = 0, livePaths = 0, live0 = 0, validPixels = 0;
+        size_t liveCap = 0;   // room of the generation-0 ray arrays (k_raygen writes no live ray past it: a count above it is a wrong bound, reported)
         unsigned long long hcnt[2 * C_COUNT] = {0};
         WorkBufs w;
     } frames[8];   // context of ticket `slot`, part j of its frame: frames[slot + 2 * j] (a frame may be split into up to four bands on as many streams)
@@ -562,13 +563,14 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const long long chunkPaths = firstPaths < maxPaths ? firstPaths : maxPaths;
     const int P = (int)chunkPaths;
     size_t rayCap = (size_t)P;
+    F.liveCap = (size_t)P;
     // The per-ray arrays hold LIVE rays only (k_raygen compacts them): a live primary ray belongs to a pixel inside the screen rectangle
     // of the scene's root box, so a plain or 16-sub-ray frame of one chunk needs room for the rectangle's paths, not for every path
     // (C5: 52 % of the image); later generations have fewer rays than the one before.  (Adaptive frames: the deeper quadrant levels are
     // lists of up to a quadrant per pixel; ray trees: sized below.)
     if (!heap && !adaptive && firstPaths <= chunkPaths) {
         const long long rectPaths = (long long)std::max(0, g.cullX1 - g.cullX0 + 1) * (long long)std::max(0, g.cullY1 - g.cullY0 + 1) * g.samples + 64;
-        if (rectPaths < (long long)rayCap) rayCap = (size_t)rectPaths;
+        if (rectPaths < (long long)rayCap) { rayCap = (size_t)rectPaths; F.liveCap = rayCap; }
     }
     if (heap) {
         const size_t capL = (size_t)std::min<long long>(s->heapRayCap, lightBound);   // (>= 8192 >= ... see above; P <= lightBound as well)
@@ -1149,6 +1151,8 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
         const size_t nb = (size_t)F.tallyChunks * F.cntStride * sizeof(int);
         for (int c = 0; c < F.tallyChunks; c++) {
             const int *hc = (const int *)F.pinned + F.cntBase + (size_t)c * F.cntStride;
+            if (hc[0] < 0 || (size_t)hc[0] > F.liveCap)
+                return fail(XRT_E_INTERNAL, "%d primary rays reach the scene but the frame's ray arrays were sized for %zu (screen rectangle of the root box)", hc[0], F.liveCap);
             for (int k = 0; k <= R; k++) {
                 F.shaded += (unsigned long long)hc[(R + 2) + k];
                 if (k > 0) F.closestDeep += (unsigned long long)(F.heap ? hc[k] : hc[(R + 2) + k - 1]);   // reflection chain: one ray per parent hit
