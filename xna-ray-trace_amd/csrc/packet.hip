@@ -11,8 +11,8 @@
 //   * wave-uniform state (SGPRs / one LDS frame per level): current block, its descriptor, the parent box, the lanes that
 //     are inside it, the position in the child order; everything the walk reads is the same for all lanes and arrives through the
 //     scalar cache (s_load), requested ahead of its use;
-//   * per lane only the ray, its best answer so far and one byte per level (which children of that level's block the
-//     ray's own box tests accepted);
+//   * per lane only the ray and its best answer so far in registers, and in LDS one byte per stacked level (which children of that
+//     level's block the ray's own box tests accepted);
 //   * a child is visited when ANY lane of the current set passed its box test (MO:331 -- hit8_*_children evaluates the
 //     reference's test for all eight children of a block); lanes that did not are masked off for that subtree, as are
 //     lanes the bucket rule lets prune it (key above the lane's best key on a `safe` interior node or a leaf);
