@@ -552,11 +552,11 @@ def main():
                 parity_failed = not line["parity_ok"]
         if solo and not args.no_extra and args.scale == 1.0:
             other = {}
-            for name, k in (("C2", 20), ("C3", 5), ("C4", 3), ("G1", 5)):   # G1: the scene the reference's own Stopwatch would time (Game1.cs)
+            for name, k in (("C2", 20), ("C3", 20), ("C4", 12), ("G1", 20)):   # G1: the scene the reference's own Stopwatch would time (Game1.cs)
                 if name == args.config:
                     continue
                 try:
-                    r2, _ = run_config(name, 1.0, k, 2, 0, local_rank, 1)
+                    r2, _ = run_config(name, 1.0, k, 3, 0, local_rank, 1)   # (enough frames for the fill and drain of two in flight not to show in the period)
                     # per-launch figures from the serialised pass when the timed frames overlapped
                     ms_i, l2, kk = (r2["serial_ms_intersect"], max(r2["serial_launches"], 1), r2["serial_steps"]) if r2["overlapped"] else (r2["ms_intersect"], max(r2["launches"], 1), k)
                     rb = roofline_block(name, intersect_bytes(r2["stats"]) * kk / l2, ms_i / l2, l2 // max(kk, 1))
