@@ -455,6 +455,91 @@ def test_default_game_scene(xrt, orc):
         assert tracer.last_stats[k] == o_st[k], (k, tracer.last_stats[k], o_st[k])
 
 
+def test_default_game_scene_as_the_reference_renders_it(xrt, orc):
+    """G1 at the size the reference's game really renders (Game1.cs:44-45: a 512x512 back buffer; Game1.cs:126: MaxReflections 8): the
+    whole frame, RGBA8 and the fp32 colours, blocking and two frames in flight, plus the oracle's ray accounting."""
+    import torch
+    spec = xrt.configs.default_game_scene(512, 512, 8)
+    scene, tracer = xrt.configs.build_product(spec)
+    o_rgba, o_rgbf, o_st = orc.OracleScene(spec).render(nthreads=16)
+    rgba, rgbf = tracer.Render(want_float=True)
+    assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+    st = tracer.last_stats
+    for k in ("rays_closest", "rays_shadow", "shaded_hits", "pixels"):
+        assert st[k] == o_st[k], (k, st[k], o_st[k])
+    outs = [torch.zeros(512 * 512, dtype=torch.int32, device="cuda") for _ in range(2)]
+    frs = [tracer.PrepareDevice(o.data_ptr()) for o in outs]
+    for _ in range(3):
+        t0 = frs[0].begin(); t1 = frs[1].begin(); frs[0].end(t0); frs[1].end(t1)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy().view(np.uint32).reshape(o_rgba.shape), o_rgba)
+
+
+def test_work_buffers_under_guards(xrt, orc, monkeypatch):
+    """XRT_GUARD=1: every device buffer of scenes created from now on ends in 4 KB of a known pattern that the end of every frame and
+    batched query checks (xrt_api.cpp guards_check) -- a kernel that writes past an array it was given is XRT_E_INTERNAL here instead
+    of a corrupted neighbour or a process abort.  The frame modes whose arrays are sized tightly: generation-0 arrays sized by the root
+    box's screen rectangle (a soup seen from close by: the case that aborted once during round 3, a camera inside the root box, a scene
+    in the image's corner), 16 sub-rays, adaptive levels, ray trees, many lights, tile shards, two frames in flight."""
+    import copy
+    import torch
+    monkeypatch.setenv("XRT_GUARD", "1")
+    try:
+        grid = xrt.configs.crate_grid_scene(96, 54)
+        inside = copy.deepcopy(grid); inside.camera = dict(grid.camera); inside.camera["pos"] = (3.0, 30.0, 5.0); inside.camera["target"] = (60.0, 10.0, 40.0)
+        corner = copy.deepcopy(xrt.configs.crate_scene(96, 64, max_reflections=2)); corner.camera = dict(corner.camera)
+        corner.camera["pos"] = (0.0, 128.0, 256.0); corner.camera["target"] = (120.0, -60.0, 0.0)
+        grid16 = copy.deepcopy(grid); grid16.multisampling = xrt.abi.MS_FIXED16
+        hf16 = xrt.configs.heightfield_scene(80, 45, m=64, multisampling=xrt.abi.MS_FIXED16)
+        adaptive = xrt.configs.heightfield_scene(64, 36, m=48, multisampling=xrt.abi.MS_ADAPTIVE); adaptive.multisample_quality = 2
+        glass = xrt.configs.default_game_scene(64, 64, 4)
+        lights = copy.deepcopy(grid); lights.lights = [xrt.configs.spot((40.0 * np.cos(i), 200.0 + i, 40.0 * np.sin(i))) for i in range(5)]
+        specs = [soup_spec(xrt, 60, 3, 2, 0.9), soup_spec(xrt, 2000, 7, 20, 0.15), inside, corner, grid16, hf16, adaptive, glass, lights]
+        for spec in specs:
+            spec = spec_with(spec, 2) if spec.name == "soup" else spec
+            o_rgba, _, _ = orc.OracleScene(spec).render(nthreads=8, want_float=False)
+            scene, tracer = xrt.configs.build_product(spec)
+            assert np.array_equal(tracer.Render(), o_rgba), spec.name          # (a violated guard raises from xrt.abi.check)
+            outs = [torch.zeros(spec.width * spec.height, dtype=torch.int32, device="cuda") for _ in range(2)]
+            frs = [tracer.PrepareDevice(o.data_ptr()) for o in outs]
+            t0 = frs[0].begin(); t1 = frs[1].begin(); frs[0].end(t0); frs[1].end(t1)
+            torch.cuda.synchronize()
+            for o in outs:
+                assert np.array_equal(o.cpu().numpy().view(np.uint32).reshape(o_rgba.shape), o_rgba), spec.name
+            rays = random_rays(xrt, 3000, 11)
+            assert hits_equal(orc.OracleScene(spec).intersect(rays), scene.IntersectBatch(rays)) == {}
+            if spec.multisampling != xrt.abi.MS_ADAPTIVE:   # tile shards of the same frame
+                tx, ty, tpr = C.c_int32(), C.c_int32(), C.c_int32()
+                xrt.abi.lib().xrt_shard_layout(spec.width, spec.height, 3, C.byref(tx), C.byref(ty), C.byref(tpr))
+                part = torch.zeros(tpr.value * 512, dtype=torch.int32, device="cuda")
+                for r in range(3):
+                    tracer.RenderDevice(part.data_ptr(), shard_rank=r, shard_count=3)
+    finally:
+        monkeypatch.delenv("XRT_GUARD")
+        s0, _ = xrt.configs.build_product(xrt.configs.crate_scene(32, 32, 0))   # (xrt_scene_create reads the switch: guards off again for the tests that follow)
+
+
+def test_many_lights_shrink_the_chunk(xrt, orc, monkeypatch):
+    """The reference iterates a List<ILight> of any length (RT:534-542).  Shadow rays, hits and words are 84 bytes per path and light in
+    every frame context: a light count whose arrays exceed the byte budget (XRT_SHADOW_BYTES, here forced small) shrinks the chunk and the
+    frame takes the multi-chunk path instead of failing with XRT_E_OOM -- 128 lights on a small image."""
+    import copy
+    spec = copy.deepcopy(xrt.configs.crate_grid_scene(160, 96))
+    spec.lights = [xrt.configs.spot((300.0 * np.cos(0.37 * i), 150.0 + 2.0 * i, 300.0 * np.sin(0.37 * i))) for i in range(128)]
+    for l in spec.lights:
+        l["intensity"] = 0.02
+    o_rgba, o_rgbf, o_st = orc.OracleScene(spec).render(nthreads=16)
+    monkeypatch.setenv("XRT_SHADOW_BYTES", str(84 * 128 * 8192))   # room for 8192 paths' shadow rays: the 160x96 frame (15,360 paths + tile padding) needs three chunks
+    scene, tracer = xrt.configs.build_product(spec)
+    rgba, rgbf = tracer.Render(want_float=True)
+    assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+    st = tracer.last_stats
+    for k in ("rays_closest", "rays_shadow", "shaded_hits"):
+        assert st[k] == o_st[k], (k, st[k], o_st[k])
+    assert st["rays_shadow"] == 128 * st["shaded_hits"]
+
+
 def test_empty_and_tiny_scenes(xrt, orc):
     """Edge cases of the containers: no bodies at all, a body without meshes, a mesh without triangles, one triangle."""
     def spec_of(meshes, objects):
@@ -511,8 +596,8 @@ def test_error_conventions_on_gpu(xrt):
 
 
 def test_full_size_properties_c2(xrt):
-    """C2 at its full 1920x1080 size (too slow for a full oracle frame in a unit test): idempotence, ray
-    accounting, sampled rows against the oracle, and sharded == unsharded."""
+    """C2 at its full 1920x1080 size: idempotence, ray accounting, EVERY row against the oracle (2.7 M rays, 0.2 s on the host's cores),
+    and sharded == unsharded."""
     import torch
     spec = xrt.configs.config("C2")
     scene, tracer = xrt.configs.build_product(spec)
@@ -523,9 +608,9 @@ def test_full_size_properties_c2(xrt):
     assert st["pixels"] == 1920 * 1080 and st["rays_closest"] >= st["pixels"] and st["rays_shadow"] == st["shaded_hits"]
     from oracle import oracle_py as orc
     o = orc.OracleScene(spec)
-    rows = (530, 546)
-    o_rgba, _, _ = o.render(nthreads=8, rows=rows, want_float=False)
-    assert np.array_equal(a.reshape(1080, 1920)[rows[0]:rows[1]], o_rgba.reshape(1080, 1920)[rows[0]:rows[1]])
+    o_rgba, _, o_st = o.render(nthreads=16, want_float=False)
+    assert np.array_equal(a.reshape(1080, 1920), o_rgba.reshape(1080, 1920))
+    assert st["rays_closest"] == o_st["rays_closest"] and st["rays_shadow"] == o_st["rays_shadow"]
     # image-tile shards rendered one after the other on this GPU, gathered and de-tiled = the whole frame
     world = 4
     tx, ty, tpr = C.c_int32(), C.c_int32(), C.c_int32()

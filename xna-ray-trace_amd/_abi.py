@@ -7,7 +7,20 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", os.environ.get("XRT_LIB_VARIANT", "libxrt.so"))   # XRT_LIB_VARIANT: a differently built libxrt (tools/ experiments: make VARIANT=..)
+import re
+
+
+def _lib_name():
+    """XRT_LIB_VARIANT selects a differently built libxrt next to the shipped one (tools/ experiments: `make variant NAME=..`).  Only a bare
+    file name of the form libxrt[_name].so inside csrc/ is accepted: the environment must not be able to make the package load an
+    arbitrary shared object (an absolute path would replace the directory in os.path.join)."""
+    v = os.environ.get("XRT_LIB_VARIANT", "libxrt.so")
+    if not re.fullmatch(r"libxrt(_\w+)?\.so", v):
+        raise ImportError("XRT_LIB_VARIANT=%r: expected libxrt[_name].so (a file inside %s)" % (v, os.path.join(_HERE, "csrc")))
+    return v
+
+
+LIB_PATH = os.path.join(_HERE, "csrc", _lib_name())
 
 XRT_OK = 0
 XRT_E_INVALID_ARG = -1
@@ -141,6 +154,8 @@ def lib():
             fn = getattr(l, name)   # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
+        if l.xrt_version() != XRT_VERSION:
+            raise ImportError("%s is ABI version %d, this binding is %d" % (LIB_PATH, l.xrt_version(), XRT_VERSION))
         _lib = l
     return _lib
 

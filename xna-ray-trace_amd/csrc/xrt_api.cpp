@@ -94,19 +94,62 @@ int guarded(const char *fn, F &&f) {
     catch (...) { return fail(XRT_E_INTERNAL, "%s: unknown exception", fn); }
 }
 
+// XRT_GUARD=1 (read by xrt_scene_create / xrt_scene_load; a test and debugging mode): every device buffer allocated from then on gets
+// GUARD_BYTES of a known pattern behind its last element, and the end of every frame and of every batched query checks that the pattern
+// is intact -- a kernel that writes past an array it was given is then XRT_E_INTERNAL naming the buffer's size, not a corrupted
+// neighbour or a GPU fault somewhere else.  (Round 3 sized the generation-0 arrays by the root box's screen rectangle while one of them
+// was still indexed by path: a process abort in the GPU suite that the next edit hid.  tests/test_gpu_parity.py runs the frame modes
+// under the guards.)
+constexpr size_t GUARD_BYTES = 4096;
+constexpr unsigned char GUARD_PATTERN = 0xA5;
+std::atomic<int> g_guardMode{0};
+struct GuardRegistry {
+    std::mutex m;
+    std::unordered_map<void *, size_t> bytesOf;   // buffer -> payload bytes (the guard follows)
+} g_guards;
+inline int guard_alloc(void **p, size_t bytes) {
+    const bool on = g_guardMode.load() != 0;
+    HIPCHECK(hipMalloc(p, bytes + (on ? GUARD_BYTES : 0)));
+    if (on) {
+        HIPCHECK(hipMemset((char *)*p + bytes, GUARD_PATTERN, GUARD_BYTES));
+        std::lock_guard<std::mutex> lk(g_guards.m);
+        g_guards.bytesOf[*p] = bytes;
+    }
+    return XRT_OK;
+}
+inline void guard_free(void *p) {
+    if (g_guardMode.load() != 0) { std::lock_guard<std::mutex> lk(g_guards.m); g_guards.bytesOf.erase(p); }
+    (void)hipFree(p);
+}
+// All guards of the process (buffers of every scene on the CURRENT device are readable; others are skipped on error).
+int guards_check(const char *where) {
+    if (g_guardMode.load() == 0) return XRT_OK;
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return XRT_OK; }
+    std::lock_guard<std::mutex> lk(g_guards.m);
+    std::vector<unsigned char> tail(GUARD_BYTES);
+    for (const auto &kv : g_guards.bytesOf) {
+        if (hipMemcpy(tail.data(), (const char *)kv.first + kv.second, GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); continue; }
+        for (size_t i = 0; i < GUARD_BYTES; i++)
+            if (tail[i] != GUARD_PATTERN)
+                return fail(XRT_E_INTERNAL, "%s: a kernel wrote %zu bytes past the end of a device buffer of %zu bytes (XRT_GUARD)", where, i + 1, kv.second);
+    }
+    return XRT_OK;
+}
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;   // elements
     int ensure(size_t n) {
         if (n <= cap && p) return XRT_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        if (p) { guard_free(p); p = nullptr; cap = 0; }
         if (n == 0) n = 1;
-        HIPCHECK(hipMalloc((void **)&p, n * sizeof(T)));
+        int rc = guard_alloc((void **)&p, n * sizeof(T));
+        if (rc != XRT_OK) { p = nullptr; return rc; }
         cap = n;
         return XRT_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) guard_free(p); p = nullptr; cap = 0; }
 };
 
 template <class T>
@@ -290,6 +333,7 @@ struct xrt_scene {
     std::vector<hipEvent_t> events;   // xrt_scene_intersect timing
     int firstBatch = 64;
     long long heapRayCap = HEAP_RAY_CAP;         // XRT_HEAP_RAY_CAP=<n> forces small ray buffers (tests of the overflow / retry path)
+    long long shadowBytes = 8LL << 30;   // budget of a frame context's shadow rays / hits / words (XRT_SHADOW_BYTES): many lights shrink the chunk
     long long maxChunkPaths = MAX_CHUNK_PATHS;   // XRT_CHUNK_PATHS=<n> (multiple of 8192) forces smaller chunks (tests of the multi-chunk path)
     float lastFrameMs = 0.0f;    // GPU time of the last finished frame
     float overlapMinMs = 0.05f;  // frames at least this long run on per-context streams
@@ -552,6 +596,13 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // (at most 2^30): many lights shrink the chunk, they are not refused -- until not even 8192 paths fit a generation.
     const long long lightBound = (1LL << 30) / (nL > 0 ? nL : 1);
     if (maxPaths > lightBound) maxPaths = lightBound & ~8191LL;
+    // ... and in bytes: shadow rays, hits and hit / miss words are 84 bytes per path and light in each frame context.  Many lights shrink
+    // the chunk to what XRT_SHADOW_BYTES (default 8 GB per context) holds -- the frame then takes the multi-chunk path -- instead of
+    // failing with XRT_E_OOM (a 1080p frame with 100 lights would want 17 GB).
+    if (nL > 0) {
+        const long long byBytes = ((long long)s->shadowBytes / (84LL * nL)) & ~8191LL;
+        if (byBytes < maxPaths) maxPaths = byBytes < 8192 ? 8192 : byBytes;
+    }
     if (maxPaths < 8192) return fail(XRT_E_UNSUPPORTED, "%d lights: the shadow rays of 8192 paths do not fit one generation (2^30 rays)", nL);
     if (heap) {
         if (maxPaths > (1 << 21)) maxPaths = 1 << 21;   // (a 1080p frame is one chunk when the level records fit 8 GB: MaxReflections <= 6)
@@ -1160,8 +1211,9 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
             }
         }
         if (!F.fast) std::memcpy(F.hcnt, (char *)F.pinned + nb, sizeof(F.hcnt));
-        if (F.fast && F.tallyChunks == 1) {   // sizes of this frame's generations: grid hints for the next one (sizing only)
-            const int *hc = (const int *)F.pinned;
+        // (adaptive frames in flight put the level-count words in front of the per-pass counters and have no framePaths key: no hints from them)
+        if (F.fast && F.tallyChunks == 1 && !F.adaptiveFast) {   // sizes of this frame's generations: grid hints for the next one (sizing only)
+            const int *hc = (const int *)F.pinned + F.cntBase;
             for (int k = 0; k <= R + 1 && k < 68; k++) {
                 const long long closest = (k == 0 || (F.heap && k <= R)) ? hc[k] : (k <= R ? hc[(R + 2) + k - 1] : 0), shaded = k >= 1 ? hc[(R + 2) + k - 1] : 0;
                 // (a hint shrinks by an eighth per frame at most: a camera that looks away for a frame, or alternates between two views,
@@ -1175,8 +1227,8 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
             for (int k = R + 2; k < 68; k++) s->genRays[k] = s->genShade[k] = -1;
             s->genKey = F.framePaths * 64 + F.nL;
         }
-        if (F.fast && s->costMap.p) {   // steer the "long ray" thresholds towards 2-6 % of each generation's rays
-            const int *hc = (const int *)F.pinned;
+        if (F.fast && s->costMap.p && !F.adaptiveFast) {   // steer the "long ray" thresholds towards 2-6 % of each generation's rays
+            const int *hc = (const int *)F.pinned + F.cntBase;
             for (int k = 0; k <= R && k < 66; k++) {
                 const long long rays = k == 0 ? hc[0] : hc[(R + 2) + k - 1], listed = hc[2 * (R + 2) + k];
                 if (rays < 4096) continue;
@@ -1244,7 +1296,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->packetMerge = s->packetMerge; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->shadowBytes = s->shadowBytes; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->packetMerge = s->packetMerge; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1298,7 +1350,7 @@ int multi_begin(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *
     // every device's share is enqueued by its own (persistent) host thread
     std::vector<int> rcs((size_t)n, XRT_OK);
     std::vector<std::string> errs((size_t)n);
-    auto work = [&](int i) {
+    auto work_body = [&](int i) {
         xrt_scene *r = rank_scene(s, i);
         if (hipSetDevice(r->device) != hipSuccess) { rcs[(size_t)i] = XRT_E_HIP; errs[(size_t)i] = "hipSetDevice failed"; return; }
         xrt_render_opts o = *opts;
@@ -1307,9 +1359,23 @@ int multi_begin(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *
         rcs[(size_t)i] = frame_begin(r, r->frames[slot], cam, lights, nLights, &o, dst, nullptr, nullptr, 0, 1, false);   // (the gather is enqueued behind the frame: no redo)
         if (rcs[(size_t)i] != XRT_OK) errs[(size_t)i] = g_err;
     };
-    for (int i = 1; i < n; i++) s->workers[(size_t)i - 1]->post([&work, i] { work(i); });
-    work(0);
-    for (int i = 1; i < n; i++) s->workers[(size_t)i - 1]->wait();
+    // (a rank's job must not throw -- on a worker thread that is std::terminate, on this one it would unwind past workers that still
+    // use the locals above: an exception becomes that rank's error code, and every posted worker is waited for whatever happens)
+    auto work = [&](int i) {
+        try { work_body(i); }
+        catch (const std::bad_alloc &) { rcs[(size_t)i] = XRT_E_OOM; errs[(size_t)i] = "out of host memory"; }
+        catch (const std::exception &e) { rcs[(size_t)i] = XRT_E_INTERNAL; errs[(size_t)i] = e.what(); }
+        catch (...) { rcs[(size_t)i] = XRT_E_INTERNAL; errs[(size_t)i] = "unknown exception"; }
+    };
+    {
+        int posted = 0;
+        struct WaitAll {
+            xrt_scene *s; int &posted;
+            ~WaitAll() { for (int i = 0; i < posted; i++) s->workers[(size_t)i]->wait(); }
+        } waitAll{s, posted};
+        for (int i = 1; i < n; i++) { s->workers[(size_t)i - 1]->post([&work, i] { work(i); }); posted = i; }
+        work(0);
+    }
     // From here on frames are in flight on the ranks: whatever fails, every rank's frame is waited for before the error is
     // reported -- a ticket that was never handed out must not leave a context pending (later renders would be XRT_E_BUSY).
     auto drain = [&]() {
@@ -1387,8 +1453,8 @@ int multi_end(xrt_scene *s, int slot, int n, xrt_stats *stats) {
 // ---- one ticket: frame (on one or n GPUs) -> optional copy into the host's Color[] (RT:122-123) -------------------------
 // d_out: the W*H frame in HBM (or this process's tile shard), or null when the frame is only wanted on the host (the
 // library then keeps it in a buffer of the ticket).  host_out: page-locked or pageable host memory, or null.
-int open_frame(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts, uint32_t *d_out,
-               float *d_outF32, uint32_t *host_out, hipStream_t st) {
+int open_frame_impl(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts, uint32_t *d_out,
+                    float *d_outF32, uint32_t *host_out, hipStream_t st) {
     if (!cam || !opts) return fail(XRT_E_INVALID_ARG, "xrt_render: null argument");
     Range rf("xrt frame (ticket %d)", slot);
     if (opts->n_gpus < 0) return fail(XRT_E_INVALID_ARG, "n_gpus must not be negative");
@@ -1436,7 +1502,7 @@ int open_frame(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *l
     return XRT_OK;
 }
 
-int close_frame(xrt_scene *s, int slot, xrt_stats *stats) {
+int close_frame_impl(xrt_scene *s, int slot, xrt_stats *stats) {
     xrt_scene::OpenFrame &O = s->open[slot];
     int rc = XRT_OK;
     if (O.nGpus > 1) rc = multi_end(s, slot, O.nGpus, stats);
@@ -1466,6 +1532,7 @@ int close_frame(xrt_scene *s, int slot, xrt_stats *stats) {
         if (e != hipSuccess && rc == XRT_OK) rc = fail(XRT_E_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
     }
     O = xrt_scene::OpenFrame();
+    if (rc == XRT_OK) rc = guards_check("end of frame");
     return rc;
 }
 
@@ -1592,6 +1659,15 @@ int scene_upload(xrt_scene *scene) {
 
 }  // namespace
 
+// Every render entry point funnels through these two: no C++ exception (std::bad_alloc from a host-side vector, ...) crosses the C boundary.
+int open_frame(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *lights, int nLights, const xrt_render_opts *opts, uint32_t *d_out,
+               float *d_outF32, uint32_t *host_out, hipStream_t st) {
+    return guarded("xrt_render", [&]() -> int { return open_frame_impl(s, slot, cam, lights, nLights, opts, d_out, d_outF32, host_out, st); });
+}
+int close_frame(xrt_scene *s, int slot, xrt_stats *stats) {
+    return guarded("xrt_render_end", [&]() -> int { return close_frame_impl(s, slot, stats); });
+}
+
 extern "C" {
 
 int xrt_version(void) { return XRT_VERSION; }
@@ -1609,6 +1685,7 @@ int xrt_device_count(int *count_out) {
 int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (!scene_out) return fail(XRT_E_INVALID_ARG, "xrt_scene_create: null argument");
     *scene_out = nullptr;
+    if (const char *e = getenv("XRT_GUARD")) g_guardMode.store(atoi(e) != 0 ? 1 : 0);
     if (device < -1) return fail(XRT_E_INVALID_ARG, "xrt_scene_create: bad device index");
     if (device >= 0) {
         int n = 0;
@@ -1650,6 +1727,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     s->noRectCull = getenv("XRT_NO_RECT_CULL") != nullptr; s->oneStream = getenv("XRT_ONE_STREAM") != nullptr; s->noFeedback = getenv("XRT_NO_FEEDBACK") != nullptr;
     if (const char *e = getenv("XRT_OVERLAP_MS")) s->overlapMinMs = (float)atof(e);   // 0: every single-chunk frame gets its context's stream
     if (const char *e = getenv("XRT_HEAP_RAY_CAP")) { long long v = atoll(e); if (v >= 1024 && v <= HEAP_RAY_CAP) s->heapRayCap = v; }
+    if (const char *e = getenv("XRT_SHADOW_BYTES")) { long long v = atoll(e); if (v >= (1LL << 20)) s->shadowBytes = v; }
     if (const char *e = getenv("XRT_CHUNK_PATHS")) { long long v = atoll(e); if (v >= 8192 && v <= MAX_CHUNK_PATHS && v % 8192 == 0) s->maxChunkPaths = v; }
     if (const char *t = getenv("XRT_TUNE")) {   // "refill,nodeBurst,leafBurst[,coopMax]" — scheduling only, never results
         int v[4] = {0, 0, 0, s->tune[3]};
@@ -1776,7 +1854,7 @@ int xrt_scene_intersect(xrt_scene *scene, const xrt_ray *rays, const int32_t *ig
     if ((rc = run_intersect(scene, scene->apiRays.p, n, scene->apiHits.p, scene->sceneMode, 0, st, stats_out, false))) return rc;
     if (n > 0) HIPCHECK(hipMemcpyAsync(hits_out, scene->apiHits.p, (size_t)n * sizeof(xrt_hit), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
-    return XRT_OK;
+    return guards_check("end of a batched query");
 }
 
 int xrt_scene_intersect_device(xrt_scene *scene, const void *d_rays, int64_t n, void *d_hits_out, void *stream) {
@@ -1800,7 +1878,7 @@ int xrt_mesh_intersect(xrt_scene *scene, int32_t mesh_id, const xrt_ray *rays, i
     if ((rc = run_intersect(scene, scene->apiRays.p, n, scene->apiHits.p, MODE_MESH, mesh_id, st, nullptr, false))) return rc;
     if (n > 0) HIPCHECK(hipMemcpyAsync(hits_out, scene->apiHits.p, (size_t)n * sizeof(xrt_hit), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
-    return XRT_OK;
+    return guards_check("end of a batched query");
 }
 
 int xrt_render(xrt_scene *scene, const xrt_camera *camera, const xrt_light *lights, int32_t n_lights, const xrt_render_opts *opts,
