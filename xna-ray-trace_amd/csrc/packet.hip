@@ -38,7 +38,7 @@
 namespace xrt {
 
 constexpr int PK_LEVELS = 24;        // deeper octrees than this fall back to k_intersect (scene_build limits depth to 20)
-constexpr int PK_FRAME_WORDS = 12;   // blk, next child position, order mask, lanes (2), parent box min (3), half (3), pad
+constexpr int PK_FRAME_WORDS = 4;    // blk, pending children (the first lane's order is found again from the lanes), lanes (2): one 16-byte LDS access
 // a wave's stack: PK_LEVELS frames, then per level one byte per lane -- which children of that level's block the lane's own box tests accepted
 constexpr int PK_STACK_WORDS = PK_LEVELS * (PK_FRAME_WORDS + 16);
 constexpr int PK_SLEVELS = 12;       // scene octree levels a packet can stack (deeper scene trees: k_intersect)
@@ -59,15 +59,59 @@ __device__ unsigned long long g_pkCounters[16];
 #define PKC(i) ((void)0)
 #endif
 
-struct PkUniform {   // wave-uniform cursor
-    int blk, p, dm0;
-    unsigned long long lanes;
-    v3 bmin, half;
-};
-
 struct alignas(4) TriWords { float w[16]; };   // a 13-word record of refT and the first three words of the next one
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float rflf(float v) { return i2f(__builtin_amdgcn_readfirstlane(f2i(v))); }
+
+struct PkUniform {   // wave-uniform cursor
+    int blk, p, dm0;
+    unsigned long long lanes;
+};
+// One block of the walk as it arrives through the scalar cache (SceneView::pblocks, traverse.h PBLOCK_*): the descriptor and the planes of
+// the eight child boxes.  No box is computed in the walk: a wave-uniform float lives in a vector register on gfx950, and deriving the child
+// boxes from the parent's (what the per-lane kernel does instead of loading them) cost a packet ~25 vector instructions per block entered and
+// ~15 per child visited -- all 64 lanes computing the same number.
+struct alignas(16) PkBlockWords { float w[PBLOCK_WORDS]; };
+struct alignas(16) Frame4 { unsigned a, b, c, d; };
+// hit8_fast_children (traverse.h) on the block's stored planes: the reference's test MO:331 for all eight children, bit c <-> child c.
+// Near / far plane of a slab by min / max of its two products -- BoundingBox.Intersects' own `if (t1 > t2) swap` -- instead of a select on
+// the direction's sign (the same two numbers for a ray without NaNs: rounding is monotone), which needed three lane masks in scalar registers.
+__device__ __forceinline__ int pk_hit8_fast(const RayPre &r, const PkBlockWords &B) {
+    const float tx0 = (B.w[8] - r.o.x) * r.inv.x, tx1 = (B.w[9] - r.o.x) * r.inv.x, tx2 = (B.w[10] - r.o.x) * r.inv.x;
+    const float ty0 = (B.w[12] - r.o.y) * r.inv.y, ty1 = (B.w[13] - r.o.y) * r.inv.y, ty2 = (B.w[14] - r.o.y) * r.inv.y;
+    const float tz0 = (B.w[16] - r.o.z) * r.inv.z, tz1 = (B.w[17] - r.o.z) * r.inv.z, tz2 = (B.w[18] - r.o.z) * r.inv.z;
+    const float nearX[2] = {fminf(tx0, tx1), fminf(tx1, tx2)}, farX[2] = {fmaxf(tx0, tx1), fmaxf(tx1, tx2)};
+    const float nearY[2] = {fminf(ty0, ty1), fminf(ty1, ty2)}, farY[2] = {fmaxf(ty0, ty1), fmaxf(ty1, ty2)};
+    const float nearZ[2] = {fminf(tz0, tz1), fminf(tz1, tz2)}, farZ[2] = {fmaxf(tz0, tz1), fmaxf(tz1, tz2)};
+    int m = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int i = (c >> 2) & 1, j = (c >> 1) & 1, k = c & 1;
+        const float num = fmaxf(fmaxf(fmaxf(nearX[i], nearY[j]), 0.0f), nearZ[k]);
+        const float num2 = fminf(fminf(fminf(farX[i], farY[j]), FLT_MAX), farZ[k]);
+        if (!(num > num2)) m |= 1 << c;
+    }
+    return m;
+}
+// The box of child c as child_box (traverse.h) forms it, read from the planes (c is wave-uniform: scalar selects).
+__device__ __forceinline__ void pk_child_box(const PkBlockWords &B, int c, v3 &cmin, v3 &cmax) {
+    // (selected as integers: a select between two wave-uniform floats is compiled as a vector select)
+    auto pick = [](int bit, float hi, float lo) { return i2f(rfl(bit ? f2i(hi) : f2i(lo))); };
+    cmin = mk(pick(c & 4, B.w[9], B.w[8]), pick(c & 2, B.w[13], B.w[12]), pick(c & 1, B.w[17], B.w[16]));
+    cmax = mk(pick(c & 4, B.w[10], B.w[11]), pick(c & 2, B.w[14], B.w[15]), pick(c & 1, B.w[18], B.w[19]));
+}
+// The same decisions with the literal box test (a ray with a parallel axis or a non-finite component, MO:331).
+__device__ __forceinline__ int pk_hit8_slow(const RayPre &r, const PkBlockWords &B) {
+    int m = 0;
+    for (int c = 0; c < 8; c++) {
+        v3 cmin, cmax;
+        pk_child_box(B, c, cmin, cmax);
+        float key;
+        if (slab(r, cmin.x, cmin.y, cmin.z, cmax.x, cmax.y, cmax.z, key)) m |= 1 << c;
+    }
+    return m;
+}
+
 
 // The triangle test of a packet, shaped for the SCALAR unit: every `if` on a per-lane condition costs the wave two or three scalar
 // instructions and a branch whether or not a lane takes it (the nested early rejections of xrt_core.h tri_stage_a / tri_stage_b and
@@ -162,12 +206,14 @@ __device__ __forceinline__ void pk_scan_leaf(const float *__restrict__ refT, int
     }
 }
 
-// One shared walk of the mesh octree whose root block is `rootBlock` (parent box rmin .. rmax) for the lanes `lanes0`: the lanes
-// whose ray passed the root's own box test (MO:265 / MO:331).  On return every lane's L.mfound / mKey / mDist / mU / mV / mRef /
-// mLeaf hold its answer of MeshOctree.GetRayIntersection (the caller cleared mfound).
-__device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const float *__restrict__ refT, const f4 *__restrict__ leafNB,
-                                        const f4 *__restrict__ leafTB, const int *__restrict__ runBase, const f4 *__restrict__ runTB, const SceneView &S, int cullMin, unsigned *stk, int lane, Lane &L,
-                                        const RayCull &RC, bool fastL, int rootBlock, v3 rmin, v3 rmax, unsigned long long lanes0) {
+// One shared walk of the mesh octree whose root block is `rootBlock` for the lanes `lanes0`: the lanes whose ray passed the root's own
+// box test (MO:265 / MO:331).  On return every lane's L.mfound / mKey / mDist / mU / mV / mRef / mLeaf hold its answer of
+// MeshOctree.GetRayIntersection (the caller cleared mfound).  Everything the walk reads comes from three arrays -- pblocks (descriptor +
+// child planes per block), lrec (per node: normal box, tight box, first run; the run records behind them), refT (triangles) --: three base
+// pointers in scalar registers where round 3 held six, no parent box, no child box arithmetic.
+__device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const float *__restrict__ refT, const float *__restrict__ lrec,
+                                        const SceneView &S, int cullMin, unsigned *stk, int lane, Lane &L,
+                                        const RayCull &RC, bool fastL, int rootBlock, unsigned long long lanes0) {
 #ifdef XRT_PK_COUNTERS
     unsigned pkc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     pkc[0] = 1;
@@ -175,15 +221,12 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
 #endif
     PkUniform U;
     U.blk = rootBlock;
-    U.bmin = rmin;
-    U.half = half_of(rmin, rmax);
     U.lanes = lanes0;
     U.p = 0; U.dm0 = 0;
     unsigned char *const cbOf = reinterpret_cast<unsigned char *>(stk + PK_LEVELS * PK_FRAME_WORDS) + lane;   // [level * 64]: this lane's byte
     int sp = 0;
     bool entering = true, anyFound = false;   // anyFound: some lane of the wave has a candidate
-    int d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-    unsigned long long offLo = 0, offHi = 0;
+    PkBlockWords B;
     int cb = 0;
     // The scalar unit is shared by the CU's four SIMDs, so scalar instructions are the scarce resource of this kernel
     // (measured: 3,900 per packet against 4,000 vector ones made it scalar-bound): the pending children are a bit mask
@@ -192,13 +235,10 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
         const bool in = ((U.lanes >> lane) & 1ull) != 0;
         if (entering) {
             PKC(1);
-            const f4 lo = blocks[2 * (size_t)U.blk], hi = blocks[2 * (size_t)U.blk + 1];
-            d0 = f2i(lo.x); d1 = f2i(lo.y); d2 = f2i(lo.z); d3 = f2i(lo.w);
-            offLo = (unsigned long long)(unsigned)f2i(hi.x) | ((unsigned long long)(unsigned)f2i(hi.y) << 32);
-            offHi = (unsigned long long)(unsigned)f2i(hi.z) | ((unsigned long long)(unsigned)f2i(hi.w) << 32);
+            B = *reinterpret_cast<const PkBlockWords *>(pblocks + (size_t)U.blk * PBLOCK_WORDS);
             cb = 0;
-            if (in) cb = fastL ? hit8_fast_children(L.r, L.dmask, U.bmin, U.half) : hit8_slow_children(L.r, U.bmin, U.half);
-            cb &= 0xff & ~((d2 >> 8) & 0xff);   // empty leaves can never hit (Q4)
+            if (in) cb = fastL ? pk_hit8_fast(L.r, B) : pk_hit8_slow(L.r, B);
+            cb &= 0xff & ~((f2i(B.w[2]) >> 8) & 0xff);   // empty leaves can never hit (Q4)
             U.dm0 = __builtin_amdgcn_readlane(L.dmask, (int)__builtin_ctzll(U.lanes));   // front-to-back order of the first lane
             // children some lane entered, in that order: bit p <-> child (p ^ dm0).  The xor moves a bit by 4, 2 and 1 places; each lane
             // moves its own bits (vector shifts by wave-uniform amounts: 0 leaves the byte as it is) before the wave's OR, which costs the
@@ -215,15 +255,11 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
             if (sp == 0) break;
             sp--;
             PKC(10);
-            const unsigned *f = stk + sp * PK_FRAME_WORDS;
-            U.blk = rfl((int)f[0]); U.p = rfl((int)f[1]); U.dm0 = rfl((int)f[2]);
-            U.lanes = (unsigned long long)(unsigned)rfl((int)f[3]) | ((unsigned long long)(unsigned)rfl((int)f[4]) << 32);
-            U.bmin = mk(rflf(i2f((int)f[5])), rflf(i2f((int)f[6])), rflf(i2f((int)f[7])));
-            U.half = mk(rflf(i2f((int)f[8])), rflf(i2f((int)f[9])), rflf(i2f((int)f[10])));
-            const f4 lo = blocks[2 * (size_t)U.blk], hi = blocks[2 * (size_t)U.blk + 1];
-            d0 = f2i(lo.x); d1 = f2i(lo.y); d2 = f2i(lo.z); d3 = f2i(lo.w);
-            offLo = (unsigned long long)(unsigned)f2i(hi.x) | ((unsigned long long)(unsigned)f2i(hi.y) << 32);
-            offHi = (unsigned long long)(unsigned)f2i(hi.z) | ((unsigned long long)(unsigned)f2i(hi.w) << 32);
+            const Frame4 f = *reinterpret_cast<const Frame4 *>(stk + sp * PK_FRAME_WORDS);
+            U.blk = rfl((int)f.a); U.p = rfl((int)f.b);
+            U.lanes = (unsigned long long)(unsigned)rfl((int)f.c) | ((unsigned long long)(unsigned)rfl((int)f.d) << 32);
+            U.dm0 = __builtin_amdgcn_readlane(L.dmask, (int)__builtin_ctzll(U.lanes));   // (the order the pending bits of this level were made in)
+            B = *reinterpret_cast<const PkBlockWords *>(pblocks + (size_t)U.blk * PBLOCK_WORDS);
             cb = (int)cbOf[sp * 64];
             continue;
         }
@@ -231,12 +267,13 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
         U.p &= U.p - 1;
         PKC(2);
         const bool inC = in && ((cb >> c) & 1);
-        v3 cmin, cmax;
-        child_box(U.bmin, U.half, c, cmin, cmax);
+        const int d0 = f2i(B.w[0]), d1 = f2i(B.w[1]), d2 = f2i(B.w[2]), d3 = f2i(B.w[3]);
         // The child's own test gives the entry key (its outcome is known: hit).  The bucket rule compares keys only once a lane
         // has a candidate; until some lane of the wave has one (most of a packet's walk) the key of a leaf is computed by the
         // lanes that find a candidate in it, and nobody computes the key of an interior child.
         auto entry_key = [&]() {
+            v3 cmin, cmax;
+            pk_child_box(B, c, cmin, cmax);
             float k = 0.0f;
             if (fastL) (void)slab_fast(L.r, L.dmask, cmin, cmax, k);
             else (void)slab(L.r, cmin.x, cmin.y, cmin.z, cmax.x, cmax.y, cmax.z, k);
@@ -252,30 +289,32 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
         const int node = U.blk * 8 + c;
         if (!((d2 >> c) & 1)) {   // ---- leaf (non-empty): MO:288-304 for the lanes the bucket rule lets in ----
             PKC(3);
-            const f4 nlo = leafNB[2 * (size_t)node], nhi = leafNB[2 * (size_t)node + 1];
+            const f4 *const nr = reinterpret_cast<const f4 *>(lrec + (size_t)node * LREC_WORDS);
+            const f4 nlo = nr[0], nhi = nr[1];
             bool go = inC & !all_back_facing(nlo, nhi, L.r.d);
             if (keyed) go = go & !((L.mfound != 0) & (key > L.mKey));   // (wave-uniform branch: nobody has a candidate before `keyed`)
             if (!__any(go)) continue;
             PKC(4);
+            const unsigned long long offLo = (unsigned long long)(unsigned)f2i(B.w[4]) | ((unsigned long long)(unsigned)f2i(B.w[5]) << 32);
+            const unsigned long long offHi = (unsigned long long)(unsigned)f2i(B.w[6]) | ((unsigned long long)(unsigned)f2i(B.w[7]) << 32);
             const int r0 = d1 + child_ref_offset(offLo, offHi, c);
             const int r1 = d1 + ((c == 7) ? d3 : child_ref_offset(offLo, offHi, c + 1));
             if (r1 - r0 >= cullMin) {   // lanes whose ray cannot reach any triangle of the leaf (xrt_core.h leaf_certainly_missed) stay out of it
-                const f4 *tb = leafTB + 4 * (size_t)node;
-                go = go && !leaf_certainly_missed(L.r, RC, tb[0], tb[1], tb[2], tb[3]);
+                go = go && !leaf_certainly_missed(L.r, RC, nr[2], nr[3], nr[4], nr[5]);
                 if (!__any(go)) continue;
             }
             PKC(5);
-            // A leaf of LEAF_RUN_MIN references or more is scanned run by run (LEAF_RUN references each, SceneView::runTB): every run has a
+            // A leaf of LEAF_RUN_MIN references or more is scanned run by run (LEAF_RUN references each): every run has a
             // tight box of its own and a run no lane can reach is passed over -- the octree stops splitting at 50 triangles (MO:42) and a
             // coherent packet comes near only a few of them.  Smaller leaves are one run.
             int nRuns = 1, rb = -1;
-            if (r1 - r0 >= LEAF_RUN_MIN) { rb = runBase[node]; if (rb >= 0) nRuns = (r1 - r0 + LEAF_RUN - 1) / LEAF_RUN; }
+            if (r1 - r0 >= LEAF_RUN_MIN) { rb = f2i(lrec[(size_t)node * LREC_WORDS + 24]); if (rb >= 0) nRuns = (r1 - r0 + LEAF_RUN - 1) / LEAF_RUN; }
             for (int jr = 0; jr < nRuns; jr++) {
                 int ra = r0, rz = r1;
                 bool goR = go;
                 if (rb >= 0) {
                     ra = r0 + LEAF_RUN * jr; rz = min(ra + LEAF_RUN, r1);
-                    const f4 *tb = runTB + 4 * (size_t)(rb + jr);
+                    const f4 *tb = reinterpret_cast<const f4 *>(lrec + (size_t)rb + (size_t)jr * RUN_WORDS);
                     PKC(6);
                     goR = go && !leaf_certainly_missed(L.r, RC, tb[0], tb[1], tb[2], tb[3]);
                     if (!__any(goR)) continue;
@@ -323,20 +362,13 @@ __device__ __forceinline__ void pk_walk(const f4 *__restrict__ blocks, const flo
         if (sp >= PK_LEVELS - 1) continue;   // (cannot happen: packet_supported checks the depth)
         if (U.p != 0) {   // something is left to do at this level: come back
             cbOf[sp * 64] = (unsigned char)cb;   // (every lane: its own accepted children of this level's block)
-            if (lane == 0) {
-                unsigned *f = stk + sp * PK_FRAME_WORDS;
-                f[0] = (unsigned)U.blk; f[1] = (unsigned)U.p; f[2] = (unsigned)U.dm0;
-                f[3] = (unsigned)U.lanes; f[4] = (unsigned)(U.lanes >> 32);
-                f[5] = (unsigned)f2i(U.bmin.x); f[6] = (unsigned)f2i(U.bmin.y); f[7] = (unsigned)f2i(U.bmin.z);
-                f[8] = (unsigned)f2i(U.half.x); f[9] = (unsigned)f2i(U.half.y); f[10] = (unsigned)f2i(U.half.z);
-            }
+            if (lane == 0) *reinterpret_cast<Frame4 *>(stk + sp * PK_FRAME_WORDS) = Frame4{(unsigned)U.blk, (unsigned)U.p, (unsigned)U.lanes, (unsigned)(U.lanes >> 32)};
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             sp++;
         }
         U.blk = d0 + __builtin_popcount((unsigned)(d2 & 0xff) & ((1u << c) - 1u));
-        U.bmin = cmin; U.half = half_of(cmin, cmax);
         U.lanes = LL;
         entering = true;
     }
@@ -373,9 +405,8 @@ template <int M> __device__ __forceinline__ unsigned *scene_frames() {
 #define PK_SCENE_WAVES 5   // waves per SIMD the scene variant is compiled for: 96 VGPRs + 44 bytes of scratch per lane, touched per packet (not per step): C3 -5 %, C4 -7.5 % against 4 waves at 106 VGPRs (profiles/r03/packet_scene_five_waves.txt; at 111 VGPRs the same switch lost)
 #endif
 template <int M>
-__global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k_packet(const f4 *__restrict__ blocks, const float *__restrict__ refT,
-                                                const f4 *__restrict__ leafNB, const f4 *__restrict__ leafTB, const int *__restrict__ runBase,
-                                                const f4 *__restrict__ runTB, const MeshRec *__restrict__ meshes,
+__global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k_packet(const float *__restrict__ pblocks, const float *__restrict__ refT,
+                                                const float *__restrict__ lrec, const MeshRec *__restrict__ meshes,
                                                 const f4 *__restrict__ snodes, const f4 *__restrict__ scull, const ObjRec *__restrict__ objects,
                                                 const int *__restrict__ objMesh, SceneView S, PacketArgs A) {
     __shared__ unsigned frames[4 * PK_STACK_WORDS];
@@ -476,8 +507,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
             // the lanes inside the root box of an interior root (MO:265; lane_begin left them in ST_NODE with mask 1 -- a root that is a
             // leaf is k_intersect's business: packet_supported)
             const unsigned long long lanes0 = mr.rootBlock < 0 ? 0ull : __ballot(valid && L.state == ST_NODE && L.mask != 0);
-            pk_walk(blocks, refT, leafNB, leafTB, runBase, runTB, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]),
-                    mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]), lanes0);
+            pk_walk(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, lanes0);
             L.mesh = mesh;
             if (valid) {
                 const HitOut h = lane_result(L, C, S, M);
@@ -597,8 +627,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
                             } else {
                                 const unsigned long long lanes0 = __ballot(inRoot);
                                 if (lanes0 != 0ull)
-                                    pk_walk(blocks, refT, leafNB, leafTB, runBase, runTB, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]),
-                                            mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]), lanes0);
+                                    pk_walk(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, lanes0);
                             }
                             if (L.mfound) {   // OSM:370-378
                                 L.mesh = m; C.obj = o;
@@ -648,11 +677,11 @@ extern "C" int xrt_debug_packet_counters(unsigned long long *out16, int reset) {
 void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     dim3 g((unsigned)gridBlocks), b(256);
     if (A.mode == MODE_MESH)
-        hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.runBase, S.runTB, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
+        hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.pblocks, S.refT, S.lrec, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
     else if (A.mode == MODE_SCENE)
-        hipExtLaunchKernelGGL((k_packet<MODE_SCENE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.runBase, S.runTB, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
+        hipExtLaunchKernelGGL((k_packet<MODE_SCENE>), g, b, 0, st, e0, e1, 0, S.pblocks, S.refT, S.lrec, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
     else
-        hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.blocks, S.refT, S.leafNB, S.leafTB, S.runBase, S.runTB, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
+        hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.pblocks, S.refT, S.lrec, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
 }
 
 }  // namespace xrt

@@ -8,7 +8,7 @@
 namespace xrt {
 
 size_t SceneArrays::bytes() const {
-    return (blocks.size() + refN.size() + snodes.size() + shade.size() + leafNB.size() + leafTB.size() + scull.size() + runTB.size()) * sizeof(f4) + refT.size() * sizeof(float) + refG.size() * sizeof(g3) +
+    return (blocks.size() + refN.size() + snodes.size() + shade.size() + leafNB.size() + leafTB.size() + scull.size() + runTB.size()) * sizeof(f4) + (refT.size() + pblocks.size() + lrec.size()) * sizeof(float) + refG.size() * sizeof(g3) +
            (childDfs.size() + srefs.size() + objMesh.size() + runBase.size()) * sizeof(int) + meshes.size() * sizeof(MeshRec) +
            objects.size() * sizeof(ObjRec) + materials.size() * sizeof(MaterialRec) + texels.size() * sizeof(uint32_t);
 }
@@ -205,6 +205,34 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
             A.blocks.push_back(lo); A.blocks.push_back(hi);
         }
         A.childDfs.insert(A.childDfs.end(), t.childDfs.begin(), t.childDfs.end());
+        // the packet kernel's block records: descriptor + child planes (traverse.h PBLOCK_*), boxes derived from the root box exactly as the
+        // builder and the per-lane kernel derive them (child_box / half_of: the same inline functions, compiled without contraction)
+        A.pblocks.resize((size_t)(blockBase + t.blocks.size() / 2) * PBLOCK_WORDS, 0.0f);
+        if (!t.blocks.empty()) {
+            struct Todo { int lb; v3 bmin, half; };
+            std::vector<Todo> todo;
+            const v3 rmn = mk(t.rootBox[0], t.rootBox[1], t.rootBox[2]);
+            todo.push_back(Todo{0, rmn, half_of(rmn, mk(t.rootBox[3], t.rootBox[4], t.rootBox[5]))});   // (local block 0 = the root's children)
+            while (!todo.empty()) {
+                const Todo w = todo.back();
+                todo.pop_back();
+                const f4 lo = A.blocks[2 * (size_t)(blockBase + w.lb)], hi = A.blocks[2 * (size_t)(blockBase + w.lb) + 1];
+                float *q = &A.pblocks[(size_t)(blockBase + w.lb) * PBLOCK_WORDS];
+                q[0] = lo.x; q[1] = lo.y; q[2] = lo.z; q[3] = lo.w; q[4] = hi.x; q[5] = hi.y; q[6] = hi.z; q[7] = hi.w;
+                const float bm[3] = {w.bmin.x, w.bmin.y, w.bmin.z}, hf[3] = {w.half.x, w.half.y, w.half.z};
+                for (int ax = 0; ax < 3; ax++) {
+                    const float p0 = bm[ax] + hf[ax] * 0.0f, p1 = bm[ax] + hf[ax] * 1.0f, p2 = p1 + hf[ax], hp0 = p0 + hf[ax];
+                    q[8 + 4 * ax] = p0; q[9 + 4 * ax] = p1; q[10 + 4 * ax] = p2; q[11 + 4 * ax] = hp0;
+                }
+                const int childBase = f2i(t.blocks[2 * (size_t)w.lb].x), interior = f2i(lo.z) & 0xff;
+                for (int c = 0; c < 8; c++)
+                    if ((interior >> c) & 1) {
+                        v3 cmin, cmax;
+                        child_box(w.bmin, w.half, c, cmin, cmax);
+                        todo.push_back(Todo{childBase + __builtin_popcount((unsigned)interior & ((1u << c) - 1u)), cmin, half_of(cmin, cmax)});
+                    }
+            }
+        }
         // per leaf: bounds of its triangles' surface normals, so a leaf whose triangles all face away from a ray
         // (RE:48-51 would reject every one of them) can be skipped without reading its references
         for (size_t bi = 0; bi < t.blocks.size() / 2; bi++) {
@@ -334,6 +362,18 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
     if (A.runBase.empty()) A.runBase.assign(8, -1);
     for (int k = 0; k < 8; k++) A.runTB.push_back(f4{0, 0, 0, 0});   // (padding: the packet kernel may request the record after a leaf's last run)
     if (A.childDfs.empty()) A.childDfs.assign(8, -1);
+    if (A.pblocks.empty()) A.pblocks.assign(PBLOCK_WORDS, 0.0f);
+    {   // the packet kernel's node records (traverse.h LREC_*): leafNB | leafTB | first run, the run records behind them
+        const size_t nNodes = A.runBase.size(), nRuns = A.runTB.size() / 4;   // (runTB ends in two records of padding)
+        A.lrec.assign(nNodes * LREC_WORDS + nRuns * RUN_WORDS, 0.0f);
+        for (size_t nd = 0; nd < nNodes; nd++) {
+            float *q = &A.lrec[nd * LREC_WORDS];
+            std::memcpy(q, &A.leafNB[2 * nd], 8 * sizeof(float));
+            std::memcpy(q + 8, &A.leafTB[4 * nd], 16 * sizeof(float));
+            q[24] = i2f(A.runBase[nd] < 0 ? -1 : (int)(nNodes * LREC_WORDS + (size_t)A.runBase[nd] * RUN_WORDS));
+        }
+        if (nRuns) std::memcpy(&A.lrec[nNodes * LREC_WORDS], A.runTB.data(), nRuns * RUN_WORDS * sizeof(float));
+    }
     built = true;
     return true;
 }
@@ -446,7 +486,7 @@ bool HostScene::load(const char *path, std::string &err) {
 SceneView HostScene::host_view() const {
     SceneView S;
     const SceneArrays &A = arrays;
-    S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data(); S.leafNB = A.leafNB.data(); S.leafTB = A.leafTB.data(); S.runBase = A.runBase.data(); S.runTB = A.runTB.data(); S.refT = A.refT.data();
+    S.blocks = A.blocks.data(); S.childDfs = A.childDfs.data(); S.leafNB = A.leafNB.data(); S.leafTB = A.leafTB.data(); S.runBase = A.runBase.data(); S.runTB = A.runTB.data(); S.refT = A.refT.data(); S.pblocks = A.pblocks.data(); S.lrec = A.lrec.data();
     S.refN = A.refN.data(); S.refG = A.refG.data(); S.meshes = A.meshes.data();
     S.snodes = A.snodes.data(); S.srefs = A.srefs.data(); S.scull = A.scull.data(); S.objects = A.objects.data(); S.objMesh = A.objMesh.data();
     S.nMeshes = (int)meshes.size(); S.nObjects = (int)objects.size();

@@ -22,6 +22,9 @@ struct SceneArrays {
     std::vector<f4> scull;                                 // 4 per scene leaf reference (traverse.h SceneView::scull)
     std::vector<f4> leafTB;                                // 4 per node: the leaf's tight box (xrt_core.h leaf_certainly_missed)
     std::vector<g3> refG;
+    // The wave-packet kernel's copies (packet.hip: everything it walks arrives through scalar loads from THREE arrays -- pblocks, lrec, refT):
+    std::vector<float> pblocks;                            // PBLOCK_WORDS per block: descriptor (8 words of `blocks`) + the planes of its eight children (traverse.h PBLOCK_*)
+    std::vector<float> lrec;                               // LREC_WORDS per node (leafNB, leafTB, first run), then RUN_WORDS per run (runTB): traverse.h LREC_*
     std::vector<int> childDfs, srefs, objMesh;
     std::vector<MeshRec> meshes;
     std::vector<ObjRec> objects;

@@ -27,6 +27,8 @@ struct SceneView {
     const f4 *refN;         // per leaf reference: (surfaceNormal.xyz, global triangle id)
     const g3 *refG;         // 3 per leaf reference: v1, E1, E2
     const float *refT;      // the same two streams as one record of TRI_REC_WORDS words per reference (k_packet's scalar loads)
+    const float *pblocks;   // k_packet: PBLOCK_WORDS per block -- the descriptor and the child planes (below)
+    const float *lrec;      // k_packet: LREC_WORDS per node (leafNB | leafTB | first run's word offset), the run records behind them
     const MeshRec *meshes;
     const f4 *snodes;       // scene octree, 2 per record
     const int *srefs;       // object id per scene leaf reference
@@ -37,6 +39,21 @@ struct SceneView {
     int nMeshes, nObjects;
     int sceneDepth, meshDepth;   // stack capacities needed
 };
+
+// k_packet's block record (SceneView::pblocks), PBLOCK_WORDS floats per block:
+//   [0..7]   the block descriptor (the two f4 of `blocks`)
+//   [8..11]  x0, x1, x2, hx0   [12..15] y0, y1, y2, hy0   [16..19] z0, z1, z2, hz0
+// the planes of the eight children of the node whose own box is (bmin, half), evaluated on the host with the builder's binary32
+// operations (MO:207, 217-218): p0 = bmin + half * 0f, p1 = bmin + half * 1f, p2 = p1 + half (what hit8_* forms: child bit b spans planes
+// b .. b+1) and hp0 = p0 + half, the far plane of child bit 0 as child_box forms it (== p1 for finite boxes).  With them a block costs the
+// walk no box arithmetic at all: where the per-lane kernel recomputes a child's box from its parent's (ALU instead of memory, one lane
+// one walk), the packet's box is wave-uniform, and a wave-uniform float lives in a VECTOR register on gfx950 (no scalar float ALU): the
+// implicit boxes cost a packet ~25 vector instructions per block entered and ~15 per child visited, all 64 lanes computing one number.
+constexpr int PBLOCK_WORDS = 20;
+// k_packet's node record (SceneView::lrec), LREC_WORDS floats per node (= block * 8 + child):
+//   [0..7] leafNB (2 f4)   [8..23] leafTB (4 f4)   [24] word offset of the leaf's first run record in lrec, or -1   [25..31] -
+// and behind the node records RUN_WORDS floats per run (runTB), then one run of padding.
+constexpr int LREC_WORDS = 32, RUN_WORDS = 16;
 
 enum : int { ST_IDLE = 0, ST_SCENE = 1, ST_NODE = 2, ST_LEAF = 3, ST_FINISH = 4 };
 // MODE_SINGLE: a scene of one SceneObject with one Mesh (C1, C2, C5): the scene-level walk collapses into

@@ -206,7 +206,7 @@ struct xrt_scene {
     const HostScene *host = &hs;   // what the frame code reads; a replica on another device points at its primary's
     // HBM-resident scene
     DevBuf<f4> blocks, refN, snodes, shade, leafNB, leafTB, scull, runTB;
-    DevBuf<float> refT;
+    DevBuf<float> refT, pblocks, lrec;
     DevBuf<g3> refG;
     DevBuf<int> childDfs, srefs, objMesh, runBase;
     DevBuf<MeshRec> meshes;
@@ -395,7 +395,7 @@ struct xrt_scene {
             }
             if (stream) (void)hipStreamDestroy(stream);
             blocks.release(); leafNB.release(); leafTB.release(); refT.release(); refN.release(); refG.release(); snodes.release(); shade.release();
-            childDfs.release(); srefs.release(); scull.release(); runTB.release(); runBase.release(); objMesh.release(); meshes.release();
+            childDfs.release(); srefs.release(); scull.release(); runTB.release(); runBase.release(); pblocks.release(); lrec.release(); objMesh.release(); meshes.release();
             objects.release(); materials.release(); texels.release();
             apiRays.release(); apiHits.release();
 
@@ -1606,14 +1606,14 @@ int scene_upload(xrt_scene *scene) {
     if (scene->device < 0) return XRT_OK;   // host-only scene: trees can be inspected, nothing can be traced
     HIPCHECK(hipSetDevice(scene->device));
     int rc;
-    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->leafNB, A.leafNB)) || (rc = upload(scene->leafTB, A.leafTB)) || (rc = upload(scene->refT, A.refT)) || (rc = upload(scene->refN, A.refN)) || (rc = upload(scene->refG, A.refG)) ||
+    if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->leafNB, A.leafNB)) || (rc = upload(scene->leafTB, A.leafTB)) || (rc = upload(scene->refT, A.refT)) || (rc = upload(scene->pblocks, A.pblocks)) || (rc = upload(scene->lrec, A.lrec)) || (rc = upload(scene->refN, A.refN)) || (rc = upload(scene->refG, A.refG)) ||
         (rc = upload(scene->snodes, A.snodes)) || (rc = upload(scene->shade, A.shade)) || (rc = upload(scene->childDfs, A.childDfs)) ||
         (rc = upload(scene->srefs, A.srefs)) || (rc = upload(scene->scull, A.scull)) || (rc = upload(scene->runTB, A.runTB)) || (rc = upload(scene->runBase, A.runBase)) || (rc = upload(scene->objMesh, A.objMesh)) ||
         (rc = upload(scene->meshes, A.meshes)) || (rc = upload(scene->objects, A.objects)) || (rc = upload(scene->materials, A.materials)) ||
         (rc = upload(scene->texels, A.texels)))
         return rc;
     SceneView &S = scene->view;
-    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.leafNB = scene->leafNB.p; S.leafTB = scene->leafTB.p; S.refT = scene->refT.p; S.refN = scene->refN.p; S.refG = scene->refG.p;
+    S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.leafNB = scene->leafNB.p; S.leafTB = scene->leafTB.p; S.refT = scene->refT.p; S.pblocks = scene->pblocks.p; S.lrec = scene->lrec.p; S.refN = scene->refN.p; S.refG = scene->refG.p;
     S.meshes = scene->meshes.p; S.snodes = scene->snodes.p; S.srefs = scene->srefs.p; S.scull = scene->scull.p; S.runTB = scene->runTB.p; S.runBase = scene->runBase.p;
     S.objects = scene->objects.p; S.objMesh = scene->objMesh.p;
     S.nMeshes = (int)scene->host->meshes.size(); S.nObjects = (int)scene->host->objects.size();
