@@ -386,6 +386,10 @@ def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_fra
     out = {"bound": bound, "kernel": "traversal launches of a frame: k_packet (wave-packet form, coherent rays) + k_intersect (per-lane form)",
            "achieved": top["achieved"] if top else None, "peak": top["peak"] if top else None, "unit": top["unit"] if top else None,
            "frac": (top["issue_frac"] if bound in ("valu", "salu", "branch", "smem") else top["frac"]) if top else None,
+           # (what a reader of this block alone must see beside `frac`: the share of the VALU peak that did useful lane work -- issue slots x lane
+           # utilisation --, and, set by the caller, the rate of the queries that really reach the traversal kernels)
+           "useful_frac": fr["valu"]["frac"] if "valu" in fr else None, "lane_utilisation": fr["valu"]["lane_utilisation"] if "valu" in fr else None,
+           "traversed_value": None,
            "traffic": traffic, "ms_per_launch": round(ms_per_launch, 5), "launches_per_frame": launches_per_frame, "fractions": fr,
            "pmc_build_id": build_id() if pmc else None,
            "note": "branchy scalar fp32 traversal, scene resident in the 256 MiB Infinity Cache: not HBM-bound. `frac` is the largest PHYSICAL fraction -- "
@@ -492,6 +496,7 @@ def main():
             "Mrays_per_s_traversed": round(trav_frame * args.steps / seconds / 1e6, 3),
             "roofline": roofline_block(args.config if (world == 1 and not in_library) else "(N > 1: no PMC pass)", bytes_per_launch, ms_per_launch, launches // max(args.steps, 1), serial),
         }
+        line["roofline"]["traversed_value"] = line["Mrays_per_s_traversed"]   # Mrays/s of the queries that reach the traversal kernels (`value` counts the primary rays k_raygen answers too)
         solo = world == 1 and not in_library   # the side measurements below are single-GPU figures
         if solo and not args.no_host and args.scale == 1.0:
             try:

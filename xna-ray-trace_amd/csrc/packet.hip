@@ -213,7 +213,7 @@ __device__ __forceinline__ void pk_scan_leaf(const float *__restrict__ refT, int
 // pointers in scalar registers where round 3 held six, no parent box, no child box arithmetic.
 __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const float *__restrict__ refT, const float *__restrict__ lrec,
                                         const SceneView &S, int cullMin, unsigned *stk, int lane, Lane &L,
-                                        const RayCull &RC, bool fastL, int rootBlock, unsigned long long lanes0) {
+                                        const RayCull &RC, bool fastL, int rootBlock, unsigned long long lanes0, bool nodeCull) {
 #ifdef XRT_PK_COUNTERS
     unsigned pkc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     pkc[0] = 1;
@@ -357,6 +357,11 @@ __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const
         // ---- interior child: a lane prunes it by key only where that is a proven lower bound (safe bit) ----
         bool go = inC;
         if (keyed && ((d2 >> (16 + c)) & 1)) go = go & !((L.mfound != 0) & (key > L.mKey));   // (wave-uniform branch)
+        if (nodeCull) {   // (wave-uniform) a subtree whose triangles all face away from a lane's ray (RE:48-51 rejects each one) is not entered by that lane
+            const f4 *const nr = reinterpret_cast<const f4 *>(lrec + (size_t)node * LREC_WORDS);
+            go = go && !all_back_facing(nr[0], nr[1], L.r.d);
+            PKC(9);
+        }
         const unsigned long long LL = __ballot(go);
         if (LL == 0ull) continue;
         if (sp >= PK_LEVELS - 1) continue;   // (cannot happen: packet_supported checks the depth)
@@ -506,8 +511,11 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
             const bool fastL = L.r.par == 0 && L.weird == 0;
             // the lanes inside the root box of an interior root (MO:265; lane_begin left them in ST_NODE with mask 1 -- a root that is a
             // leaf is k_intersect's business: packet_supported)
-            const unsigned long long lanes0 = mr.rootBlock < 0 ? 0ull : __ballot(valid && L.state == ST_NODE && L.mask != 0);
-            pk_walk(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, lanes0);
+            // (S.nodeCull: 1 = packets of rays that leave a surface -- the shadow rays and reflections of a frame --, 2 = every packet)
+            const bool nodeCull = S.nodeCull == 2 || (S.nodeCull == 1 && __any(valid && L.ignoreId >= 0));
+            const bool meshAway = nodeCull && all_back_facing(f4{mr.nbMin[0], mr.nbMin[1], mr.nbMin[2], mr.nbMin[3]}, f4{mr.nbMax[0], mr.nbMax[1], mr.nbMax[2], mr.nbMax[3]}, L.r.d);
+            const unsigned long long lanes0 = mr.rootBlock < 0 ? 0ull : __ballot(valid && L.state == ST_NODE && L.mask != 0 && !meshAway);
+            pk_walk(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, lanes0, nodeCull);
             L.mesh = mesh;
             if (valid) {
                 const HitOut h = lane_result(L, C, S, M);
@@ -525,6 +533,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
             const bool nan = is_nan(o.x) || is_nan(o.y) || is_nan(o.z) || is_nan(d.x) || is_nan(d.y) || is_nan(d.z);
             C.w = make_ray(o, d);
             C.sfound = 0;
+            const bool nodeCull = S.nodeCull == 2 || (S.nodeCull == 1 && __any(valid && L.ignoreId >= 0));
             int sblk = 0, smask = 1, ssp = 0;   // root = slot 0 of block 0
             unsigned long long slanes = __ballot(valid && im != DEAD_RAY && !nan);
             while (slanes != 0ull) {
@@ -625,9 +634,10 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
                                     }
                                 }
                             } else {
-                                const unsigned long long lanes0 = __ballot(inRoot);
+                                const bool meshAway = nodeCull && all_back_facing(f4{mr.nbMin[0], mr.nbMin[1], mr.nbMin[2], mr.nbMin[3]}, f4{mr.nbMax[0], mr.nbMax[1], mr.nbMax[2], mr.nbMax[3]}, L.r.d);
+                                const unsigned long long lanes0 = __ballot(inRoot && !meshAway);
                                 if (lanes0 != 0ull)
-                                    pk_walk(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, lanes0);
+                                    pk_walk(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, lanes0, nodeCull);
                             }
                             if (L.mfound) {   // OSM:370-378
                                 L.mesh = m; C.obj = o;

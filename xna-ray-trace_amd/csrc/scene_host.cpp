@@ -277,6 +277,50 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
                 A.runBase.push_back(runFirst);
             }
         }
+        // ... and for every INTERIOR node the box of all the surface normals below it (the union of its children's boxes, bottom-up: a child
+        // block has a higher index than its parent's), so that a whole subtree RE:48-51 would reject triangle by triangle -- the terrain
+        // under a ray that leaves it, the far side of a crate -- is never entered (traverse.h all_back_facing: the same test, the same margin).
+        f4 meshNBlo{0, 0, 0, 0}, meshNBhi{0, 0, 0, 0};
+        {
+            bool meshAny = false;
+            const size_t nb = t.blocks.size() / 2;
+            for (size_t bi = nb; bi-- > 0;) {
+                const int masks = f2i(t.blocks[2 * bi].z), childBase = f2i(t.blocks[2 * bi].x);
+                for (int c = 0; c < 8; c++) {
+                    if (!((masks >> c) & 1)) continue;   // (a leaf: done above)
+                    const size_t cb = (size_t)childBase + (size_t)__builtin_popcount((unsigned)(masks & 0xff) & ((1u << c) - 1u));
+                    const int cmasks = f2i(t.blocks[2 * cb].z);
+                    f4 mn{0, 0, 0, 0}, mx{0, 0, 0, 0};
+                    bool any = false;
+                    for (int k = 0; k < 8; k++) {
+                        if ((cmasks >> (8 + k)) & 1) continue;   // empty leaf
+                        const f4 a = A.leafNB[2 * ((size_t)(blockBase + cb) * 8 + k)], b2 = A.leafNB[2 * ((size_t)(blockBase + cb) * 8 + k) + 1];
+                        if (!any) { mn = a; mx = b2; any = true; }
+                        else {
+                            mn.x = a.x < mn.x ? a.x : mn.x; mn.y = a.y < mn.y ? a.y : mn.y; mn.z = a.z < mn.z ? a.z : mn.z;
+                            mx.x = b2.x > mx.x ? b2.x : mx.x; mx.y = b2.y > mx.y ? b2.y : mx.y; mx.z = b2.z > mx.z ? b2.z : mx.z;
+                            if (a.w != 0.0f) mn.w = 1.0f;
+                        }
+                    }
+                    if (!any) mn.w = 1.0f;   // (cannot happen: an interior node holds triangles)
+                    A.leafNB[2 * ((size_t)(blockBase + bi) * 8 + c)] = mn; A.leafNB[2 * ((size_t)(blockBase + bi) * 8 + c) + 1] = mx;
+                }
+            }
+            if (nb) {
+                const int masks = f2i(t.blocks[0].z);
+                for (int k = 0; k < 8; k++) {
+                    if ((masks >> (8 + k)) & 1) continue;
+                    const f4 a = A.leafNB[2 * ((size_t)blockBase * 8 + k)], b2 = A.leafNB[2 * ((size_t)blockBase * 8 + k) + 1];
+                    if (!meshAny) { meshNBlo = a; meshNBhi = b2; meshAny = true; }
+                    else {
+                        meshNBlo.x = a.x < meshNBlo.x ? a.x : meshNBlo.x; meshNBlo.y = a.y < meshNBlo.y ? a.y : meshNBlo.y; meshNBlo.z = a.z < meshNBlo.z ? a.z : meshNBlo.z;
+                        meshNBhi.x = b2.x > meshNBhi.x ? b2.x : meshNBhi.x; meshNBhi.y = b2.y > meshNBhi.y ? b2.y : meshNBhi.y; meshNBhi.z = b2.z > meshNBhi.z ? b2.z : meshNBhi.z;
+                        if (a.w != 0.0f) meshNBlo.w = 1.0f;
+                    }
+                }
+            }
+            if (!meshAny) meshNBlo.w = 1.0f;   // (a mesh whose root is a leaf, or without triangles: no record, never culled)
+        }
         for (int tri : t.leafRefs) {   // leaf references in leaf order: normal stream + geometry stream
             const float *p = &m.v[(size_t)tri * 9];
             const float *sn = &m.sn[(size_t)tri * 3];
@@ -313,6 +357,8 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
         for (int a = 0; a < 3; a++) { mr.rmin[a] = t.rootBox[a]; mr.rmax[a] = t.rootBox[3 + a]; }
         mr.rootBlock = t.rootIsLeaf ? -1 : blockBase;
         mr.rootRef = refBase; mr.rootCount = t.rootIsLeaf ? t.rootCount : 0;
+        mr.nbMin[0] = meshNBlo.x; mr.nbMin[1] = meshNBlo.y; mr.nbMin[2] = meshNBlo.z; mr.nbMin[3] = meshNBlo.w;
+        mr.nbMax[0] = meshNBhi.x; mr.nbMax[1] = meshNBhi.y; mr.nbMax[2] = meshNBhi.z; mr.nbMax[3] = meshNBhi.w;
         mr.triBase = triBase; mr.ntri = m.ntri; mr.material = (int)mi; mr.maxDepth = t.maxDepth; mr.dfsBase = blockBase * 8;
         A.meshes.push_back(mr);
         if (t.maxDepth > A.meshDepth) A.meshDepth = t.maxDepth;
@@ -491,6 +537,7 @@ SceneView HostScene::host_view() const {
     S.snodes = A.snodes.data(); S.srefs = A.srefs.data(); S.scull = A.scull.data(); S.objects = A.objects.data(); S.objMesh = A.objMesh.data();
     S.nMeshes = (int)meshes.size(); S.nObjects = (int)objects.size();
     S.sceneDepth = A.sceneDepth + 1; S.meshDepth = A.meshDepth + 1;
+    S.nodeCull = 1;
     return S;
 }
 

@@ -20,7 +20,7 @@ namespace xrt {
 struct SceneView {
     const f4 *blocks;       // mesh octrees: 2 per block descriptor (implicit boxes, xrt_core.h)
     const int *childDfs;    // 8 per block: DFS pre-order index of child c
-    const f4 *leafNB;       // 2 per node: component-wise min / max of the leaf's surface normals
+    const f4 *leafNB;       // 2 per node: component-wise min / max of the surface normals of the leaf / of every leaf below the interior node
     const f4 *leafTB;       // 4 per node: the leaf's tight box (xrt_core.h leaf_certainly_missed)
     const int *runBase;     // per node: first run record of a leaf of >= LEAF_RUN_MIN references (index into runTB / 4), else -1
     const f4 *runTB;        // 4 per run of LEAF_RUN consecutive references: the run's tight box (same form as leafTB)
@@ -38,6 +38,8 @@ struct SceneView {
     const int *objMesh;
     int nMeshes, nObjects;
     int sceneDepth, meshDepth;   // stack capacities needed
+    int nodeCull;                // interior nodes (and whole meshes) whose triangles all face away from the ray are not entered (all_back_facing on the node's
+                                 // normal box): 0 off, 1 for rays that lately met back faces only / packets of rays leaving a surface, 2 always
 };
 
 // k_packet's block record (SceneView::pblocks), PBLOCK_WORDS floats per block:
@@ -103,6 +105,7 @@ XRT_HD int ctz32(unsigned x) { return __builtin_ctz(x); }
 XRT_HD int node_dfs(const SceneView &S, int node) { return node < 0 ? 0 : S.childDfs[node]; }
 
 XRT_HD void finish_mesh_query(Lane &L, int mode);
+XRT_HD bool all_back_facing(f4 nmin, f4 nmax, v3 d);
 
 // The eight children of block `blk`: descriptor into registers, every non-empty child pending.
 XRT_HD void load_block(Lane &L, const SceneView &S, int blk) {
@@ -230,6 +233,9 @@ XRT_HD void begin_mesh_query(Lane &L, const SceneView &S, int mesh, bool enter =
         return;
     }
     if (!enter) { L.mask = 1; return; }   // (mask 1 tells the packet "inside the root box": a ray that misses it ends here with mask 0, MO:265)
+    // every triangle of the mesh faces away from the ray (RE:48-51 would reject each one): the answer of MO:259 is "no intersection"
+    if (S.nodeCull && (S.nodeCull == 2 || !L.spec) &&
+        all_back_facing(f4{mr.nbMin[0], mr.nbMin[1], mr.nbMin[2], mr.nbMin[3]}, f4{mr.nbMax[0], mr.nbMax[1], mr.nbMax[2], mr.nbMax[3]}, L.r.d)) return;
     L.bmin = mk(mr.rmin[0], mr.rmin[1], mr.rmin[2]);
     L.half = half_of(L.bmin, mk(mr.rmax[0], mr.rmax[1], mr.rmax[2]));
     load_block(L, S, mr.rootBlock);
@@ -495,6 +501,10 @@ XRT_HD void advance_node(Lane &L, const SceneView &S, Stack &stk, int mode, bool
     }
     // interior child: prune by its own entry key only when that is a proven lower bound (safe bit)
     if (L.mfound && ((L.d2 >> (16 + c)) & 1) && key > L.mKey) return;
+    if (S.nodeCull && (S.nodeCull == 2 || !L.spec)) {   // ... and do not enter a subtree whose triangles all face away from the ray (the normal box of an interior node)
+        const f4 nlo = S.leafNB[2 * (size_t)(L.blk * 8 + c)], nhi = S.leafNB[2 * (size_t)(L.blk * 8 + c) + 1];
+        if (all_back_facing(nlo, nhi, L.r.d)) return;
+    }
     stk.set(S.sceneDepth + L.sp, ((unsigned)L.blk << 8) | (unsigned)L.mask);
     L.path = (L.path & ~(7ull << (3 * L.sp))) | ((unsigned long long)c << (3 * L.sp));
     L.sp++;

@@ -1618,6 +1618,8 @@ int scene_upload(xrt_scene *scene) {
     S.objects = scene->objects.p; S.objMesh = scene->objMesh.p;
     S.nMeshes = (int)scene->host->meshes.size(); S.nObjects = (int)scene->host->objects.size();
     S.sceneDepth = A.sceneDepth + 1; S.meshDepth = A.meshDepth + 1;
+    S.nodeCull = 1;
+    if (const char *e = getenv("XRT_NODE_CULL")) { const int v = atoi(e); if (v >= 0 && v <= 2) S.nodeCull = v; }   // (tools: a scheduling-free switch, results never change)
     scene->sceneMode = (scene->host->objects.size() == 1 && scene->host->objects[0].meshes.size() == 1 && scene->host->meshes.size() == 1 &&
                         scene->host->sceneTree.nodeCount == 1) ? MODE_SINGLE : MODE_SCENE;
     if (getenv("XRT_NO_SINGLE")) scene->sceneMode = MODE_SCENE;

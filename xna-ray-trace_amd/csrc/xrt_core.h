@@ -59,7 +59,7 @@ constexpr int ROOT_NODE = -1;
 //             performs per test)
 struct g3 { float x, y, z; };
 
-struct MeshRec {        // 80 B = five f4
+struct MeshRec {        // 112 B = seven f4
     float bmin[3];      // Mesh.MeshBoundingBox (MESH:14, TMP:244-307)
     int   rootBlock;    // block of the root's children, or -1 when the root is a leaf
     float bmax[3];
@@ -72,6 +72,8 @@ struct MeshRec {        // 80 B = five f4
     int   material;
     int   maxDepth;
     int   dfsBase;      // offset of this mesh's entries in childDfs (= rootBlock * 8 for interior roots)
+    float nbMin[4];     // component-wise min / max of ALL the mesh's surface normals (nbMin[3] != 0: a NaN normal, never cull) -- the
+    float nbMax[4];     // root's record of the node normal boxes (SceneView::leafNB holds the other nodes', interior ones included)
 };
 
 struct ObjRec {         // 176 B
