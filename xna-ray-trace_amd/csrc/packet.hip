@@ -357,7 +357,7 @@ __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const
         // ---- interior child: a lane prunes it by key only where that is a proven lower bound (safe bit) ----
         bool go = inC;
         if (keyed && ((d2 >> (16 + c)) & 1)) go = go & !((L.mfound != 0) & (key > L.mKey));   // (wave-uniform branch)
-        if (nodeCull) {   // (wave-uniform) a subtree whose triangles all face away from a lane's ray (RE:48-51 rejects each one) is not entered by that lane
+        if (nodeCull && ((d2 >> (24 + c)) & 1)) {   // (wave-uniform) a subtree whose triangles all face away from a lane's ray (RE:48-51 rejects each one) is not entered by that lane
             const f4 *const nr = reinterpret_cast<const f4 *>(lrec + (size_t)node * LREC_WORDS);
             go = go && !all_back_facing(nr[0], nr[1], L.r.d);
             PKC(9);

@@ -304,6 +304,14 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
                     }
                     if (!any) mn.w = 1.0f;   // (cannot happen: an interior node holds triangles)
                     A.leafNB[2 * ((size_t)(blockBase + bi) * 8 + c)] = mn; A.leafNB[2 * ((size_t)(blockBase + bi) * 8 + c) + 1] = mx;
+                    // all_back_facing needs sum_k min(nmin_k d_k, nmax_k d_k) > 0; an axis whose interval holds 0 contributes <= 0 for every d_k, so a box
+                    // that holds the origin can never pass: only the other interior children are worth the test (descriptor bits 24..31)
+                    const bool canPass = mn.w == 0.0f && (mn.x > 0.0f || mx.x < 0.0f || mn.y > 0.0f || mx.y < 0.0f || mn.z > 0.0f || mx.z < 0.0f);
+                    if (canPass) {
+                        f4 &lo = A.blocks[2 * (size_t)(blockBase + bi)];
+                        lo.z = i2f(f2i(lo.z) | (1 << (24 + c)));
+                        A.pblocks[(size_t)(blockBase + bi) * PBLOCK_WORDS + 2] = lo.z;
+                    }
                 }
             }
             if (nb) {

@@ -501,7 +501,7 @@ XRT_HD void advance_node(Lane &L, const SceneView &S, Stack &stk, int mode, bool
     }
     // interior child: prune by its own entry key only when that is a proven lower bound (safe bit)
     if (L.mfound && ((L.d2 >> (16 + c)) & 1) && key > L.mKey) return;
-    if (S.nodeCull && (S.nodeCull == 2 || !L.spec)) {   // ... and do not enter a subtree whose triangles all face away from the ray (the normal box of an interior node)
+    if (S.nodeCull && ((L.d2 >> (24 + c)) & 1) && (S.nodeCull == 2 || !L.spec)) {   // ... and do not enter a subtree whose triangles all face away from the ray (the normal box of an interior node)
         const f4 nlo = S.leafNB[2 * (size_t)(L.blk * 8 + c)], nhi = S.leafNB[2 * (size_t)(L.blk * 8 + c) + 1];
         if (all_back_facing(nlo, nhi, L.r.d)) return;
     }

@@ -36,11 +36,13 @@ XRT_HD float i2f(int i)   { return __builtin_bit_cast(float, i); }
 // Block descriptor = the 8 children (c = 4i+2j+k) of one interior node, two f4:
 //   w0 childBlockBase : interior child c owns block  childBlockBase + popcount(interiorMask & ((1<<c)-1))
 //   w1 refBase        : first leaf reference of this block's leaf children (stored contiguously, child order)
-//   w2 masks          : interiorMask | emptyMask << 8 | safeMask << 16
+//   w2 masks          : interiorMask | emptyMask << 8 | safeMask << 16 | facingMask << 24
 //                       empty: leaf child without triangles (bucketed by the reference, can never hit, Q4)
 //                       safe : interior child whose non-empty descendant leaf boxes all lie inside its own
 //                              box, so its own entry key is a lower bound of every bucket key below it
 //                              (slab monotonicity) and it may be pruned by key
+//                       facing: interior child whose normal box (SceneView::leafNB) does not hold the origin -- only such a subtree
+//                              can face away from a ray as a whole (traverse.h all_back_facing); set by scene_host.cpp
 //   w3 total          : leaf references of the block
 //   w4..w7 offs[8]    : 16-bit start offset of child c's references relative to refBase
 // Node id (for leaf ids / ties) = block * 8 + c, root = -1; childDfs[node id] = DFS pre-order index.
