@@ -92,7 +92,7 @@ def intersect_bytes(st):
 GATHER_EVERY = 4   # N > 1: one RCCL gather moves the tiles of this many frames (the collective's fixed cost is ~a frame's GPU time)
 
 
-def time_frames_sharded(tracer, outs, steps, warmup, rank, world, width, height, gathered_out):
+def time_frames_sharded(tracer, outs, steps, warmup, rank, world, width, height, gathered_out, table_dev=None, tiles_per_rank=None):
     """N > 1.  W warm-up frames, then K timed frames bracketed by barrier + synchronize on both sides.  Each rank renders
     its tiles of frame i into slot i % M of a group of M tile buffers (two groups); when a group is full (or at the end)
     ONE gather moves it to rank 0 -- the path's exchange step, RCCL over xGMI -- while the next group is being rendered,
@@ -118,7 +118,7 @@ def time_frames_sharded(tracer, outs, steps, warmup, rank, world, width, height,
         if rank == 0:
             dev = got if nccl else got.cuda()          # gloo: rehearsal on a box with fewer GPUs than ranks
             for m in range(count):
-                xrt.dist.detile_device(dev, width, height, world, gathered_out, rank_stride=M * n_out, offset=m * n_out)
+                xrt.dist.detile_device(dev, width, height, world, gathered_out, rank_stride=M * n_out, offset=m * n_out, table_dev=table_dev, tiles_per_rank=tiles_per_rank)
 
     def flush(g, count):
         src = groups[g] if nccl else groups[g].cpu()
@@ -167,9 +167,9 @@ def time_frames_sharded(tracer, outs, steps, warmup, rank, world, width, height,
     return dt, acc[0], acc[1]
 
 
-def time_frames(tracer, outs, steps, warmup, rank, world, width, height, gathered_out, stream=None):
+def time_frames(tracer, outs, steps, warmup, rank, world, width, height, gathered_out, stream=None, table_dev=None, tiles_per_rank=None):
     if world > 1:
-        return time_frames_sharded(tracer, outs, steps, warmup, rank, world, width, height, gathered_out)
+        return time_frames_sharded(tracer, outs, steps, warmup, rank, world, width, height, gathered_out, table_dev, tiles_per_rank)
     """One GPU.  W warm-up frames, then K timed frames bracketed by synchronize on both sides; frame i is enqueued before
     frame i-1 is waited for."""
     # stream None: libxrt decides (single-chunk frames of >= 0.05 ms of GPU time alternate between two streams of its own and
@@ -214,6 +214,7 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
     torch.cuda.synchronize()
     mem1 = torch.cuda.mem_get_info()[0]
     tracer.NumGpus = n_gpus_in_library   # > 1: every frame below is ONE xrt_render_device call that the library spreads over that many devices
+    tracer.BalanceTiles = n_gpus_in_library > 1 and os.environ.get("XRT_BENCH_BALANCE", "1") != "0"   # ... its tiles dealt by the previous frame's costs
     build_s = time.perf_counter() - t0
     W, H = spec.width, spec.height
     tx, ty, tpr = xrt.dist.shard_layout(W, H, world)
@@ -226,7 +227,28 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
     tracer.collect_stats = with_stats
     st0 = tracer.RenderDevice(outs[0].data_ptr(), shard_rank=rank, shard_count=world)
     tracer.collect_stats = False
-    dt, ms_int, launches = time_frames(tracer, outs, steps, warmup, rank, world, W, H, final)
+    # N > 1: cost-aware tile assignment (xrt.h xrt_scene_set_tile_table) -- two untimed frames under the round-robin layout leave the cost of
+    # every tile on the rank that rendered it; summed over the ranks, every rank derives the same longest-first table (xrt_balance_tiles) and
+    # renders its row of it from then on.  The static counterpart of the reference's dynamic row stealing (RT:48-52); XRT_BENCH_BALANCE=0: round-robin.
+    table_dev, tprb, balance = None, tpr, None
+    if world > 1 and os.environ.get("XRT_BENCH_BALANCE", "1") != "0":
+        tracer.TileCosts(reset=True)
+        for _ in range(2):
+            tracer.RenderDevice(outs[0].data_ptr(), shard_rank=rank, shard_count=world)
+        cost = torch.from_numpy(tracer.TileCosts())
+        if dist.get_backend() == "nccl":
+            cost = cost.cuda()
+        dist.all_reduce(cost)
+        cost = cost.cpu().numpy()
+        if cost.any():
+            tprb, table = xrt.dist.balanced_table(W, H, world, cost)
+            tracer.SetTileTable(world, tprb, table)
+            table_dev = torch.from_numpy(table).cuda()
+            loads = np.array([cost[r[r >= 0]].sum() for r in table.reshape(world, tprb)])
+            rr = np.array([cost[np.arange(cost.size) % world == k].sum() for k in range(world)])
+            balance = {"by_cost_round_robin": round(float(rr.mean() / rr.max()), 4), "by_cost_table": round(float(loads.mean() / loads.max()), 4), "tiles_per_rank": int(tprb)}
+            outs = [torch.zeros(tprb * 512, dtype=torch.int32, device="cuda") for _ in range(2)]
+    dt, ms_int, launches = time_frames(tracer, outs, steps, warmup, rank, world, W, H, final, table_dev=table_dev, tiles_per_rank=tprb)
     torch.cuda.synchronize()
     mem2 = torch.cuda.mem_get_info()[0]   # after two frames in flight: both frame contexts hold their work buffers
     # the pixels the timed loop's own render objects produced last (read back after the timed region): what main() compares with the oracle
@@ -240,7 +262,7 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
     rays = st0["rays_closest"] + st0["rays_shadow"]
     device_memory = {"scene_GB": round((mem0 - mem1) / 1e9, 3), "frame_work_buffers_GB": round((mem1b - mem2) / 1e9, 3),
                      "what": "hipMemGetInfo differences: scene arrays after the build; work buffers of BOTH frame contexts (two frames in flight) after the timed frames, output buffers excluded"}
-    res = dict(rays=rays, seconds=dt, ms_intersect=ms_int, launches=launches, stats=st0, build_s=build_s, width=W, height=H, last_frame=last_frame, device_memory=device_memory,
+    res = dict(tile_balance=balance, rays=rays, seconds=dt, ms_intersect=ms_int, launches=launches, stats=st0, build_s=build_s, width=W, height=H, last_frame=last_frame, device_memory=device_memory,
                tris=sum(m[0].ntri for m in spec.meshes), instances=len(spec.objects), overlapped=False)
     if world == 1 and dt / max(steps, 1) * 1e3 >= 0.04:
         # The frames of the timed region overlapped pairwise on the GPU (two streams), so a launch's duration includes time
@@ -491,8 +513,10 @@ def main():
                        "rays_closest_per_frame": int(st["rays_closest"]) if world == 1 else None, "rays_shadow_per_frame": int(st["rays_shadow"]) if world == 1 else None,
                        "rays_traversed_per_frame": int(trav_frame),
                        "rays_answered_by_raygen_per_frame": int(rays_frame - trav_frame),
-                       "parallelism": ("image tiles 64x8 round-robin x%d, one process: xrt_render_opts.n_gpus (in-library RCCL send/recv gather)" % args.gpus) if in_library
-                                      else "image tiles 64x8 round-robin x%d" % world, "scene_build_s": round(res["build_s"], 3), "device_memory": res["device_memory"]},
+                       "parallelism": ("image tiles 64x8 x%d (xrt_render_opts.balance_tiles: dealt by the previous frame's tile costs), one process: xrt_render_opts.n_gpus (in-library RCCL send/recv gather)" % args.gpus) if in_library
+                                      else ("image tiles 64x8 x%d, dealt longest-first by the previous frames' tile costs (xrt_balance_tiles; balance by cost %.3f, round-robin %.3f)"
+                                            % (world, res["tile_balance"]["by_cost_table"], res["tile_balance"]["by_cost_round_robin"]) if res.get("tile_balance")
+                                            else "image tiles 64x8 round-robin x%d" % world), "scene_build_s": round(res["build_s"], 3), "device_memory": res["device_memory"]},
             "Mrays_per_s_traversed": round(trav_frame * args.steps / seconds / 1e6, 3),
             "roofline": roofline_block(args.config if (world == 1 and not in_library) else "(N > 1: no PMC pass)", bytes_per_launch, ms_per_launch, launches // max(args.steps, 1), serial),
         }

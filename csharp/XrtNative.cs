@@ -41,7 +41,15 @@ namespace RayTraceProject.Native
     {
         public int maxReflections, useMultisampling, multisampleQuality, addressMode, filtering, shardRank, shardCount, collectStats;
         public int nGpus;                          // > 1: the library spreads the frame's tiles over that many devices and gathers them with RCCL
-        public int reserved0, reserved1, reserved2;   // zero
+        public int balanceTiles;                   // with nGpus > 1: 1 = the tiles are dealt by the previous frame's costs (the static counterpart of GetNextScanline, RayTracer.cs:48-52), 0 = round-robin
+        public int reserved0, reserved1;           // zero
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public unsafe struct XrtNodeInfo                // xrt_scene_get_tree: the private CubeNode (MeshOctree.cs:32-40) flattened, DFS pre-order
+    {
+        public fixed float bmin[3]; public fixed float bmax[3];
+        public int isLeaf, count, dfsIndex, depth, firstRef, reserved;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -88,6 +96,29 @@ namespace RayTraceProject.Native
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_host_register(IntPtr hostPtr, ulong bytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_host_unregister(IntPtr hostPtr);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern float xrt_progress(IntPtr scene);
+        // ---- the rest of include/xrt.h (every export is bound: tests/test_host_logic.py checks this file against the header) ----
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_device_count(out int count);
+        // inspection of the built trees (meshId -1: the scene octree); call with null arrays for the counts
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_scene_get_tree(IntPtr scene, int meshId, [Out] XrtNodeInfo[] nodes, ref long nNodes,
+                                                                    [Out] int[] refs, ref long nRefs);
+        // seam 1 with HBM-resident rays / hits (device pointers, asynchronous on `stream`), and MeshOctree.GetRayIntersection of one mesh (MeshOctree.cs:259-326)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_scene_intersect_device(IntPtr scene, IntPtr dRays, long n, IntPtr dHitsOut, IntPtr stream);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_mesh_intersect(IntPtr scene, int meshId, [In] XrtRay[] rays, long n, [Out] XrtHit[] hits);
+        // blocking frame into device memory (or this process's tile shard)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_render_device(IntPtr scene, ref XrtCamera camera, XrtLight[] lights, int nLights,
+                                                                      ref XrtRenderOpts opts, IntPtr dRgbaOut, IntPtr stream, IntPtr statsOut);
+        // image-tile shards (one process per GPU): layout, de-tile of the gathered buffers
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_shard_layout(int width, int height, int shardCount, out int tilesX, out int tilesY, out int tilesPerRank);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_detile_device(int width, int height, int shardCount, IntPtr dGathered, long rankStride,
+                                                                      IntPtr dRgbaOut, IntPtr stream);
+        // cost-aware tile assignment: the previous frame's tile costs -> a longest-first table -> installed for the next frames
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_scene_set_tile_table(IntPtr scene, int width, int height, int shardCount, int tilesPerRank, int[] tileOfSlot);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_scene_tile_costs(IntPtr scene, int width, int height, [Out] float[] costOut, int reset);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_balance_tiles(int width, int height, int shardCount, float[] tileCost, int tilesPerRank, [Out] int[] tileOfSlotOut);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_detile_table_device(int width, int height, int shardCount, int tilesPerRank, IntPtr dTileOfSlot,
+                                                                            IntPtr dGathered, long rankStride, IntPtr dRgbaOut, IntPtr stream);
+        // the primary rays of RayTracer.Render (RayTracer.cs:410-421), row-major
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_generate_primary_rays(IntPtr scene, ref XrtCamera camera, [Out] XrtRay[] raysOut);
         // can n_gpus > 1 load RCCL?  OK or E_RCCL (-6) with the loader's message; no device is touched
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_rccl_probe();
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define XRT_VERSION 201
+#define XRT_VERSION 202
 
 /* error codes (C# shim: BUSY -> InvalidOperationException (RT:26-27,62-63),
  * INVALID_ARG -> ArgumentException (SO:123-124, MAT:85,97)) */
@@ -142,7 +142,12 @@ typedef struct xrt_render_opts {
      * W*H frame there.  Needs N visible devices (XRT_E_NO_DEVICE) and shard_count <= 1 (XRT_E_INVALID_ARG); an RCCL
      * failure is XRT_E_RCCL. */
     int32_t n_gpus;
-    int32_t reserved[3];          /* zero */
+    /* n_gpus > 1 only.  1: cost-aware tile assignment -- every frame leaves the cost of its tiles (xrt_scene_tile_costs), and the next
+     * frame of the same size deals the tiles to the devices longest-first (xrt_balance_tiles) instead of round-robin: the reference's only
+     * parallel idea is DYNAMIC row stealing (RT:48-52, 105-120), which a static t % N assignment does not reproduce where rows differ in
+     * cost (the horizon).  0: round-robin.  Scheduling only: the frame is the same. */
+    int32_t balance_tiles;
+    int32_t reserved[2];          /* zero */
 } xrt_render_opts;
 
 /* Exact work counters of the REFERENCE algorithm for the rays of one call and the
@@ -306,6 +311,42 @@ int xrt_render_device_end(xrt_scene *scene, int32_t ticket, xrt_stats *stats_out
 #define XRT_TILE_H 8
 int xrt_shard_layout(int32_t width, int32_t height, int32_t shard_count, int32_t *tiles_x_out,
                      int32_t *tiles_y_out, int32_t *tiles_per_rank_out);
+
+/* ---- cost-aware tile assignment (one process per GPU; xrt_render_opts.balance_tiles does the same inside the library) ------------
+ * The reference balances its render threads dynamically: each takes the next scanline from a shared counter (RT:48-52, 105-120).
+ * Across GPUs the counterpart is a TILE TABLE made from the previous frame's costs, replacing the round-robin default:
+ *   tile_of_slot[r * tiles_per_rank + s] = the tile (row-major number, as xrt_shard_layout) rank r renders at slot s of its buffer,
+ *                                          or -1 for an unused slot; every tile of the frame appears exactly once.
+ * Results never depend on the table (every tile is rendered exactly once, by the same code); only which rank renders it does. */
+
+/* Install (tile_of_slot != NULL) or remove (NULL) the table of frames of width x height pixels rendered with shard_count shards.  The
+ * table is copied.  While it is installed, xrt_render_device[_begin] calls of that size and shard count render the tiles of row
+ * shard_rank of the table, tiles_per_rank slots (512 pixels each, unused slots zero) -- other sizes and shard counts keep the
+ * round-robin layout.  XRT_E_INVALID_ARG unless every tile appears exactly once.  XRT_E_BUSY while a frame is in flight. */
+int xrt_scene_set_tile_table(xrt_scene *scene, int32_t width, int32_t height, int32_t shard_count, int32_t tiles_per_rank,
+                             const int32_t *tile_of_slot);
+
+/* Cost of every tile (tiles_x * tiles_y floats, row-major tile order) of the frames of width x height pixels this scene object rendered
+ * since the last call with reset != 0: device-clock ticks its wave packets spent on the tile's rays, all generations (tiles another
+ * rank rendered: 0 -- sum the ranks' arrays).  Frames the per-lane kernel traces (one sample per pixel on one-body scenes, adaptive
+ * supersampling, ray trees) report no costs: all zeros, and xrt_balance_tiles then returns the round-robin table.  XRT_E_BUSY while a
+ * frame is in flight. */
+int xrt_scene_tile_costs(xrt_scene *scene, int32_t width, int32_t height, float *cost_out, int32_t reset);
+
+/* Greedy longest-processing-time-first assignment of the frame's tiles to shard_count ranks: tiles in descending order of cost (ties:
+ * ascending tile number), each to the rank with the least cost so far that still has a free slot (ties: the lowest rank); the slots
+ * of a rank are then filled in ascending tile order (neighbouring waves work on neighbouring tiles).  tiles_per_rank must be at least
+ * ceil(tiles / shard_count) -- the slack above that is what lets a rank take more cheap tiles than another takes expensive ones
+ * (xrt_shard_layout's value + 25 % is what bench.py uses).  A cost array without a positive finite entry gives the round-robin
+ * table.  Pure host arithmetic, deterministic: every rank computes the same table from the same costs.  tile_of_slot_out:
+ * shard_count * tiles_per_rank entries. */
+int xrt_balance_tiles(int32_t width, int32_t height, int32_t shard_count, const float *tile_cost, int32_t tiles_per_rank,
+                      int32_t *tile_of_slot_out);
+
+/* xrt_detile_device for buffers rendered under a tile table: d_tile_of_slot is the table in DEVICE memory (shard_count *
+ * tiles_per_rank int32). */
+int xrt_detile_table_device(int32_t width, int32_t height, int32_t shard_count, int32_t tiles_per_rank, const void *d_tile_of_slot,
+                            const void *d_gathered, int64_t rank_stride, void *d_rgba_out, void *stream);
 
 /* De-tile the gathered per-rank buffers (rank-major: rank r's tiles_per_rank * 512 pixels start at pixel
  * r * rank_stride; rank_stride 0 = tiles_per_rank * 512, i.e. contiguous) into a W*H frame on the device (used on

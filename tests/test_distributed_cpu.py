@@ -22,6 +22,39 @@ def _free_port():
     return p
 
 
+def _worker_table(rank, world, port, width, height, q):
+    """The same exchange under a cost-aware tile table (xrt.h xrt_scene_set_tile_table): every rank holds the per-tile costs of ITS tiles,
+    an all-reduce sums them, every rank computes the same longest-first table (xrt_balance_tiles, host arithmetic), packs its row of it."""
+    sys.path.insert(0, ROOT)
+    xrt = importlib.import_module("xna-ray-trace_amd")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tx, ty, tpr = xrt.dist.shard_layout(width, height, world)
+        rng = np.random.default_rng(5)
+        frame = rng.integers(0, 2**32, size=width * height, dtype=np.uint32)
+        cost_all = (rng.random(tx * ty) ** 3 * 1000 + 1).astype(np.float32)
+        mine = torch.zeros(tx * ty)
+        t = np.arange(tx * ty)
+        mine[torch.from_numpy(t[t % world == rank])] = torch.from_numpy(cost_all[t % world == rank])   # what xrt_scene_tile_costs gives a round-robin rank
+        dist.all_reduce(mine)
+        tprb, table = xrt.dist.balanced_table(width, height, world, mine.numpy())
+        ok = not np.array_equal(table, np.pad(xrt.dist.round_robin_table(width, height, world)[1].reshape(world, -1), ((0, 0), (0, tprb - tpr)), constant_values=-1).reshape(-1))
+        local = torch.from_numpy(xrt.dist.pack_shard(frame, width, height, rank, world, table, tprb).view(np.int32).copy())
+        gathered = xrt.dist.gather_frame(local, width, height)
+        tables = [None] * world
+        dist.all_gather_object(tables, table.tolist())
+        ok = ok and all(tb == tables[0] for tb in tables)   # every rank computed the same table
+        if rank == 0:
+            out = xrt.dist.detile_host(gathered.numpy().view(np.uint32), width, height, world, table=table, tiles_per_rank=tprb)
+            loads = np.array([cost_all[r[r >= 0]].sum() for r in table.reshape(world, tprb)])
+            rr = np.array([cost_all[t % world == r].sum() for r in range(world)])
+            q.put(bool(ok and np.array_equal(out, frame) and loads.mean() / loads.max() >= rr.mean() / rr.max() and loads.mean() / loads.max() > 0.97))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, width, height, q):
     sys.path.insert(0, ROOT)
     xrt = importlib.import_module("xna-ray-trace_amd")
@@ -64,6 +97,53 @@ def test_tile_shard_gather_detile_gloo(world, width, height):
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("world,width,height", [(2, 640, 160), (3, 500, 133)])
+def test_balanced_tile_table_gloo(world, width, height):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_table, args=(r, world, port, width, height, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_balance_tiles_properties():
+    """xrt_balance_tiles (host arithmetic, no device): every tile exactly once, no rank over its slots, a rank's slots in descending order of cost, a
+    better balance than round-robin on skewed costs, round-robin without costs, deterministic, and the refusals."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    xrt = importlib.import_module("xna-ray-trace_amd")
+    rng = np.random.default_rng(3)
+    for (w, h, n) in ((1920, 1080, 8), (3840, 2160, 8), (1920, 1080, 2), (100, 37, 3), (64, 8, 4)):
+        tx, ty, tpr = xrt.dist.shard_layout(w, h, n)
+        cost = (rng.random(tx * ty) ** 4 * 1e6).astype(np.float32)
+        cost[: tx * ty // 5] *= 30          # an expensive band (the horizon rows)
+        cost[rng.integers(0, tx * ty, size=3)] = 0.0
+        tprb, table = xrt.dist.balanced_table(w, h, n, cost)
+        rows = table.reshape(n, tprb)
+        assert np.array_equal(np.sort(table[table >= 0]), np.arange(tx * ty))
+        floor = cost[cost > 0].min()
+        for r in rows:
+            used = r[r >= 0]
+            assert np.all(r[len(used):] == -1)
+            assert np.all(np.diff(np.maximum(cost[used], floor)) <= 0)   # a rank's slots in descending order of cost: its launches start with their longest packets
+        if tx * ty >= 4 * n:
+            loads = np.array([cost[r[r >= 0]].sum() for r in rows])
+            rr = np.array([cost[np.arange(tx * ty) % n == k].sum() for k in range(n)])
+            assert loads.mean() / loads.max() >= rr.mean() / rr.max()
+            if tx * ty >= 100 * n:
+                assert loads.mean() / loads.max() > 0.99
+        assert np.array_equal(xrt.dist.balanced_table(w, h, n, cost)[1], table)
+        assert np.array_equal(xrt.dist.balanced_table(w, h, n, np.zeros(tx * ty, np.float32), slack=0.0)[1], xrt.dist.round_robin_table(w, h, n)[1])
+    out = (C.c_int32 * 8)()
+    assert xrt.abi.lib().xrt_balance_tiles(1920, 1080, 8, None, 10, out) == xrt.abi.XRT_E_INVALID_ARG   # 80 slots for 4050 tiles
+    assert b"do not hold" in xrt.abi.lib().xrt_last_error()
 
 
 def test_shard_layout_matches_library():

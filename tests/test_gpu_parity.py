@@ -1130,6 +1130,83 @@ def test_full_size_c4_c5_as_specified(xrt, name):
         xrt.abi.check(xrt.abi.lib().xrt_detile_device(W, H, world, C.c_void_p(gathered.data_ptr()), 0, C.c_void_p(out.data_ptr()), None))
         torch.cuda.synchronize()
         assert torch.equal(out, whole), world
+    # Cost-aware tile assignment (xrt.h xrt_scene_set_tile_table): the whole frame's tile costs -> a longest-first table for 4 and 8 ranks; the
+    # shards rendered under it, gathered and de-tiled through the table == the unsharded frame, ray counts adding up; the table is better
+    # balanced than round-robin BY THE MEASURED COSTS (what tools/shard_predict.py then times); then back to round-robin.
+    tracer.TileCosts(reset=True)
+    tracer.RenderDevice(again.data_ptr())
+    cost = tracer.TileCosts(reset=True)
+    assert cost.size == ((W + 63) // 64) * ((H + 7) // 8) and (cost > 0).sum() > 0.3 * cost.size and np.isfinite(cost).all()
+    for world in (4, 8):
+        tprb, table = xrt.dist.balanced_table(W, H, world, cost)
+        rows = table.reshape(world, tprb)
+        assert np.array_equal(np.sort(table[table >= 0]), np.arange(cost.size))
+        loads = np.array([cost[r[r >= 0]].sum() for r in rows])
+        _, rr = xrt.dist.round_robin_table(W, H, world)
+        rr_loads = np.array([cost[r[r >= 0]].sum() for r in rr.reshape(world, -1)])
+        assert loads.mean() / loads.max() >= 0.99 and loads.mean() / loads.max() >= rr_loads.mean() / rr_loads.max()
+        tracer.SetTileTable(world, tprb, table)
+        n = tprb * 512
+        gathered = torch.zeros(world * n, dtype=torch.int32, device="cuda")
+        acc = dict(rays_closest=0, rays_shadow=0, shaded_hits=0, pixels=0)
+        for r in range(world):
+            s_r = tracer.RenderDevice(gathered[r * n:(r + 1) * n].data_ptr(), shard_rank=r, shard_count=world)
+            for k in acc:
+                acc[k] += s_r[k]
+        for k in acc:
+            assert acc[k] == st[k], (world, k, acc[k], st[k])
+        out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+        xrt.dist.detile_device(gathered, W, H, world, out, table_dev=torch.from_numpy(table).cuda(), tiles_per_rank=tprb)
+        torch.cuda.synchronize()
+        assert torch.equal(out, whole), ("balanced", world)
+        tracer.SetTileTable(world, tprb, None)
+    tracer.RenderDevice(again.data_ptr())
+    assert torch.equal(again, whole)
+
+
+def test_tile_table_validation_and_small_frames(xrt, orc):
+    """xrt_scene_set_tile_table refuses a table that misses or repeats a tile; a hand-made (reversed, uneven) table on a small frame renders
+    the same pixels; frames of another size keep the round-robin layout while the table is installed; a scene traced by the per-lane kernel
+    reports no costs and xrt_balance_tiles then answers round-robin."""
+    import torch
+    spec = xrt.configs.crate_grid_scene(200, 120)   # 4 x 15 = 60 tiles
+    spec.multisampling = xrt.abi.MS_FIXED16
+    scene, tracer = xrt.configs.build_product(spec)
+    want = tracer.Render().copy()
+    W, H, world, tiles = 200, 120, 3, 60
+    tpr = 26
+    table = np.full(world * tpr, -1, dtype=np.int32)
+    order = np.arange(tiles)[::-1]
+    table[0:26] = order[:26]; table[26:26 + 20] = order[26:46]; table[52:52 + 14] = order[46:]
+    for bad in (table[:world * tpr - 1].tolist() + [table[0]], np.where(table == 7, -1, table)):
+        with pytest.raises(ValueError):
+            tracer.SetTileTable(world, tpr, np.asarray(bad, dtype=np.int32))
+    tracer.SetTileTable(world, tpr, table)
+    n = tpr * 512
+    gathered = torch.zeros(world * n, dtype=torch.int32, device="cuda")
+    for r in range(world):
+        tracer.RenderDevice(gathered[r * n:(r + 1) * n].data_ptr(), shard_rank=r, shard_count=world)
+    out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    xrt.dist.detile_device(gathered, W, H, world, out, table_dev=torch.from_numpy(table).cuda(), tiles_per_rank=tpr)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(xrt.dist.detile_host(gathered.cpu().numpy().view(np.uint32), W, H, world, table=table, tiles_per_rank=tpr), want)
+    # two shards of the same frame: not the table's shard count -> round-robin
+    tx, ty, tpr2 = xrt.dist.shard_layout(W, H, 2)
+    g2 = torch.zeros(2 * tpr2 * 512, dtype=torch.int32, device="cuda")
+    for r in range(2):
+        tracer.RenderDevice(g2[r * tpr2 * 512:(r + 1) * tpr2 * 512].data_ptr(), shard_rank=r, shard_count=2)
+    xrt.dist.detile_device(g2, W, H, 2, out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want)
+    # a crate traced at one sample per pixel goes to the per-lane kernel: no costs
+    s1 = xrt.configs.crate_scene(128, 64, 2)
+    sc1, tr1 = xrt.configs.build_product(s1)
+    tr1.Render()
+    c1 = tr1.TileCosts()
+    assert not c1.any()
+    tprb, t1 = xrt.dist.balanced_table(128, 64, 4, c1, slack=0.0)
+    assert np.array_equal(t1, xrt.dist.round_robin_table(128, 64, 4)[1])
 
 
 def test_in_library_multi_gpu(xrt, monkeypatch):
@@ -1176,6 +1253,27 @@ def test_in_library_multi_gpu(xrt, monkeypatch):
             d = torch.zeros(s2.width * s2.height, dtype=torch.int32, device="cuda")
             tracer2.RenderDevice(d.data_ptr())                              # xrt_render_device
             assert np.array_equal(d.cpu().numpy().view(np.uint32), ref), (mode, n)
+        # balance_tiles: the second frame onwards deals the tiles by the frame before's costs (adaptive and ray-tree frames report none: round-robin)
+        tracer2.BalanceTiles = True
+        for n in (3, 8):
+            tracer2.NumGpus = n
+            for rep in range(3):
+                assert np.array_equal(tracer2.Render(), ref), (mode, n, rep, "balanced")
+                for k in keys:
+                    assert tracer2.last_stats[k] == st_ref[k], (mode, n, k, "balanced")
+            d = torch.zeros(s2.width * s2.height, dtype=torch.int32, device="cuda")
+            tracer2.RenderDevice(d.data_ptr())
+            assert np.array_equal(d.cpu().numpy().view(np.uint32), ref), (mode, n, "balanced")
+        tracer2.NumGpus = 2
+        outs = [torch.zeros(s2.width * s2.height, dtype=torch.int32, device="cuda") for _ in range(2)]
+        frs = [tracer2.PrepareDevice(o.data_ptr()) for o in outs]
+        for rep in range(2):   # two tickets open under the installed table
+            t0, t1 = frs[0].begin(), frs[1].begin()
+            frs[0].end(t0); frs[1].end(t1)
+            for o in outs:
+                assert np.array_equal(o.cpu().numpy().view(np.uint32), ref), (mode, "balanced, pipelined")
+        tracer2.BalanceTiles = False
+        assert np.array_equal(tracer2.Render(), ref), (mode, "round-robin again")
         # pipelined, two tickets open, to device and to host memory
         tracer2.NumGpus = 2
         outs = [torch.zeros(s2.width * s2.height, dtype=torch.int32, device="cuda") for _ in range(2)]

@@ -22,9 +22,27 @@ def test_abi_exports_every_declared_symbol(xrt):
     declared -= {"xrt_scene"}
     assert declared == set(xrt.abi.SYMBOLS), declared ^ set(xrt.abi.SYMBOLS)
     lib = xrt.abi.lib()                      # resolves all of them or raises
-    assert lib.xrt_version() == 201
+    assert lib.xrt_version() == 202
     assert C.sizeof(xrt.abi.xrt_ray) == 32 and C.sizeof(xrt.abi.xrt_hit) == 48
     assert lib.xrt_last_error() is not None
+
+
+def test_csharp_binding_covers_the_header():
+    """csharp/XrtNative.cs (the P/Invoke shim of the reference's C# host; uncompiled here: no .NET in the image) binds EVERY export of
+    include/xrt.h, each with CallingConvention.Cdecl, and its struct sizes match the header's (counted from the field lists)."""
+    hdr = open(os.path.join(ROOT, "include", "xrt.h")).read()
+    cs = open(os.path.join(ROOT, "csharp", "XrtNative.cs")).read()
+    declared = set(re.findall(r"\b(xrt_[a-z_]+)\s*\(", hdr)) - {"xrt_scene"}
+    imports = re.findall(r"\[DllImport\(Lib, CallingConvention = CallingConvention\.Cdecl\)\]\s*public static extern (?:unsafe )?\w+ (xrt_[a-z_]+)\(", cs)
+    assert set(imports) == declared, set(imports) ^ declared
+    assert len(imports) == len(set(imports))
+    assert len(re.findall(r"\[DllImport\(", cs)) == len(imports)          # no import without the calling convention
+    # xrt_render_opts: 12 ints in both
+    opts_c = re.search(r"typedef struct xrt_render_opts \{(.*?)\} xrt_render_opts;", hdr, re.S).group(1)
+    n_c = sum(int(m.group(1) or 1) for m in re.finditer(r"int32_t\s+\w+(?:\[(\d+)\])?;", opts_c))
+    opts_cs = re.search(r"public struct XrtRenderOpts\s*\{(.*?)\n    \}", cs, re.S).group(1)
+    n_cs = sum(len(m.group(1).split(",")) for m in re.finditer(r"public int ([^;]+);", opts_cs))
+    assert n_c == n_cs == 12
 
 
 def test_header_is_plain_c_and_the_c_host_builds(xrt, tmp_path):

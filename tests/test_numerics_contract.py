@@ -109,6 +109,26 @@ def test_hot_kernel_resources(isa):
         assert int(vgprs) <= budget and int(scratch) <= spill and int(occ) >= want, (name, vgprs, scratch, occ)
 
 
+def test_packet_kernel_argument_offsets():
+    """k_packet re-reads the arguments a packet needs once from the kernel-argument segment (packet.hip PkKernarg) at offsets it computes from
+    the parameter list: eight pointers, SceneView, PacketArgs.  The code object's own metadata must say the same."""
+    asm = open(os.path.join(CSRC, "packet.s")).read()
+    src = open(os.path.join(CSRC, "packet.hip")).read()
+    assert "PK_KERNARG_SCENE = 8 * 8, PK_KERNARG_ARGS = PK_KERNARG_SCENE + (unsigned)sizeof(SceneView)" in src
+    kernels = re.findall(r"\.args:(.*?)\.group_segment_fixed_size:.*?\.name:\s+(\S+)", asm, flags=re.S)
+    seen = 0
+    for args, name in kernels:
+        if "k_packet" not in name:
+            continue
+        seen += 1
+        offs = [(int(o), int(sz), kind) for o, sz, kind in re.findall(r"\.offset:\s+(\d+)\s+\.size:\s+(\d+)\s+\.value_kind:\s+(\w+)", args)]
+        ptrs = [x for x in offs if x[2] == "global_buffer"]
+        byval = [x for x in offs if x[2] == "by_value"]
+        assert [o for o, _, _ in ptrs] == [8 * i for i in range(8)] and len(byval) == 2
+        assert byval[0][0] == 64 and byval[1][0] == 64 + byval[0][1]          # SceneView at 64, PacketArgs right behind it (sizeof(SceneView) % 8 == 0)
+    assert seen == 3
+
+
 def test_packet_kernel_resources(isa):
     """k_packet: no scratch, and an SGPR allocation within what packet_blocks_per_cu (packet.hip) sizes its grid for -- the
     occupancy API over-reports resident blocks in the 81-112 SGPR range (MI355X_MICROARCH.md, Correctness boundaries)."""

@@ -9,16 +9,21 @@ name = sys.argv[1] if len(sys.argv) > 1 else "C5"
 spec = xrt.configs.config(name)
 scene, tracer = xrt.configs.build_product(spec)
 out = torch.zeros(spec.width * spec.height, dtype=torch.int32, device="cuda")
-fr = tracer.PrepareDevice(out.data_ptr())
+# optional: one tile shard of the frame -- python tools/pk_counters.py C5 <rank> <count>
+rank, count = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (0, 1)
+fr = tracer.PrepareDevice(out.data_ptr(), shard_rank=rank, shard_count=count)
 lib = xrt.abi.lib()
 buf = (C.c_ulonglong * 16)()
 for _ in range(3):
     fr()
 torch.cuda.synchronize()
 lib.xrt_debug_packet_counters(buf, 1)
+ticks = (C.c_ulonglong * 32)()
+lib.xrt_debug_packet_ticks(ticks, 1)
 st = fr()
 torch.cuda.synchronize()
 lib.xrt_debug_packet_counters(buf, 1)
+lib.xrt_debug_packet_ticks(ticks, 1)
 names = ["walks", "blocks entered", "child visits", "leaf children", "leaves some lane may need (bucket rule, facing)", "leaves past their tight box", "run box tests",
          "runs scanned", "triangle steps", "-", "pops", "child visits with keys", "lanes at the root", "lane-visits of children", "lane-triangle tests", "-"]
 w = max(buf[0], 1)
@@ -27,3 +32,8 @@ for i, n in enumerate(names):
     if n != "-":
         print("  %-50s %12d  %8.2f per walk" % (n, buf[i], buf[i] / w))
 print("  lanes per child visit %.1f, lanes per triangle step %.1f" % (buf[13] / max(buf[2], 1), buf[14] / max(buf[8], 1)))
+print("  packets by duration (device clock, 10 ns ticks; frame %.3f ms, traversal %.3f ms):" % (st["ms_total"], st["ms_intersect"]))
+tot = sum(ticks)
+for b in range(32):
+    if ticks[b]:
+        print("    %8.1f .. %8.1f us  %9d packets  %5.1f %%   (their time, at the bucket's middle: %.1f wave-ms)" % (2 ** b / 100.0, 2 ** (b + 1) / 100.0, ticks[b], 100.0 * ticks[b] / tot, ticks[b] * 1.5 * 2 ** b / 1e5))

@@ -63,6 +63,7 @@ def main():
     ap.add_argument("configs", nargs="*", default=["C4", "C5"])
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--n", default="2,4,8", help="shard counts")
+    ap.add_argument("--layouts", default="balanced", help="comma list of round_robin, balanced (tiles dealt longest-first by the whole frame's tile costs: xrt_balance_tiles)")
     ap.add_argument("--out", default=os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "shard_predict.json"))
     args = ap.parse_args()
     out = {"what": "one-GPU PREDICTION of image-tile strong scaling: every shard rendered alone on one MI355X; not a multi-GPU measurement",
@@ -76,11 +77,24 @@ def main():
         t_whole, st_whole, p_whole = timed([tracer.PrepareDevice(whole.data_ptr()), tracer.PrepareDevice(whole2.data_ptr())], args.reps)
         cfg = {"width": W, "height": H, "t_whole_ms": round(t_whole, 4), "period_whole_ms": round(p_whole, 4), "rays_whole": int(st_whole["rays_closest"] + st_whole["rays_shadow"]),
                "rays_traversed_whole": int(st_whole["rays_traversed"]), "shards": {}}
-        for n in [int(x) for x in args.n.split(",")]:
+        tracer.TileCosts(reset=True)
+        for _ in range(2):
+            tracer.RenderDevice(whole.data_ptr())
+        cost = tracer.TileCosts(reset=True)   # what every rank's xrt_scene_tile_costs add up to after two frames
+        for n, layout in [(int(x), l) for x in args.n.split(",") for l in args.layouts.split(",")]:
             import ctypes as C
             c_tpr = C.c_int32()
             xrt.abi.check(xrt.abi.lib().xrt_shard_layout(W, H, n, None, None, C.byref(c_tpr)))   # (the library's own layout: variants may differ)
             tpr = c_tpr.value
+            table_dev, by_cost = None, None
+            if layout == "balanced":
+                tpr, table = xrt.dist.balanced_table(W, H, n, cost)
+                tracer.SetTileTable(n, tpr, table)
+                table_dev = torch.from_numpy(table).cuda()
+                loads = [float(cost[r[r >= 0]].sum()) for r in table.reshape(n, tpr)]
+                by_cost = sum(loads) / n / max(loads)
+            else:
+                tracer.SetTileTable(n, tpr, None)
             count = tpr * 512
             gathered = torch.zeros(n * count, dtype=torch.int32, device="cuda")
             second = torch.zeros(count, dtype=torch.int32, device="cuda")   # output of the other frame in flight
@@ -96,7 +110,7 @@ def main():
             dts = []
             for _ in range(5):
                 e0.record()
-                xrt.dist.detile_device(gathered, W, H, n, final)
+                xrt.dist.detile_device(gathered, W, H, n, final, table_dev=table_dev, tiles_per_rank=tpr)
                 e1.record()
                 torch.cuda.synchronize()
                 dts.append(e0.elapsed_time(e1))
@@ -104,16 +118,17 @@ def main():
             detile_ms = statistics.median(dts)
             gather_ms = (count * 4) / (XGMI_LINK_GBS * 1e9) * 1e3 + 0.010   # every rank sends its tile buffer over its OWN link to rank 0 (point-to-point xGMI): the n-1 transfers run side by side
             fixed = detile_ms + gather_ms
-            cfg["shards"][str(n)] = {"t_shard_ms": [round(t, 4) for t in ts], "period_shard_ms": [round(t, 4) for t in ps],
+            cfg["shards"][str(n) if layout == "round_robin" else "%d_%s" % (n, layout)] = {"layout": layout, "tiles_per_rank": tpr, "balance_by_tile_cost": None if by_cost is None else round(by_cost, 4), "t_shard_ms": [round(t, 4) for t in ts], "period_shard_ms": [round(t, 4) for t in ps],
                                      "predicted_throughput_scaling": round(p_whole / max(ps), 3),
                                      "predicted_throughput_scaling_with_fixed": round(p_whole / (max(ps) + fixed), 3), "rays": rays, "rays_traversed": trav,
                                      "predicted_strong_scaling": round(t_whole / max(ts), 3), "balance": round(sum(ts) / n / max(ts), 3),
                                      "sum_of_shards_over_whole": round(sum(ts) / t_whole, 3),
                                      "fixed_ms": {"detile_measured": round(detile_ms, 4), "gather_estimated": round(gather_ms, 4)},
                                      "predicted_with_fixed": round(t_whole / (max(ts) + fixed), 3)}
-            print("%s N=%d: blocking: whole %.3f ms, shards %s ms -> predicted x%.2f (with fixed costs x%.2f), balance %.2f | two in flight: whole %.3f ms, shards %s ms -> x%.2f (with fixed x%.2f)" % (
-                name, n, t_whole, " ".join("%.3f" % t for t in ts), t_whole / max(ts), t_whole / (max(ts) + fixed), sum(ts) / n / max(ts),
+            print("%s N=%d %s: blocking: whole %.3f ms, shards %s ms -> predicted x%.2f (with fixed costs x%.2f), balance %.2f | two in flight: whole %.3f ms, shards %s ms -> x%.2f (with fixed x%.2f)" % (
+                name, n, layout, t_whole, " ".join("%.3f" % t for t in ts), t_whole / max(ts), t_whole / (max(ts) + fixed), sum(ts) / n / max(ts),
                 p_whole, " ".join("%.3f" % t for t in ps), p_whole / max(ps), p_whole / (max(ps) + fixed)), flush=True)
+        tracer.SetTileTable(2, 1, None)
         out["configs"][name] = cfg
         del tracer, scene
     out["time"] = time.strftime("%Y-%m-%dT%H:%M:%S")

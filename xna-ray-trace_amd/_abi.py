@@ -72,7 +72,7 @@ class xrt_light(C.Structure):
 class xrt_render_opts(C.Structure):
     _fields_ = [("max_reflections", C.c_int32), ("use_multisampling", C.c_int32), ("multisample_quality", C.c_int32),
                 ("address_mode", C.c_int32), ("filtering", C.c_int32), ("shard_rank", C.c_int32),
-                ("shard_count", C.c_int32), ("collect_stats", C.c_int32), ("n_gpus", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("shard_count", C.c_int32), ("collect_stats", C.c_int32), ("n_gpus", C.c_int32), ("balance_tiles", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class xrt_stats(C.Structure):
@@ -92,7 +92,7 @@ class xrt_node_info(C.Structure):
 
 
 assert C.sizeof(xrt_ray) == 32 and C.sizeof(xrt_hit) == 48 and C.sizeof(xrt_render_opts) == 48
-XRT_VERSION = 201
+XRT_VERSION = 202
 
 # every symbol include/xrt.h declares: name -> (restype, argtypes)
 _P = C.POINTER
@@ -122,6 +122,10 @@ SYMBOLS = {
     "xrt_render_device_end": (C.c_int, [C.c_void_p, C.c_int32, _P(xrt_stats)]),
     "xrt_shard_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "xrt_detile_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "xrt_scene_set_tile_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_int32)]),
+    "xrt_scene_tile_costs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _F, C.c_int32]),
+    "xrt_balance_tiles": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _F, C.c_int32, _P(C.c_int32)]),
+    "xrt_detile_table_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "xrt_progress": (C.c_float, [C.c_void_p]),
     "xrt_rccl_probe": (C.c_int, []),
     "xrt_generate_primary_rays": (C.c_int, [C.c_void_p, _P(xrt_camera), _P(xrt_ray)]),

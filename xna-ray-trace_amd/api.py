@@ -388,6 +388,7 @@ class RayTracer:
         self.last_stats = None
         self.collect_stats = False
         self.NumGpus = 1                # xrt_render_opts.n_gpus: one process, the frame's tiles dealt to this many devices
+        self.BalanceTiles = False       # xrt_render_opts.balance_tiles (with NumGpus > 1): tiles dealt by the last frame's costs instead of round-robin
 
     @property
     def CurrentTarget(self):
@@ -424,6 +425,7 @@ class RayTracer:
         o.shard_rank, o.shard_count = shard_rank, shard_count
         o.collect_stats = int(self.collect_stats)
         o.n_gpus = int(self.NumGpus) if shard_count <= 1 else 0
+        o.balance_tiles = 1 if (self.BalanceTiles and o.n_gpus > 1) else 0
         return o
 
     def _lights_abi(self):
@@ -494,6 +496,24 @@ class RayTracer:
             return self.last_stats
         frame.begin, frame.end = begin, end
         return frame
+
+    # ---- cost-aware tile assignment (xrt.h: the static counterpart of the reference's dynamic row stealing, RT:48-52) ----
+    def TileCosts(self, reset=True):
+        """xrt_scene_tile_costs: ticks per tile (row-major tile order) of the frames of the current target's size rendered since the last reset."""
+        w, h = self._target.Width, self._target.Height
+        tx, ty = (w + abi.TILE_W - 1) // abi.TILE_W, (h + abi.TILE_H - 1) // abi.TILE_H
+        cost = np.zeros(tx * ty, dtype=np.float32)
+        abi.check(abi.lib().xrt_scene_tile_costs(self.CurrentScene.handle, w, h, _fp(cost), 1 if reset else 0))
+        return cost
+
+    def SetTileTable(self, shard_count, tiles_per_rank, table):
+        """xrt_scene_set_tile_table for frames of the current target's size (table None: back to round-robin)."""
+        w, h = self._target.Width, self._target.Height
+        if table is None:
+            abi.check(abi.lib().xrt_scene_set_tile_table(self.CurrentScene.handle, w, h, 0, 0, None))
+            return
+        t = np.ascontiguousarray(table, dtype=np.int32)
+        abi.check(abi.lib().xrt_scene_set_tile_table(self.CurrentScene.handle, w, h, int(shard_count), int(tiles_per_rank), t.ctypes.data_as(C.POINTER(C.c_int32))))
 
     def PrepareHost(self, host_array):
         """Pipelined host-output frames (xrt_render_begin / xrt_render_end): RenderAsync with the frame ending in the host's

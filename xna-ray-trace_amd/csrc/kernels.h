@@ -65,6 +65,8 @@ constexpr int STAMP_HEADER = 2, STAMP_SLOTS = 8192, STAMP_STRIDE = STAMP_HEADER 
 
 // k_packet (packet.hip): one wavefront traces 64 consecutive rays of a coherent population together -- a shared walk of the
 // mesh octree with per-lane box / triangle tests.  Same answers as k_intersect (same tests, same arg-min rule).
+// What part B of k_shade needs of a shaded hit (see below, ShadeArgs): world position, path, fragment normal, Reflectiveness.
+struct alignas(16) SlotRec { float wx, wy, wz; int path; float nx, ny, nz, refl; };
 struct PacketArgs {
     const xrt_ray *rays = nullptr;
     xrt_hit *hits = nullptr;
@@ -86,6 +88,13 @@ struct PacketArgs {
     int *flags2 = nullptr;
     const int *nDev2 = nullptr;
     int nMul2 = 0, nCap2 = 0;
+    // Cost of the frame's tiles (xrt.h xrt_scene_tile_costs): every packet adds the device-clock ticks it took to the tile of its first ray --
+    // tileCost[path >> tileShift], path = pathOf1[ray] (or slotOf1[ray / nL1].path, or the ray's index) for the first segment, slotOf2[ray / nL2].path for the second.
+    unsigned *tileCost = nullptr;
+    int tileShift = 9, nL1 = 1, nL2 = 1;
+    const int *pathOf1 = nullptr;
+    const SlotRec *slotOf1 = nullptr;   // (a launch whose FIRST segment is shadow rays)
+    const SlotRec *slotOf2 = nullptr;
 };
 constexpr int PACKET_QUEUE_HEADS = 8, PACKET_HEAD_STRIDE = 64;   // every head on a 256-byte line of its own: atomics on one line serialise whatever the word
 constexpr int PACKET_QUEUE_WORDS = PACKET_QUEUE_HEADS * PACKET_HEAD_STRIDE;
@@ -102,7 +111,6 @@ constexpr int FLAG_MISS = 0, FLAG_HIT = 1, FLAG_TRANSPARENT = 2;
 // ray tree (== generation for a plain reflection chain).
 // What part B of k_shade needs of a shaded hit, left by part A at the hit's slot (the slots of a generation are dense, so both sides stream
 // 32 bytes per hit; the level record lvlA[node][path] is written once, by part B): world position, path, fragment normal, Reflectiveness.
-struct alignas(16) SlotRec { float wx, wy, wz; int path; float nx, ny, nz, refl; };
 
 // k_shade: part A works on generation `level`, part B on generation level-1 (kernels.hip).
 struct ShadeArgs {
@@ -175,6 +183,6 @@ void launch_ms_decide(const RayGenParams &g, const uint32_t *quadColor, const in
 void launch_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *childBase, const int *childMask, int n, hipStream_t st,
                     const int *nDev = nullptr);
 void launch_detile(int width, int height, int shardCount, int tilesPerRank, const uint32_t *gathered, long long rankStride, uint32_t *out,
-                   hipStream_t st);
+                   hipStream_t st, const int *table = nullptr);
 
 }  // namespace xrt

@@ -554,8 +554,8 @@ void launch_count(const SceneView &S, const IntersectArgs &A, unsigned long long
 __device__ __forceinline__ bool path_pixel(const RayGenParams &g, long long pix, int &x, int &y) {
     long long slot = pix >> 9;
     int within = (int)(pix & 511);
-    long long t = shard_tile(slot, g.shardRank, g.shardCount, g.tilesX);
-    if (t >= (long long)g.tilesX * g.tilesY) return false;
+    long long t = g.tileOfSlot ? (long long)g.tileOfSlot[slot] : shard_tile(slot, g.shardRank, g.shardCount, g.tilesX);
+    if (t < 0 || t >= (long long)g.tilesX * g.tilesY) return false;
     const unsigned ti = (unsigned)t;   // tilesX * tilesY < 2^31: one 32-bit division instead of two 64-bit ones
     const int ty = (int)(ti / (unsigned)g.tilesX), tx = (int)(ti - (unsigned)ty * (unsigned)g.tilesX);
     int wx, wy;
@@ -1218,8 +1218,9 @@ void launch_ms_fold(uint32_t *quadColor, const uint32_t *childColor, const int *
 }
 
 // rank-major gathered tiles -> W*H frame (rank 0 after the RCCL gather)
+// (table: the tile of every (rank, slot) under an installed tile table, xrt.h xrt_scene_set_tile_table; null: round-robin)
 __global__ __launch_bounds__(256) void k_detile(int width, int height, int shardCount, int tilesPerRank, int tilesX, int tilesY,
-                                                const uint32_t *gathered, long long rankStride, uint32_t *out) {
+                                                const uint32_t *gathered, long long rankStride, uint32_t *out, const int *table) {
     const long long total = (long long)shardCount * tilesPerRank * 512;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         int rank;
@@ -1233,8 +1234,8 @@ __global__ __launch_bounds__(256) void k_detile(int width, int height, int shard
         }
         long long slot = rem >> 9;
         int within = (int)(rem & 511);
-        long long t = shard_tile(slot, rank, shardCount, tilesX);
-        if (t >= (long long)tilesX * tilesY) continue;
+        long long t = table ? (long long)table[(long long)rank * tilesPerRank + slot] : shard_tile(slot, rank, shardCount, tilesX);
+        if (t < 0 || t >= (long long)tilesX * tilesY) continue;
         const unsigned ti = (unsigned)t, tyq = ti / (unsigned)tilesX;
         int wx, wy;
         tile_slot_xy(within, wx, wy);
@@ -1242,9 +1243,10 @@ __global__ __launch_bounds__(256) void k_detile(int width, int height, int shard
         if (x < width && y < height) out[(size_t)y * width + x] = gathered[(long long)rank * rankStride + rem];
     }
 }
-void launch_detile(int width, int height, int shardCount, int tilesPerRank, const uint32_t *gathered, long long rankStride, uint32_t *out, hipStream_t st) {
+void launch_detile(int width, int height, int shardCount, int tilesPerRank, const uint32_t *gathered, long long rankStride, uint32_t *out, hipStream_t st,
+                   const int *table) {
     int tilesX = (width + XRT_TILE_W - 1) / XRT_TILE_W, tilesY = (height + XRT_TILE_H - 1) / XRT_TILE_H;
-    hipLaunchKernelGGL(k_detile, dim3(2048), dim3(256), 0, st, width, height, shardCount, tilesPerRank, tilesX, tilesY, gathered, rankStride, out);
+    hipLaunchKernelGGL(k_detile, dim3(2048), dim3(256), 0, st, width, height, shardCount, tilesPerRank, tilesX, tilesY, gathered, rankStride, out, table);
 }
 
 }  // namespace xrt

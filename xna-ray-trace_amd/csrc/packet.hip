@@ -54,6 +54,7 @@ constexpr int PK_SGPRS = 112;        // SGPR allocation the kernel may reach (ch
 // xrt_debug_packet_counters, which exists only in such a build)
 #ifdef XRT_PK_COUNTERS
 __device__ unsigned long long g_pkCounters[16];
+__device__ unsigned long long g_pkTicks[32];   // packets by duration: bucket b counts packets of 2^b .. 2^(b+1) - 1 ticks of the 100 MHz device clock (xrt_debug_packet_ticks)
 #define PKC(i) (pkc[i]++)
 #else
 #define PKC(i) ((void)0)
@@ -406,6 +407,36 @@ template <int M> __device__ __forceinline__ unsigned *scene_frames() {
     else return nullptr;
 }
 
+// Arguments a packet needs once -- its ray / hit arrays, the queue, the tile-cost words, the arrays lane_result reads -- are RE-READ from the
+// kernel-argument segment where they are used (scalar loads from constant memory, the pointer passed through an empty asm per packet so
+// that the loads stay inside the loop) instead of living in scalar registers across the walk: the allocator kept them in SGPRs spilled to
+// vector-register lanes (v_writelane / v_readlane) around every walk.  Offsets: the eight pointer parameters, then SceneView, then PacketArgs,
+// each at its natural alignment (checked against the code object's metadata in tests/test_numerics_contract.py).
+constexpr unsigned PK_KERNARG_SCENE = 8 * 8, PK_KERNARG_ARGS = PK_KERNARG_SCENE + (unsigned)sizeof(SceneView);
+static_assert(sizeof(SceneView) % 8 == 0 && alignof(PacketArgs) == 8, "kernel-argument offsets of k_packet");
+typedef const __attribute__((address_space(4))) PacketArgs *PkArgsK;
+typedef const __attribute__((address_space(4))) SceneView *PkSceneK;
+struct PkKernarg {
+    unsigned long long base;
+    __device__ __forceinline__ PkKernarg() : base((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr()) {}
+    // (the loads that follow cannot be hoisted above this point: the pointer's halves go through an empty asm; the readfirstlane in front
+    // of it guarantees the asm's scalar-register operand whatever register class the allocator keeps `base` in)
+    __device__ __forceinline__ void fresh() {
+        unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
+        asm volatile("" : "+s"(lo), "+s"(hi));
+        base = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    }
+    __device__ __forceinline__ PkArgsK args() const { return (PkArgsK)(base + PK_KERNARG_ARGS); }
+    __device__ __forceinline__ PkSceneK scene() const { return (PkSceneK)(base + PK_KERNARG_SCENE); }
+    // what lane_result (traverse.h) reads of the scene
+    __device__ __forceinline__ SceneView result_view() const {
+        const PkSceneK k = scene();
+        SceneView v = {};
+        v.refG = k->refG; v.refN = k->refN; v.meshes = k->meshes; v.childDfs = k->childDfs; v.objects = k->objects;
+        return v;
+    }
+};
+
 #ifndef PK_SCENE_WAVES
 #define PK_SCENE_WAVES 5   // waves per SIMD the scene variant is compiled for: 96 VGPRs + 44 bytes of scratch per lane, touched per packet (not per step): C3 -5 %, C4 -7.5 % against 4 waves at 106 VGPRs (profiles/r03/packet_scene_five_waves.txt; at 111 VGPRs the same switch lost)
 #endif
@@ -418,6 +449,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
     unsigned *const sframesAll = scene_frames<M>();
     unsigned *const parkAll = scene_park<M>();
     stamp_begin(A.stamps);
+    PkKernarg KA;
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     unsigned *const stk = &frames[wave * PK_STACK_WORDS];
     int n = A.nDev ? (*A.nDev) * A.nMul : A.n;
@@ -471,9 +503,11 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
                     }
                     const int len = (dynTotal - cur + PK_QUEUES - 1) / PK_QUEUES;   // tickets of this head
                     int want = (len - seen) / (nWaves / PK_QUEUES * 2 + 1);   // guided: a share of what is left of this head's tickets
-                    want = want < 1 ? 1 : (want > A.grabMax ? A.grabMax : want);
+                    KA.fresh();
+                    const int grabMax = KA.args()->grabMax;
+                    want = want < 1 ? 1 : (want > grabMax ? grabMax : want);
                     unsigned g = 0;
-                    if (lane == 0) g = atomicAdd(A.queue + cur * PACKET_HEAD_STRIDE, (unsigned)want);
+                    if (lane == 0) g = atomicAdd(KA.args()->queue + cur * PACKET_HEAD_STRIDE, (unsigned)want);
                     const int head = rfl((int)g);
                     if (head >= 0 && head < len) { dNext = head; dEnd = min(head + want, len); seen = dEnd; curR = cur; got = true; break; }
                     dead |= 1u << cur;
@@ -484,12 +518,17 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
             dNext++;
         }
         // ---- the packet's 64 rays ------------------------------------------------------------------------------------
+        KA.fresh();
+#ifdef XRT_PK_COUNTERS
+        const bool costed = true;
+#else
+        const bool costed = KA.args()->tileCost != nullptr;
+#endif
+        const unsigned long long tPacket = costed ? wall_clock64() : 0ull;
         const bool seg2 = pk >= nPk1;   // wave-uniform
         const int w = (seg2 ? pk - nPk1 : pk) * 64 + lane;
         const bool valid = w < (seg2 ? n2 : n);
-        const xrt_ray *const raysS = seg2 ? A.rays2 : A.rays;
-        xrt_hit *const hitsS = seg2 ? A.hits2 : A.hits;
-        int *const flagsS = seg2 ? A.flags2 : A.flags;
+        const xrt_ray *const raysS = seg2 ? KA.args()->rays2 : KA.args()->rays;
         Lane L;
         L.state = ST_FINISH; L.mfound = 0; L.cost = 0; L.rayIndex = 0; L.mesh = 0; L.weird = 0; L.dmask = 0; L.ignoreId = -1; L.mask = 0;
         L.r = make_ray(mk(0, 0, 0), mk(1, 1, 1));
@@ -497,9 +536,10 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
         v3 o = mk(0, 0, 0), d = mk(0, 0, 0);
         int im = DEAD_RAY, it = -1;
         if (valid) {
-            idx = (A.index && !seg2) ? A.index[w] : w;
+            const int *const indexL = KA.args()->index;
+            idx = (indexL && !seg2) ? indexL[w] : w;
             load_ray(raysS + idx, o, d, im, it);
-            if (A.unmark && heavy_marked(it)) it ^= HEAVY_BIT;
+            if (KA.args()->unmark && heavy_marked(it)) it ^= HEAVY_BIT;
         }
         if constexpr (M != MODE_SCENE) {
             SceneLane C;
@@ -517,8 +557,12 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
             const unsigned long long lanes0 = mr.rootBlock < 0 ? 0ull : __ballot(valid && L.state == ST_NODE && L.mask != 0 && !meshAway);
             pk_walk(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, lanes0, nodeCull);
             L.mesh = mesh;
+            KA.fresh();
             if (valid) {
-                const HitOut h = lane_result(L, C, S, M);
+                const SceneView Sr = KA.result_view();
+                const HitOut h = lane_result(L, C, Sr, M);
+                xrt_hit *const hitsS = seg2 ? KA.args()->hits2 : KA.args()->hits;
+                int *const flagsS = seg2 ? KA.args()->flags2 : KA.args()->flags;
                 if (flagsS) flagsS[idx] = h.hit;
                 if (!flagsS || h.hit) store_hit(hitsS + idx, h);
             }
@@ -648,15 +692,36 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
                     }
                 }
             }
+            KA.fresh();
             if (valid) {
                 L.mfound = 0;
-                const HitOut h = lane_result(L, C, S, M);
+                const SceneView Sr = KA.result_view();
+                const HitOut h = lane_result(L, C, Sr, M);
+                xrt_hit *const hitsS = seg2 ? KA.args()->hits2 : KA.args()->hits;
+                int *const flagsS = seg2 ? KA.args()->flags2 : KA.args()->flags;
                 if (flagsS) flagsS[idx] = h.hit;
                 if (!flagsS || h.hit) store_hit(hitsS + idx, h);
             }
         }
+        if (costed) {   // the tile this packet's first ray belongs to pays for the packet (scheduling feedback for the next frame's tile table)
+            const unsigned dt = (unsigned)(wall_clock64() - tPacket);
+#ifdef XRT_PK_COUNTERS
+            if (lane == 0) atomicAdd(&g_pkTicks[dt ? 31 - __builtin_clz(dt) : 0], 1ull);
+            if (lane == 0 && KA.args()->tileCost) {
+#else
+            if (lane == 0) {
+#endif
+                const PkArgsK a = KA.args();
+                const int first = (seg2 ? pk - nPk1 : pk) * 64;
+                const SlotRec *const sl = seg2 ? a->slotOf2 : a->slotOf1;
+                const int *const po = a->pathOf1;
+                const int path = sl ? sl[first / (seg2 ? a->nL2 : a->nL1)].path : (po ? po[first] : first);
+                atomicAdd(a->tileCost + (path >> a->tileShift), dt);
+            }
+        }
     }
-    stamp_end(A.stamps);
+    KA.fresh();
+    stamp_end(KA.args()->stamps);
 }
 
 bool packet_supported(int mode, int meshDepth, int sceneDepth) {
@@ -677,6 +742,11 @@ int packet_blocks_per_cu(int mode) {
 }
 
 #ifdef XRT_PK_COUNTERS
+extern "C" int xrt_debug_packet_ticks(unsigned long long *out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_pkTicks), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pkTicks), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
 extern "C" int xrt_debug_packet_counters(unsigned long long *out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pkCounters), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pkCounters), z, sizeof(z)) != hipSuccess) return -1; }

@@ -315,6 +315,7 @@ struct xrt_scene {
         bool fast = false;           // no copy / fill / event-record commands: k_compose hands the counters over, events ride on kernels
         int *pinnedDev = nullptr;    // device view of `pinned`
         long long framePaths = 0;    // paths of the frame (part) this context holds: key of the grid hints
+        int frameW = 0, frameH = 0;  // the frame's size in pixels
         bool heap = false, redone = false;   // a ray-tree frame; ... that overflowed on the optimistic way and was rendered again
         bool adaptiveFast = false;           // an adaptive frame enqueued without host round trips (level sizes stay on the device)
         int cntBase = 0, levelCap = 0, quality = 0;   // words in front of the per-pass counters in `pinned`; quadrant capacity of a deeper level
@@ -372,7 +373,18 @@ struct xrt_scene {
     DevBuf<uint32_t> frameOut[2];    // W*H frame of a host-output ticket
     hipEvent_t tilesReady[2] = {nullptr, nullptr};   // replica (fake mode): its tiles are rendered
     hipEvent_t tailDone[2] = {nullptr, nullptr};     // primary: gather + de-tile + host copy of the ticket are done
-    struct OpenFrame { int nGpus = 0, nParts = 1; bool tail = false; uint32_t *hostOut = nullptr, *devOut = nullptr; size_t px = 0; hipStream_t st0 = nullptr; } open[2];
+    // Cost-aware tile assignment (xrt.h xrt_scene_set_tile_table / xrt_scene_tile_costs).  tileTable: the installed table (host copy and device
+    // copy) for frames of tableW x tableH pixels with tableCount shards, tableTpr slots per rank; tileCost: ticks per LOCAL tile slot of the
+    // frames rendered since the last reset, with the geometry they were rendered under (costKey) and their slots' tiles (costTiles).
+    std::vector<int> tileTable;
+    DevBuf<int> tileTableDev;
+    int tableW = 0, tableH = 0, tableCount = 0, tableTpr = 0;
+    DevBuf<unsigned> tileCost;
+    std::vector<int> costTiles;      // tile of every local slot the cost words belong to
+    int costW = 0, costH = 0;
+    std::vector<float> balanceCost;  // n_gpus > 1 with balance_tiles: the last frame's costs by tile (all ranks summed), its size
+    int balanceW = 0, balanceH = 0, balanceN = 0;
+    struct OpenFrame { int nGpus = 0, nParts = 1; bool tail = false, balance = false; uint32_t *hostOut = nullptr, *devOut = nullptr; size_t px = 0; hipStream_t st0 = nullptr; } open[2];
     std::mutex apiMutex;
     std::unordered_map<hipStream_t, int> queueOfStream;
     // development switches, read once at xrt_scene_create (never per frame)
@@ -384,6 +396,7 @@ struct xrt_scene {
         replicas.clear();
         if (device >= 0) {
             (void)hipSetDevice(device);
+            tileTableDev.release(); tileCost.release();
             for (int i = 0; i < 2; i++) { if (tilesReady[i]) (void)hipEventDestroy(tilesReady[i]); if (tailDone[i]) (void)hipEventDestroy(tailDone[i]); gathered[i].release(); tileOut[i].release(); frameOut[i].release(); }
             for (auto e : events) (void)hipEventDestroy(e);
             for (auto &f : frames) {
@@ -485,6 +498,60 @@ LightRec make_light(const xrt_light &l) {
     return r;
 }
 
+// ---- cost-aware tile assignment (xrt.h) ------------------------------------------------------------------------------------------
+// Longest-processing-time-first: tiles in descending order of cost (ties: ascending tile number), each to the rank with the least cost so
+// far that still has a free slot (ties: the lowest rank); a rank's slots are filled in that order.  Costs that are not
+// positive finite numbers count as the smallest positive cost seen (a tile nobody measured still takes a slot's worth of launch overhead).
+int balance_tiles_impl(int tiles, int count, const float *cost, int tpr, int *out) {
+    if (tiles <= 0 || count <= 0 || tpr <= 0 || !out) return fail(XRT_E_INVALID_ARG, "xrt_balance_tiles: bad argument");
+    if ((long long)tpr * count < tiles) return fail(XRT_E_INVALID_ARG, "xrt_balance_tiles: %d slots per rank x %d ranks do not hold %d tiles", tpr, count, tiles);
+    std::fill(out, out + (size_t)count * tpr, -1);
+    double lowest = 0.0;
+    bool any = false;
+    if (cost)
+        for (int t = 0; t < tiles; t++)
+            if (cost[t] > 0.0f && cost[t] < 3.0e38f) { if (!any || cost[t] < lowest) lowest = cost[t]; any = true; }
+    if (!any) {   // no measurement: the round-robin layout of xrt_shard_layout
+        for (int t = 0; t < tiles; t++) out[(size_t)(t % count) * tpr + t / count] = t;
+        return XRT_OK;
+    }
+    std::vector<int> order((size_t)tiles);
+    std::vector<double> c((size_t)tiles);
+    for (int t = 0; t < tiles; t++) { order[(size_t)t] = t; c[(size_t)t] = (cost[t] > 0.0f && cost[t] < 3.0e38f) ? (double)cost[t] : lowest; }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return c[(size_t)a] > c[(size_t)b2]; });
+    std::vector<double> load((size_t)count, 0.0);
+    std::vector<std::vector<int>> mine((size_t)count);
+    for (int t : order) {
+        int best = -1;
+        for (int r = 0; r < count; r++)
+            if ((int)mine[(size_t)r].size() < tpr && (best < 0 || load[(size_t)r] < load[(size_t)best])) best = r;
+        mine[(size_t)best].push_back(t);
+        load[(size_t)best] += c[(size_t)t];
+    }
+    // A rank's slots in the order its tiles were dealt -- descending cost: its launches start with their longest packets.  (A launch ends when
+    // its slowest packet does, and a packet of rays that skim the terrain near the horizon takes a hundred times the median: in ascending
+    // tile order such packets started wherever their rows fell, and the shards of a frame that were unlucky took up to twice as long as the
+    // others whatever their cost sums.)
+    for (int r = 0; r < count; r++)
+        for (size_t k = 0; k < mine[(size_t)r].size(); k++) out[(size_t)r * tpr + k] = mine[(size_t)r][k];
+    return XRT_OK;
+}
+
+// Every tile exactly once?
+int check_tile_table(int tiles, int count, int tpr, const int *table) {
+    if (tpr <= 0 || (long long)tpr * count < tiles) return fail(XRT_E_INVALID_ARG, "tile table: %d slots per rank x %d ranks do not hold %d tiles", tpr, count, tiles);
+    std::vector<char> seen((size_t)tiles, 0);
+    for (size_t i = 0; i < (size_t)count * tpr; i++) {
+        const int t = table[i];
+        if (t == -1) continue;
+        if (t < 0 || t >= tiles) return fail(XRT_E_INVALID_ARG, "tile table: entry %zu names tile %d of %d", i, t, tiles);
+        if (seen[(size_t)t]) return fail(XRT_E_INVALID_ARG, "tile table: tile %d appears twice", t);
+        seen[(size_t)t] = 1;
+    }
+    for (int t = 0; t < tiles; t++) if (!seen[(size_t)t]) return fail(XRT_E_INVALID_ARG, "tile table: tile %d is missing", t);
+    return XRT_OK;
+}
+
 int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g, const float *rootBox = nullptr /* min xyz, max xyz; null: no screen-rectangle cull */) {
     if (cam->vp_width <= 0 || cam->vp_height <= 0) return fail(XRT_E_INVALID_ARG, "viewport must be positive");
     float wv[16], wvp[16], ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -502,6 +569,7 @@ int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g
     g.cullX0 = 0; g.cullY0 = 0; g.cullX1 = g.width - 1; g.cullY1 = g.height - 1;
     g.cullSkipsRecord = 0;
     g.pathsDev = nullptr; g.pathsMul = 1; g.pathsCap = 0;
+    g.tileOfSlot = nullptr;
     if (g.shardRank < 0 || g.shardRank >= g.shardCount) return fail(XRT_E_INVALID_ARG, "shard_rank out of range");
     if (rootBox) {
         // Screen rectangle of the scene's root box.  A ray through pixel (x, y) that reaches the box at a point P has P
@@ -578,7 +646,12 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const int R = opts->max_reflections;
     const int nL = nLights;
     const long long totalTiles = (long long)g.tilesX * g.tilesY;
-    const long long myTiles = shard_tiles_per_rank(totalTiles, g.shardCount, g.tilesX);   // tiles_per_rank (slots, some may be past the end)
+    // an installed tile table for this frame geometry replaces the round-robin layout (xrt.h xrt_scene_set_tile_table)
+    const bool tabled = !s->tileTable.empty() && s->tableW == g.width && s->tableH == g.height && s->tableCount == g.shardCount;
+    const int *const tableRow = tabled ? s->tileTable.data() + (size_t)g.shardRank * s->tableTpr : nullptr;
+    g.tileOfSlot = tabled ? s->tileTableDev.p + (size_t)g.shardRank * s->tableTpr : nullptr;
+    const long long myTiles = tabled ? s->tableTpr : shard_tiles_per_rank(totalTiles, g.shardCount, g.tilesX);   // tiles_per_rank (slots, some may be past the end)
+    auto tile_of_slot = [&](long long sl) -> long long { return tabled ? (long long)tableRow[sl] : shard_tile(sl, g.shardRank, g.shardCount, g.tilesX); };
     const long long totalPixels = myTiles * 512;
     if (adaptive && totalPixels * 4 > 0x7fffffffLL) return fail(XRT_E_UNSUPPORTED, "frame too large for adaptive supersampling");
     const long long framePaths = totalPixels * g.samples;   // the whole frame (this shard)
@@ -676,6 +749,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         F.redoOut = d_out; F.redoOutF32 = d_outF32; F.redoSt = st;
     }
     F.framePaths = (nParts == 1 && !adaptive) ? firstPaths : -1;
+    F.frameW = g.width; F.frameH = g.height;
     // the traversal launches time themselves on the device clock instead of carrying events (device_util.h); a frame of more
     // than MAX_STAMP_ROWS launches (many chunks or supersampling levels) goes on with events
     const bool useStamps = !s->launchEvents && !s->noLaunchTiming && s->wallClockKHz > 0;
@@ -697,6 +771,22 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             if (!W.stream) HIPCHECK(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
             st = W.stream;
         } else st = s->stream;
+    }
+    // Tile costs (xrt.h xrt_scene_tile_costs): the packets of plain one-chunk frames add their device-clock ticks to the tile of their first
+    // ray.  The words belong to the scene (both frame contexts add to them); a frame of another geometry or tile table starts them afresh.
+    unsigned *tileCostDev = nullptr;
+    if (fast && !adaptive && !heap && nParts == 1 && s->packetOk) {
+        if ((rc = s->tileCost.ensure((size_t)myTiles))) return rc;
+        bool same = s->costW == g.width && s->costH == g.height && (long long)s->costTiles.size() == myTiles;
+        for (long long sl = 0; same && sl < myTiles; sl++) { const long long t = tile_of_slot(sl); same = s->costTiles[(size_t)sl] == (t < totalTiles ? (int)t : -1); }
+        if (!same) {
+            s->costTiles.resize((size_t)myTiles);
+            for (long long sl = 0; sl < myTiles; sl++) { const long long t = tile_of_slot(sl); s->costTiles[(size_t)sl] = t < totalTiles ? (int)t : -1; }
+            s->costW = g.width; s->costH = g.height;
+            HIPCHECK(hipMemsetAsync(s->tileCost.p, 0, (size_t)myTiles * sizeof(unsigned), st));
+            if (s->frames[0].pending || s->frames[1].pending) HIPCHECK(hipStreamSynchronize(st));   // (the other context's frame may be adding to them: start clean)
+        }
+        tileCostDev = s->tileCost.p;
     }
     // which ray populations the wave-packet kernel traces this frame (packet.hip): bit 0 primary rays, 1 shadow rays, 2 closest-hit
     // rays of later generations
@@ -841,6 +931,12 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 PacketArgs PA;
                 PA.rays = I.rays; PA.hits = I.hits; PA.flags = I.flags; PA.index = I.index; PA.nDev = I.nDev; PA.nMul = I.nMul; PA.n = I.n; PA.nCap = I.nCap;
                 if (I2) { PA.rays2 = I2->rays; PA.hits2 = I2->hits; PA.flags2 = I2->flags; PA.nDev2 = I2->nDev; PA.nMul2 = I2->nMul; PA.nCap2 = I2->nCap; }
+                if (tileCostDev && pathBase == 0) {   // which tile pays for a packet: the path of its first ray (closest-hit rays: the path list; shadow rays: their hit's slot record)
+                    PA.tileCost = tileCostDev; PA.tileShift = 9 + (gp.samples == 16 ? 4 : (gp.samples == 4 ? 2 : 0));
+                    if (&I == &B) { PA.slotOf1 = slotOf[prv]; PA.nL1 = nL; }
+                    else PA.pathOf1 = k == 0 ? W.index0.p : paths[cur];
+                    if (I2) { PA.slotOf2 = slotOf[prv]; PA.nL2 = nL; }
+                }
                 PA.queue = q + QW * k + 1 + PACKET_QUEUE_WORDS * word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv; PA.grabMax = s->packetGrabMax; PA.cullMin = s->packetCullMin;
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
@@ -1025,8 +1121,9 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     validPixels = 0;
     const long long slot0 = partStart / (512LL * g.samples), slot1 = (partStart + firstPaths + 512LL * g.samples - 1) / (512LL * g.samples);   // tile slots of this part
     for (long long sl = slot0; sl < slot1; sl++) {
-        const long long t = shard_tile(sl, g.shardRank, g.shardCount, g.tilesX);
+        const long long t = tile_of_slot(sl);
         if (t >= totalTiles) break;
+        if (t < 0) continue;   // (an unused slot of a tile table)
         int tx = (int)(t % g.tilesX), ty = (int)(t / g.tilesX);
         int w = g.width - tx * XRT_TILE_W; if (w > XRT_TILE_W) w = XRT_TILE_W;
         int h = g.height - ty * XRT_TILE_H; if (h > XRT_TILE_H) h = XRT_TILE_H;
@@ -1314,6 +1411,26 @@ int ensure_replicas(xrt_scene *s, int n) {
 
 xrt_scene *rank_scene(xrt_scene *s, int i) { return i == 0 ? s : s->replicas[(size_t)i - 1]; }
 
+// Install / remove a tile table on one scene object (its device must be current).  Caller has checked the table.
+int install_tile_table(xrt_scene *r, int w, int h, int count, int tpr, const int *table) {
+    if (!table) { r->tileTable.clear(); r->tableW = r->tableH = r->tableCount = r->tableTpr = 0; return XRT_OK; }
+    r->tileTable.assign(table, table + (size_t)count * tpr);
+    int rc = upload(r->tileTableDev, r->tileTable);
+    if (rc != XRT_OK) { r->tileTable.clear(); return rc; }
+    r->tableW = w; r->tableH = h; r->tableCount = count; r->tableTpr = tpr;
+    return XRT_OK;
+}
+// The costs of this scene object's tiles, added to cost[tile] (tiles entries); optionally cleared.  Its device must be current, no frame in flight.
+int read_tile_costs(xrt_scene *r, int w, int h, float *cost, bool reset) {
+    if (r->costW != w || r->costH != h || r->costTiles.empty() || !r->tileCost.p) return XRT_OK;
+    std::vector<unsigned> ticks(r->costTiles.size());
+    HIPCHECK(hipMemcpy(ticks.data(), r->tileCost.p, ticks.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    const int tiles = ((w + XRT_TILE_W - 1) / XRT_TILE_W) * ((h + XRT_TILE_H - 1) / XRT_TILE_H);
+    for (size_t sl = 0; sl < ticks.size(); sl++) { const int t = r->costTiles[sl]; if (t >= 0 && t < tiles) cost[t] += (float)ticks[sl]; }
+    if (reset) HIPCHECK(hipMemset(r->tileCost.p, 0, ticks.size() * sizeof(unsigned)));
+    return XRT_OK;
+}
+
 // Frame `slot` on n devices: rank i renders the tiles t with t % n == i (its own frame context `slot`, its own stream, one
 // host thread per device so that frames which need host decisions between passes still run side by side), then ONE
 // grouped RCCL exchange moves the tile buffers to rank 0 -- the path's only exchange step -- and k_detile writes the
@@ -1336,8 +1453,29 @@ int multi_begin(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *
         if (!s->rccl.init(devs, err)) return fail(XRT_E_RCCL, "%s", err.c_str());
         HIPCHECK(hipSetDevice(s->device));
     }
-    int tpr = 0;
-    xrt_shard_layout(cam->vp_width, cam->vp_height, n, nullptr, nullptr, &tpr);
+    int tpr = 0, tilesX = 0, tilesY = 0;
+    xrt_shard_layout(cam->vp_width, cam->vp_height, n, &tilesX, &tilesY, &tpr);
+    // balance_tiles: the tiles are dealt by the last frame's costs (longest first) instead of round-robin -- the static counterpart of the
+    // reference's dynamic row stealing (RT:48-52).  The table is made once per frame here and installed on every rank's scene object.
+    const bool balanced = opts->balance_tiles != 0 && s->balanceW == cam->vp_width && s->balanceH == cam->vp_height && s->balanceN == n &&
+                          (int)s->balanceCost.size() == tilesX * tilesY && !s->frames[slot ^ 1].pending;
+    const bool tableFits = s->tableW == cam->vp_width && s->tableH == cam->vp_height && s->tableCount == n && !s->tileTable.empty();
+    if (balanced) {
+        const int tprB = tpr + (tpr + 3) / 4;
+        std::vector<int> table((size_t)n * tprB);
+        if ((rc = balance_tiles_impl(tilesX * tilesY, n, s->balanceCost.data(), tprB, table.data()))) return rc;
+        for (int i = 0; i < n; i++) {
+            xrt_scene *r = rank_scene(s, i);
+            HIPCHECK(hipSetDevice(r->device));
+            if ((rc = install_tile_table(r, cam->vp_width, cam->vp_height, n, tprB, table.data()))) { (void)hipSetDevice(s->device); return rc; }
+        }
+        HIPCHECK(hipSetDevice(s->device));
+        tpr = tprB;
+    } else if (opts->balance_tiles != 0 && tableFits) tpr = s->tableTpr;   // (the other ticket's frame is in flight under the installed table: keep it)
+    else if (tableFits && opts->balance_tiles == 0) {   // back to round-robin
+        for (int i = 0; i < n; i++) (void)install_tile_table(rank_scene(s, i), 0, 0, 0, 0, nullptr);
+    }
+    const bool tabled = s->tableW == cam->vp_width && s->tableH == cam->vp_height && s->tableCount == n && !s->tileTable.empty();
     const size_t count = (size_t)tpr * 512;
     if ((rc = s->gathered[slot].ensure(count * (size_t)n))) return rc;
     for (int i = 1; i < n; i++) {
@@ -1410,7 +1548,7 @@ int multi_begin(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_light *
             if (!s->rccl.gather(src, srcRank, srcStream, dst, count, st0, err)) return fail(XRT_E_RCCL, "%s", err.c_str());
         }
         HIPCHECK(hipSetDevice(s->device));
-        launch_detile(cam->vp_width, cam->vp_height, n, tpr, s->gathered[slot].p, (long long)count, d_out, st0);
+        launch_detile(cam->vp_width, cam->vp_height, n, tpr, s->gathered[slot].p, (long long)count, d_out, st0, tabled ? s->tileTableDev.p : nullptr);
         HIPCHECK(hipGetLastError());
         *stream0_out = st0;
         return XRT_OK;
@@ -1432,7 +1570,7 @@ void add_stats(xrt_stats &acc, const xrt_stats &st, bool first) {
     acc.rays_traversed += st.rays_traversed;
 }
 
-int multi_end(xrt_scene *s, int slot, int n, xrt_stats *stats) {
+int multi_end(xrt_scene *s, int slot, int n, xrt_stats *stats, bool balance) {
     int rc = XRT_OK;
     xrt_stats acc;
     std::memset(&acc, 0, sizeof(acc));
@@ -1444,6 +1582,18 @@ int multi_end(xrt_scene *s, int slot, int n, xrt_stats *stats) {
         const int rci = frame_finish(r, r->frames[slot], &st);
         if (rci != XRT_OK) { rc = rci; continue; }
         add_stats(acc, st, i == 0);
+    }
+    if (rc == XRT_OK && balance && !s->frames[slot ^ 1].pending) {   // this frame's tile costs, all ranks: what the next frame's table is made from
+        const xrt_scene::FrameCtx &F0 = s->frames[slot];
+        const int w = F0.frameW, h = F0.frameH;
+        const int tiles = ((w + XRT_TILE_W - 1) / XRT_TILE_W) * ((h + XRT_TILE_H - 1) / XRT_TILE_H);
+        std::vector<float> cost((size_t)tiles, 0.0f);
+        bool ok = w > 0 && h > 0;
+        for (int i = 0; ok && i < n; i++) {
+            xrt_scene *r = rank_scene(s, i);
+            ok = hipSetDevice(r->device) == hipSuccess && read_tile_costs(r, w, h, cost.data(), true) == XRT_OK;
+        }
+        if (ok) { s->balanceCost.swap(cost); s->balanceW = w; s->balanceH = h; s->balanceN = n; }
     }
     (void)hipSetDevice(s->device);
     if (rc == XRT_OK && stats) *stats = acc;
@@ -1486,7 +1636,7 @@ int open_frame_impl(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_lig
         st0 = s->frames[slot].w.lastStream;
     } else if ((rc = multi_begin(s, slot, cam, lights, nLights, opts, d_out, &st0))) return rc;
     xrt_scene::OpenFrame &O = s->open[slot];
-    O.nGpus = n;
+    O.nGpus = n; O.balance = n > 1 && opts->balance_tiles != 0;
     O.nParts = nParts;
     O.tail = n > 1 || host_out != nullptr;
     O.hostOut = host_out; O.devOut = d_out; O.px = px; O.st0 = st0;
@@ -1505,7 +1655,7 @@ int open_frame_impl(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_lig
 int close_frame_impl(xrt_scene *s, int slot, xrt_stats *stats) {
     xrt_scene::OpenFrame &O = s->open[slot];
     int rc = XRT_OK;
-    if (O.nGpus > 1) rc = multi_end(s, slot, O.nGpus, stats);
+    if (O.nGpus > 1) rc = multi_end(s, slot, O.nGpus, stats, O.balance);
     else if (O.nParts <= 1) {
         rc = frame_finish(s, s->frames[slot], stats);
         if (rc == XRT_OK && s->frames[slot].redone && O.tail && O.hostOut && O.px) {   // the copy enqueued behind the first attempt took the wrong pixels
@@ -1986,6 +2136,53 @@ int xrt_detile_device(int32_t width, int32_t height, int32_t shard_count, const 
     if (rank_stride < 0 || (rank_stride > 0 && rank_stride < (int64_t)tpr * 512)) return fail(XRT_E_INVALID_ARG, "xrt_detile_device: rank_stride smaller than a rank's tiles");
     launch_detile(width, height, shard_count, tpr, (const uint32_t *)d_gathered, rank_stride > 0 ? rank_stride : (long long)tpr * 512,
                   (uint32_t *)d_rgba_out, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+    return XRT_OK;
+}
+
+int xrt_scene_set_tile_table(xrt_scene *scene, int32_t width, int32_t height, int32_t shard_count, int32_t tiles_per_rank, const int32_t *tile_of_slot) {
+    int rc = need_device(scene, "xrt_scene_set_tile_table");
+    if (rc != XRT_OK) return rc;
+    BusyGuard guard(scene);
+    if (!guard.owned || scene->frames[0].pending || scene->frames[1].pending) return fail(XRT_E_BUSY, "Current render operation not finished.");
+    return guarded("xrt_scene_set_tile_table", [&]() -> int {
+        HIPCHECK(hipSetDevice(scene->device));
+        if (!tile_of_slot) return install_tile_table(scene, 0, 0, 0, 0, nullptr);
+        if (width <= 0 || height <= 0 || shard_count <= 0 || tiles_per_rank <= 0) return fail(XRT_E_INVALID_ARG, "xrt_scene_set_tile_table: bad argument");
+        const int tiles = ((width + XRT_TILE_W - 1) / XRT_TILE_W) * ((height + XRT_TILE_H - 1) / XRT_TILE_H);
+        int rc2 = check_tile_table(tiles, shard_count, tiles_per_rank, tile_of_slot);
+        if (rc2 != XRT_OK) return rc2;
+        return install_tile_table(scene, width, height, shard_count, tiles_per_rank, tile_of_slot);
+    });
+}
+
+int xrt_scene_tile_costs(xrt_scene *scene, int32_t width, int32_t height, float *cost_out, int32_t reset) {
+    int rc = need_device(scene, "xrt_scene_tile_costs");
+    if (rc != XRT_OK) return rc;
+    if (width <= 0 || height <= 0 || !cost_out) return fail(XRT_E_INVALID_ARG, "xrt_scene_tile_costs: bad argument");
+    BusyGuard guard(scene);
+    if (!guard.owned || scene->frames[0].pending || scene->frames[1].pending) return fail(XRT_E_BUSY, "Current render operation not finished.");
+    const int tiles = ((width + XRT_TILE_W - 1) / XRT_TILE_W) * ((height + XRT_TILE_H - 1) / XRT_TILE_H);
+    std::fill(cost_out, cost_out + tiles, 0.0f);
+    HIPCHECK(hipSetDevice(scene->device));
+    return guarded("xrt_scene_tile_costs", [&]() -> int { return read_tile_costs(scene, width, height, cost_out, reset != 0); });
+}
+
+int xrt_balance_tiles(int32_t width, int32_t height, int32_t shard_count, const float *tile_cost, int32_t tiles_per_rank, int32_t *tile_of_slot_out) {
+    if (width <= 0 || height <= 0 || shard_count <= 0 || tiles_per_rank <= 0 || !tile_of_slot_out) return fail(XRT_E_INVALID_ARG, "xrt_balance_tiles: bad argument");
+    const int tiles = ((width + XRT_TILE_W - 1) / XRT_TILE_W) * ((height + XRT_TILE_H - 1) / XRT_TILE_H);
+    return guarded("xrt_balance_tiles", [&]() -> int { return balance_tiles_impl(tiles, shard_count, tile_cost, tiles_per_rank, tile_of_slot_out); });
+}
+
+int xrt_detile_table_device(int32_t width, int32_t height, int32_t shard_count, int32_t tiles_per_rank, const void *d_tile_of_slot, const void *d_gathered,
+                            int64_t rank_stride, void *d_rgba_out, void *stream) {
+    if (width <= 0 || height <= 0 || shard_count <= 0 || tiles_per_rank <= 0 || !d_tile_of_slot || !d_gathered || !d_rgba_out)
+        return fail(XRT_E_INVALID_ARG, "xrt_detile_table_device: bad argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(XRT_E_NO_DEVICE, "no HIP device visible"); }
+    if (rank_stride < 0 || (rank_stride > 0 && rank_stride < (int64_t)tiles_per_rank * 512)) return fail(XRT_E_INVALID_ARG, "xrt_detile_table_device: rank_stride smaller than a rank's tiles");
+    launch_detile(width, height, shard_count, tiles_per_rank, (const uint32_t *)d_gathered, rank_stride > 0 ? rank_stride : (long long)tiles_per_rank * 512,
+                  (uint32_t *)d_rgba_out, (hipStream_t)stream, (const int *)d_tile_of_slot);
     HIPCHECK(hipGetLastError());
     return XRT_OK;
 }

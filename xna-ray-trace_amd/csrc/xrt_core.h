@@ -395,6 +395,7 @@ struct RayGenParams {
     int   width, height;
     int   tilesX, tilesY;
     int   shardRank, shardCount;   // path -> tile mapping
+    const int *tileOfSlot;         // ... or this rank's row of an installed tile table (xrt_scene_set_tile_table): the tile of slot s, -1 = unused; null: round-robin
     int   samples;                 // 1, or 16 for XRT_MS_FIXED16, or 4 for one level of the adaptive quadrants
     int   quadLevel;               // adaptive supersampling (RT:215-311): -1 off; level 0 quadrants are the pixels,
     const float *quadCx, *quadCy;  // deeper ones are listed (centre per quadrant)

@@ -46,14 +46,42 @@ def _slots_to_tile(slots):
     return tile
 
 
-def pack_shard(frame, width, height, rank, world):
-    """Host mirror of what xrt_render_device writes for a shard: frame (H*W uint32) -> this rank's
-    tile-contiguous buffer (tiles_per_rank*512).  Used by the CPU (gloo) tests."""
+def balanced_table(width, height, world, tile_cost, slack=0.25):
+    """xrt_balance_tiles: (tiles_per_rank, table[world * tiles_per_rank]) -- the frame's tiles dealt longest-first by `tile_cost` (one float
+    per tile, row-major; None or all zeros: round-robin), with `slack` more slots per rank than an even deal needs.  Deterministic:
+    every rank computes the same table from the same costs (bench.py all-reduces them first)."""
     tx, ty, tpr = shard_layout(width, height, world)
+    tprb = tpr + int(np.ceil(tpr * slack))
+    table = np.full(world * tprb, -1, dtype=np.int32)
+    cost = None if tile_cost is None else np.ascontiguousarray(tile_cost, dtype=np.float32)
+    if cost is not None and cost.size != tx * ty:
+        raise ValueError("tile_cost has %d entries, the frame has %d tiles" % (cost.size, tx * ty))
+    abi.check(abi.lib().xrt_balance_tiles(width, height, world, None if cost is None else cost.ctypes.data_as(C.POINTER(C.c_float)), tprb,
+                                          table.ctypes.data_as(C.POINTER(C.c_int32))))
+    return tprb, table
+
+
+def round_robin_table(width, height, world):
+    """The default layout (tile t -> rank t % world, slot t // world) written as a table."""
+    tx, ty, tpr = shard_layout(width, height, world)
+    table = np.full(world * tpr, -1, dtype=np.int32)
+    t = np.arange(tx * ty)
+    table[(t % world) * tpr + t // world] = t
+    return tpr, table
+
+
+def pack_shard(frame, width, height, rank, world, table=None, tiles_per_rank=None):
+    """Host mirror of what xrt_render_device writes for a shard: frame (H*W uint32) -> this rank's
+    tile-contiguous buffer (tiles_per_rank*512).  Used by the CPU (gloo) tests.  table / tiles_per_rank: an installed tile table."""
+    tx, ty, tpr = shard_layout(width, height, world)
+    if table is not None:
+        tpr = int(tiles_per_rank)
     img = np.asarray(frame, dtype=np.uint32).reshape(height, width)
     out = np.zeros(tpr * 512, dtype=np.uint32)
     for slot in range(tpr):
-        t = slot * world + rank
+        t = slot * world + rank if table is None else int(table[rank * tpr + slot])
+        if t < 0:
+            continue
         if t >= tx * ty:
             break
         x0, y0 = (t % tx) * abi.TILE_W, (t // tx) * abi.TILE_H
@@ -64,16 +92,20 @@ def pack_shard(frame, width, height, rank, world):
     return out
 
 
-def detile_host(gathered, width, height, world, rank_stride=0, offset=0):
-    """Host mirror of xrt_detile_device (k_detile): rank-major gathered buffers -> H*W frame."""
+def detile_host(gathered, width, height, world, rank_stride=0, offset=0, table=None, tiles_per_rank=None):
+    """Host mirror of xrt_detile_device / xrt_detile_table_device (k_detile): rank-major gathered buffers -> H*W frame."""
     tx, ty, tpr = shard_layout(width, height, world)
+    if table is not None:
+        tpr = int(tiles_per_rank)
     flat = np.asarray(gathered, dtype=np.uint32).reshape(-1)
     stride = rank_stride or tpr * 512
     g = np.stack([flat[offset + r * stride: offset + r * stride + tpr * 512] for r in range(world)]).reshape(world, tpr, 512)
     img = np.zeros((height, width), dtype=np.uint32)
     for rank in range(world):
         for slot in range(tpr):
-            t = slot * world + rank
+            t = slot * world + rank if table is None else int(table[rank * tpr + slot])
+            if t < 0:
+                continue
             if t >= tx * ty:
                 break
             x0, y0 = (t % tx) * abi.TILE_W, (t // tx) * abi.TILE_H
@@ -108,9 +140,15 @@ def gather_frame_async(local, group=None, dst=0, recv=None):
     return wait
 
 
-def detile_device(gathered, width, height, world, out, stream=None, rank_stride=0, offset=0):
+def detile_device(gathered, width, height, world, out, stream=None, rank_stride=0, offset=0, table_dev=None, tiles_per_rank=None):
     """xrt_detile_device on HBM-resident tensors.  rank_stride / offset (pixels): rank r's tiles start at
-    offset + r * rank_stride of `gathered` (0 = contiguous) -- one gather may carry the tiles of several frames."""
+    offset + r * rank_stride of `gathered` (0 = contiguous) -- one gather may carry the tiles of several frames.
+    table_dev (an int32 tensor on the device) / tiles_per_rank: the buffers were rendered under that tile table (xrt_detile_table_device)."""
+    if table_dev is not None:
+        abi.check(abi.lib().xrt_detile_table_device(width, height, world, int(tiles_per_rank), C.c_void_p(table_dev.data_ptr()),
+                                                    C.c_void_p(gathered.data_ptr() + 4 * int(offset)), int(rank_stride), C.c_void_p(out.data_ptr()),
+                                                    C.c_void_p(stream or 0)))
+        return out
     abi.check(abi.lib().xrt_detile_device(width, height, world, C.c_void_p(gathered.data_ptr() + 4 * int(offset)), int(rank_stride),
                                           C.c_void_p(out.data_ptr()), C.c_void_p(stream or 0)))
     return out
