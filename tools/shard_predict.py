@@ -32,6 +32,28 @@ xrt = importlib.import_module("xna-ray-trace_amd")
 XGMI_LINK_GBS = 153.0
 
 
+def timed_deep(frs, reps):
+    """Frame period with len(frs) frames in flight: the render objects belong to len(frs) / 2 scene objects (two tickets each), frame i + depth - 1 is
+    enqueued before frame i is waited for."""
+    depth = len(frs)
+    for f in frs:
+        f(); f()
+    k = max(3 * depth, 2 * reps)
+    open_t = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(k):
+        open_t.append((i % depth, frs[i % depth].begin()))
+        if len(open_t) >= depth:
+            j, t = open_t.pop(0)
+            frs[j].end(t)
+    while open_t:
+        j, t = open_t.pop(0)
+        frs[j].end(t)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / k * 1e3
+
+
 def timed(frs, reps):
     """Median GPU time of a blocking frame (xrt_stats.ms_total: the latency one call sees) and the period of the same frame rendered the way
     bench.py times it: two tickets open on two render objects with an output buffer each, frame i+1 enqueued before frame i is waited for
@@ -63,6 +85,7 @@ def main():
     ap.add_argument("configs", nargs="*", default=["C4", "C5"])
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--n", default="2,4,8", help="shard counts")
+    ap.add_argument("--deep", type=int, default=0, help="also time every shard with this many frames in flight (2 per scene object: 4 = two scene objects per rank)")
     ap.add_argument("--layouts", default="balanced", help="comma list of round_robin, balanced (tiles dealt longest-first by the whole frame's tile costs: xrt_balance_tiles)")
     ap.add_argument("--out", default=os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "shard_predict.json"))
     args = ap.parse_args()
@@ -77,6 +100,14 @@ def main():
         t_whole, st_whole, p_whole = timed([tracer.PrepareDevice(whole.data_ptr()), tracer.PrepareDevice(whole2.data_ptr())], args.reps)
         cfg = {"width": W, "height": H, "t_whole_ms": round(t_whole, 4), "period_whole_ms": round(p_whole, 4), "rays_whole": int(st_whole["rays_closest"] + st_whole["rays_shadow"]),
                "rays_traversed_whole": int(st_whole["rays_traversed"]), "shards": {}}
+        extra = []   # more scene objects of the same scene on this device (frames in flight beyond two)
+        for _ in range(max(0, args.deep // 2 - 1)):
+            extra.append(xrt.configs.build_product(spec))
+        if args.deep:
+            frs = []
+            for sc, tr in [(scene, tracer)] + extra:
+                frs += [tr.PrepareDevice(torch.zeros(W * H, dtype=torch.int32, device="cuda").data_ptr()) for _ in range(2)]
+            cfg["period_whole_deep_ms"] = round(timed_deep(frs, args.reps), 4)
         tracer.TileCosts(reset=True)
         for _ in range(2):
             tracer.RenderDevice(whole.data_ptr())
@@ -90,16 +121,25 @@ def main():
             if layout == "balanced":
                 tpr, table = xrt.dist.balanced_table(W, H, n, cost)
                 tracer.SetTileTable(n, tpr, table)
+                for sc, tr in extra:
+                    tr.SetTileTable(n, tpr, table)
                 table_dev = torch.from_numpy(table).cuda()
                 loads = [float(cost[r[r >= 0]].sum()) for r in table.reshape(n, tpr)]
                 by_cost = sum(loads) / n / max(loads)
             else:
                 tracer.SetTileTable(n, tpr, None)
+                for sc, tr in extra:
+                    tr.SetTileTable(n, tpr, None)
             count = tpr * 512
             gathered = torch.zeros(n * count, dtype=torch.int32, device="cuda")
             second = torch.zeros(count, dtype=torch.int32, device="cuda")   # output of the other frame in flight
-            ts, ps, rays, trav = [], [], [], []
+            ts, ps, rays, trav, deep = [], [], [], [], []
             for r in range(n):
+                if args.deep:
+                    frs = []
+                    for sc, tr in [(scene, tracer)] + extra:
+                        frs += [tr.PrepareDevice(torch.zeros(count, dtype=torch.int32, device="cuda").data_ptr(), shard_rank=r, shard_count=n) for _ in range(2)]
+                    deep.append(timed_deep(frs, args.reps))
                 t, st, per = timed([tracer.PrepareDevice(gathered[r * count:(r + 1) * count].data_ptr(), shard_rank=r, shard_count=n),
                                     tracer.PrepareDevice(second.data_ptr(), shard_rank=r, shard_count=n)], args.reps)
                 tracer.PrepareDevice(gathered[r * count:(r + 1) * count].data_ptr(), shard_rank=r, shard_count=n)()   # (the shard's pixels for the de-tile check below)
@@ -125,6 +165,13 @@ def main():
                                      "sum_of_shards_over_whole": round(sum(ts) / t_whole, 3),
                                      "fixed_ms": {"detile_measured": round(detile_ms, 4), "gather_estimated": round(gather_ms, 4)},
                                      "predicted_with_fixed": round(t_whole / (max(ts) + fixed), 3)}
+            if deep:
+                cfg["shards"][str(n) if layout == "round_robin" else "%d_%s" % (n, layout)].update({"frames_in_flight_deep": args.deep, "period_shard_deep_ms": [round(t, 4) for t in deep],
+                    "predicted_throughput_scaling_deep": round(cfg["period_whole_deep_ms"] / max(deep), 3), "predicted_throughput_scaling_deep_with_fixed": round(cfg["period_whole_deep_ms"] / (max(deep) + fixed), 3),
+                    "predicted_throughput_scaling_deep_vs_two_in_flight_whole": round(p_whole / (max(deep) + fixed), 3)})
+                print("%s N=%d %s: %d frames in flight: whole %.3f ms, shards %s ms -> x%.2f (with fixed x%.2f; against the whole frame with two in flight x%.2f)" % (
+                    name, n, layout, args.deep, cfg["period_whole_deep_ms"], " ".join("%.3f" % t for t in deep), cfg["period_whole_deep_ms"] / max(deep),
+                    cfg["period_whole_deep_ms"] / (max(deep) + fixed), p_whole / (max(deep) + fixed)), flush=True)
             print("%s N=%d %s: blocking: whole %.3f ms, shards %s ms -> predicted x%.2f (with fixed costs x%.2f), balance %.2f | two in flight: whole %.3f ms, shards %s ms -> x%.2f (with fixed x%.2f)" % (
                 name, n, layout, t_whole, " ".join("%.3f" % t for t in ts), t_whole / max(ts), t_whole / (max(ts) + fixed), sum(ts) / n / max(ts),
                 p_whole, " ".join("%.3f" % t for t in ps), p_whole / max(ps), p_whole / (max(ps) + fixed)), flush=True)

@@ -340,10 +340,12 @@ struct xrt_scene {
     float overlapMinMs = 0.05f;  // frames at least this long run on per-context streams
     // A launch of persistent waves leaves the machine half empty while its last rays finish; a blocking single frame (what the
     // C# host's RenderInternal asks for) has no other frame to fill the gaps, so it is rendered as two halves of its tiles on
-    // two streams.  XRT_SPLIT=0 never (default), 1 frames nobody else overlaps, 2 also pipelined frames.  It paid while a launch's
-    // waves were alive 55-60 % of its duration (C4 13.3 -> 10.9 ms); with 64-ray batches and whole-wave refills they are alive
-    // 75-95 % and the second set of launches costs what the overlap gains (C3 2.74 vs 2.91 ms, C4 7.1 vs 6.9, C5 7.9 vs 8.0).
-    int splitMode = 0, splitParts = 2;
+    // two streams.  XRT_SPLIT=0 never, 1 frames nobody else overlaps (default), 2 also pipelined frames.  It paid while a launch's
+    // waves were alive 55-60 % of its duration (C4 13.3 -> 10.9 ms), did not in rounds 2 and 3 (the second set of launches cost what the
+    // overlap gained: C3 2.74 vs 2.91 ms, C4 7.1 vs 6.9, C5 7.9 vs 8.0), and pays again now that the kernels are faster and a launch's tail
+    // is a larger share of it (round 4, one box: C3 1.95 -> 1.72 ms per blocking frame, C4 4.26 -> 4.13, C5 4.48 -> 4.43; three or four
+    // bands no better; profiles/r04/frame_split.txt).
+    int splitMode = 1, splitParts = 2;
     bool launchEvents = false;   // XRT_LAUNCH_EVENTS=1: single-chunk frames time their traversal launches with events on the dispatch packets, too
     int maxStampRows = MAX_STAMP_ROWS;   // XRT_STAMP_ROWS=<n> (tests): launches of a frame beyond the n-th carry events instead
     bool adaptiveFastOk = true;  // adaptive frames are enqueued whole (level buffers sized optimistically) until a level overflows; XRT_ADAPTIVE_FAST=0
