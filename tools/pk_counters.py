@@ -20,6 +20,8 @@ torch.cuda.synchronize()
 lib.xrt_debug_packet_counters(buf, 1)
 ticks = (C.c_ulonglong * 32)()
 lib.xrt_debug_packet_ticks(ticks, 1)
+worst = (C.c_ulonglong * 16)()
+lib.xrt_debug_packet_worst(worst, 1)
 st = fr()
 torch.cuda.synchronize()
 lib.xrt_debug_packet_counters(buf, 1)
@@ -37,3 +39,6 @@ tot = sum(ticks)
 for b in range(32):
     if ticks[b]:
         print("    %8.1f .. %8.1f us  %9d packets  %5.1f %%   (their time, at the bucket's middle: %.1f wave-ms)" % (2 ** b / 100.0, 2 ** (b + 1) / 100.0, ticks[b], 100.0 * ticks[b] / tot, ticks[b] * 1.5 * 2 ** b / 1e5))
+lib.xrt_debug_packet_worst(worst, 1)
+print("  the packet that took longest (any launch of the frame): %.1f us; packet %d of %d (segment %d), %d valid rays: %d mesh walks, %d blocks entered, %d child visits, %d triangle steps, %d run box tests" % (
+    worst[0] / 100.0, worst[1], worst[9], worst[2], worst[8], worst[3], worst[4], worst[5], worst[6], worst[7]))

@@ -89,9 +89,9 @@ struct PacketArgs {
     const int *nDev2 = nullptr;
     int nMul2 = 0, nCap2 = 0;
     // Cost of the frame's tiles (xrt.h xrt_scene_tile_costs): every packet adds the device-clock ticks it took to the tile of its first ray --
-    // tileCost[path >> tileShift], path = pathOf1[ray] (or slotOf1[ray / nL1].path, or the ray's index) for the first segment, slotOf2[ray / nL2].path for the second.
+    // tileCost[(tileBase + path) >> tileShift], path = pathOf1[ray] (or slotOf1[ray / nL1].path, or the ray's index) for the first segment, slotOf2[ray / nL2].path for the second.
     unsigned *tileCost = nullptr;
-    int tileShift = 9, nL1 = 1, nL2 = 1;
+    int tileShift = 9, nL1 = 1, nL2 = 1, tileBase = 0;   // (tileBase: first path of this launch's part of the frame)
     const int *pathOf1 = nullptr;
     const SlotRec *slotOf1 = nullptr;   // (a launch whose FIRST segment is shadow rays)
     const SlotRec *slotOf2 = nullptr;

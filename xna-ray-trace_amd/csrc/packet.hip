@@ -52,9 +52,16 @@ constexpr int PK_SGPRS = 112;        // SGPR allocation the kernel may reach (ch
 
 // make variant NAME=cnt DEFS=-DXRT_PK_COUNTERS: event counts of the shared walk (development aid; tools/pk_counters.py reads them through
 // xrt_debug_packet_counters, which exists only in such a build)
+#if defined(XRT_PK_COUNTERS) && !defined(XRT_PK_TICKS)
+#define XRT_PK_TICKS   // (make variant NAME=ticks DEFS=-DXRT_PK_TICKS: only the packets' durations -- histogram and the longest one -- at the product build's speed; tools/pk_ticks.py)
+#endif
+#ifdef XRT_PK_TICKS
+__device__ unsigned long long g_pkWorst[16];   // the packet that took longest: ticks, work item, segment, its walks / blocks / child visits / triangle steps / run tests, valid rays, packets of its launch
+__device__ unsigned long long g_pkTicks[32];   // packets by duration: bucket b counts packets of 2^b .. 2^(b+1) - 1 ticks of the 100 MHz device clock (xrt_debug_packet_ticks)
+#endif
 #ifdef XRT_PK_COUNTERS
 __device__ unsigned long long g_pkCounters[16];
-__device__ unsigned long long g_pkTicks[32];   // packets by duration: bucket b counts packets of 2^b .. 2^(b+1) - 1 ticks of the 100 MHz device clock (xrt_debug_packet_ticks)
+__device__ unsigned g_pkCur[8 * 65536];         // (per resident wave: this packet's running totals; indexed by a wave id below 65536)
 #define PKC(i) (pkc[i]++)
 #else
 #define PKC(i) ((void)0)
@@ -380,6 +387,10 @@ __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const
     }
 #ifdef XRT_PK_COUNTERS
     if (lane == 0) for (int i = 0; i < 16; i++) if (pkc[i]) atomicAdd(&g_pkCounters[i], (unsigned long long)pkc[i]);
+    if (lane == 0) {
+        unsigned *cur = g_pkCur + 8 * ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 65535);
+        cur[0] += pkc[0]; cur[1] += pkc[1]; cur[2] += pkc[2]; cur[3] += pkc[8]; cur[4] += pkc[6];
+    }
 #endif
 }
 
@@ -519,7 +530,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
         }
         // ---- the packet's 64 rays ------------------------------------------------------------------------------------
         KA.fresh();
-#ifdef XRT_PK_COUNTERS
+#ifdef XRT_PK_TICKS
         const bool costed = true;
 #else
         const bool costed = KA.args()->tileCost != nullptr;
@@ -705,8 +716,23 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
         }
         if (costed) {   // the tile this packet's first ray belongs to pays for the packet (scheduling feedback for the next frame's tile table)
             const unsigned dt = (unsigned)(wall_clock64() - tPacket);
-#ifdef XRT_PK_COUNTERS
+#ifdef XRT_PK_TICKS
             if (lane == 0) atomicAdd(&g_pkTicks[dt ? 31 - __builtin_clz(dt) : 0], 1ull);
+            {
+                const unsigned long long nv = __popcll(__ballot(valid));
+                if (lane == 0) {
+#ifdef XRT_PK_COUNTERS
+                    unsigned *cur = g_pkCur + 8 * ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 65535);
+#else
+                    unsigned cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+                    if ((unsigned long long)dt > atomicMax(&g_pkWorst[0], (unsigned long long)dt)) {
+                        g_pkWorst[1] = (unsigned long long)pk; g_pkWorst[2] = seg2 ? 1ull : 0ull; g_pkWorst[3] = cur[0]; g_pkWorst[4] = cur[1]; g_pkWorst[5] = cur[2];
+                        g_pkWorst[6] = cur[3]; g_pkWorst[7] = cur[4]; g_pkWorst[8] = nv; g_pkWorst[9] = (unsigned long long)nPk;
+                    }
+                    for (int i = 0; i < 8; i++) cur[i] = 0;
+                }
+            }
             if (lane == 0 && KA.args()->tileCost) {
 #else
             if (lane == 0) {
@@ -716,7 +742,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k
                 const SlotRec *const sl = seg2 ? a->slotOf2 : a->slotOf1;
                 const int *const po = a->pathOf1;
                 const int path = sl ? sl[first / (seg2 ? a->nL2 : a->nL1)].path : (po ? po[first] : first);
-                atomicAdd(a->tileCost + (path >> a->tileShift), dt);
+                atomicAdd(a->tileCost + ((a->tileBase + path) >> a->tileShift), dt);
             }
         }
     }
@@ -741,12 +767,19 @@ int packet_blocks_per_cu(int mode) {
     return nb > 8 ? 8 : nb;
 }
 
-#ifdef XRT_PK_COUNTERS
+#ifdef XRT_PK_TICKS
+extern "C" int xrt_debug_packet_worst(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pkWorst), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pkWorst), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
 extern "C" int xrt_debug_packet_ticks(unsigned long long *out32, int reset) {
     if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_pkTicks), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pkTicks), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
+#endif
+#ifdef XRT_PK_COUNTERS
 extern "C" int xrt_debug_packet_counters(unsigned long long *out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pkCounters), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pkCounters), z, sizeof(z)) != hipSuccess) return -1; }

@@ -777,7 +777,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // Tile costs (xrt.h xrt_scene_tile_costs): the packets of plain one-chunk frames add their device-clock ticks to the tile of their first
     // ray.  The words belong to the scene (both frame contexts add to them); a frame of another geometry or tile table starts them afresh.
     unsigned *tileCostDev = nullptr;
-    if (fast && !adaptive && !heap && nParts == 1 && s->packetOk) {
+    if (fast && !adaptive && !heap && s->packetOk && framePaths < (1LL << 31)) {
         if ((rc = s->tileCost.ensure((size_t)myTiles))) return rc;
         bool same = s->costW == g.width && s->costH == g.height && (long long)s->costTiles.size() == myTiles;
         for (long long sl = 0; same && sl < myTiles; sl++) { const long long t = tile_of_slot(sl); same = s->costTiles[(size_t)sl] == (t < totalTiles ? (int)t : -1); }
@@ -933,8 +933,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                 PacketArgs PA;
                 PA.rays = I.rays; PA.hits = I.hits; PA.flags = I.flags; PA.index = I.index; PA.nDev = I.nDev; PA.nMul = I.nMul; PA.n = I.n; PA.nCap = I.nCap;
                 if (I2) { PA.rays2 = I2->rays; PA.hits2 = I2->hits; PA.flags2 = I2->flags; PA.nDev2 = I2->nDev; PA.nMul2 = I2->nMul; PA.nCap2 = I2->nCap; }
-                if (tileCostDev && pathBase == 0) {   // which tile pays for a packet: the path of its first ray (closest-hit rays: the path list; shadow rays: their hit's slot record)
-                    PA.tileCost = tileCostDev; PA.tileShift = 9 + (gp.samples == 16 ? 4 : (gp.samples == 4 ? 2 : 0));
+                if (tileCostDev) {   // which tile pays for a packet: the path of its first ray (closest-hit rays: the path list; shadow rays: their hit's slot record)
+                    PA.tileCost = tileCostDev; PA.tileBase = (int)pathBase; PA.tileShift = 9 + (gp.samples == 16 ? 4 : (gp.samples == 4 ? 2 : 0));
                     if (&I == &B) { PA.slotOf1 = slotOf[prv]; PA.nL1 = nL; }
                     else PA.pathOf1 = k == 0 ? W.index0.p : paths[cur];
                     if (I2) { PA.slotOf2 = slotOf[prv]; PA.nL2 = nL; }
