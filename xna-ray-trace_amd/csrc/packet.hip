@@ -48,7 +48,10 @@ constexpr int PK_SFRAME_WORDS = 4;   // scene block, pending children, lanes (2)
 #endif
 constexpr int PK_QUEUES = XRT_PK_QUEUES;   // interleaved heads of the packet queue (PacketArgs::queue points at PACKET_QUEUE_WORDS zeroed words)
 static_assert(PK_QUEUES >= 1 && PK_QUEUES <= PACKET_QUEUE_HEADS, "the host zeroes PACKET_QUEUE_WORDS heads per packet launch");
-constexpr int PK_SGPRS = 112;        // SGPR allocation the kernel may reach (checked against the ISA in tests/test_numerics_contract.py)
+#ifndef PK_SINGLE_WAVES
+#define PK_SINGLE_WAVES 6             // waves per SIMD the one-body variants are compiled for (7: make variant DEFS=-DPK_SINGLE_WAVES=7 -- 96 SGPRs, 72 VGPRs)
+#endif
+constexpr int PK_SGPRS = PK_SINGLE_WAVES >= 7 ? 96 : 112;   // SGPR allocation the kernel may reach (checked against the ISA in tests/test_numerics_contract.py)
 
 // make variant NAME=cnt DEFS=-DXRT_PK_COUNTERS: event counts of the shared walk (development aid; tools/pk_counters.py reads them through
 // xrt_debug_packet_counters, which exists only in such a build)
@@ -452,7 +455,7 @@ struct PkKernarg {
 #define PK_SCENE_WAVES 5   // waves per SIMD the scene variant is compiled for: 96 VGPRs + 44 bytes of scratch per lane, touched per packet (not per step): C3 -5 %, C4 -7.5 % against 4 waves at 106 VGPRs (profiles/r03/packet_scene_five_waves.txt; at 111 VGPRs the same switch lost)
 #endif
 template <int M>
-__global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : 1) void k_packet(const float *__restrict__ pblocks, const float *__restrict__ refT,
+__global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGLE_WAVES >= 7 ? 7 : 1)) __attribute__((amdgpu_num_sgpr(PK_SGPRS))) void k_packet(const float *__restrict__ pblocks, const float *__restrict__ refT,
                                                 const float *__restrict__ lrec, const MeshRec *__restrict__ meshes,
                                                 const f4 *__restrict__ snodes, const f4 *__restrict__ scull, const ObjRec *__restrict__ objects,
                                                 const int *__restrict__ objMesh, SceneView S, PacketArgs A) {
