@@ -513,6 +513,9 @@ def main():
                        "rays_closest_per_frame": int(st["rays_closest"]) if world == 1 else None, "rays_shadow_per_frame": int(st["rays_shadow"]) if world == 1 else None,
                        "rays_traversed_per_frame": int(trav_frame),
                        "rays_answered_by_raygen_per_frame": int(rays_frame - trav_frame),
+                       # ... and of the traversed ones, the mesh queries the mesh's normal box answers (every triangle faces away from the ray, RE:48-51:
+                       # the shadow rays and reflections of this terrain): counted by the untimed counting pass (xrt_stats.mesh_queries_facing_away)
+                       "mesh_queries_answered_by_normal_box_per_frame": int(st.get("mesh_queries_facing_away", 0)) if world == 1 else None,
                        "parallelism": ("image tiles 64x8 x%d (xrt_render_opts.balance_tiles: dealt by the previous frame's tile costs), one process: xrt_render_opts.n_gpus (in-library RCCL send/recv gather)" % args.gpus) if in_library
                                       else ("image tiles 64x8 x%d, dealt longest-first by the previous frames' tile costs (xrt_balance_tiles; balance by cost %.3f, round-robin %.3f)"
                                             % (world, res["tile_balance"]["by_cost_table"], res["tile_balance"]["by_cost_round_robin"]) if res.get("tile_balance")

@@ -1111,6 +1111,12 @@ def test_full_size_c4_c5_as_specified(xrt, name):
     assert (want & 0xffffff).any()
     for k in ("rays_closest", "rays_shadow", "shaded_hits", "pixels"):
         assert st[k] == o_st[k], (k, st[k], o_st[k])
+    if name == "C5":   # the counting pass also says how many mesh queries the mesh's normal box answers: most shadow rays and reflections of this terrain
+        tracer.collect_stats = True
+        st_c = dict(tracer.RenderDevice(whole.data_ptr()))
+        tracer.collect_stats = False
+        assert st_c["mesh_queries"] == o_st["mesh_queries"] and 0.4 * st_c["mesh_queries"] < st_c["mesh_queries_facing_away"] < st_c["mesh_queries"]
+        assert np.array_equal(whole.cpu().numpy().view(np.uint32), want)
     again = torch.zeros_like(whole)
     tracer.RenderDevice(again.data_ptr())
     assert torch.equal(again, whole)

@@ -134,7 +134,9 @@ def test_packet_kernel_resources(isa):
     occupancy API over-reports resident blocks in the 81-112 SGPR range (MI355X_MICROARCH.md, Correctness boundaries)."""
     usage = open(os.path.join(CSRC, "packet.usage.txt")).read()
     src = open(os.path.join(CSRC, "packet.hip")).read()
-    budget = int(re.search(r"constexpr int PK_SGPRS = (\d+);", src).group(1))
+    waves = int(re.search(r"#define PK_SINGLE_WAVES (\d+)", src).group(1))
+    hi, lo = re.search(r"constexpr int PK_SGPRS = PK_SINGLE_WAVES >= 7 \? (\d+) : (\d+);", src).groups()
+    budget = int(hi) if waves >= 7 else int(lo)
     blocks = re.findall(r"Function Name: (\S*k_packet\S*).*?TotalSGPRs: (\d+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", usage, flags=re.S)
     assert len(blocks) == 3   # MODE_SCENE (0), MODE_MESH (1), MODE_SINGLE (2)
     for name, sgprs, vgprs, scratch in blocks:

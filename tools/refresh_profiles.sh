@@ -3,14 +3,14 @@
 #   1. separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ wave/VALU set | SQ scalar set) of the bench of every config -> tools/pmc_collect.py ->
 #      profiles/pmc_traversal.json (stamped with the kernel sources' hash; bench.py's roofline block reads it)
 #   2. rocprofv3 --kernel-trace --stats of the default `python3 bench.py` command (the bench line is kept next to it)
-# Usage: tools/refresh_profiles.sh [configs...]   (default: C5 C3 C2 C4)
+# Usage: tools/refresh_profiles.sh [configs...]   (default: C5 C3 C2 C4 G1)
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/final
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CFGS=${@:-C5 C3 C2 C4}
+CFGS=${@:-C5 C3 C2 C4 G1}
 SC="SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES"
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU"
 for c in $CFGS; do

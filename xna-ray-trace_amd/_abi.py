@@ -80,7 +80,8 @@ class xrt_stats(C.Structure):
         "rays_closest", "rays_shadow", "hits_closest", "hits_shadow", "scene_node_tests", "instance_visits",
         "mesh_aabb_tests", "mesh_queries", "node_tests", "leaf_refs", "tri_tests", "shaded_hits", "pixels",
         "algorithmic_bytes")] + [("ms_total", C.c_double), ("ms_intersect", C.c_double),
-                                 ("intersect_launches", C.c_uint32), ("pieces", C.c_uint32), ("rays_traversed", C.c_uint64)]
+                                 ("intersect_launches", C.c_uint32), ("pieces", C.c_uint32), ("rays_traversed", C.c_uint64),
+                                 ("mesh_queries_facing_away", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

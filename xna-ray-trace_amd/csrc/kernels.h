@@ -103,7 +103,7 @@ int  packet_blocks_per_cu(int mode);
 void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 
 // reference-work counters accumulated on the device (same order as the head of xrt_stats)
-enum { C_RAYS = 0, C_HITS, C_SCENE_NODES, C_INSTANCES, C_MESH_AABB, C_MESH_QUERIES, C_NODES, C_REFS, C_TRIS, C_COUNT };
+enum { C_RAYS = 0, C_HITS, C_SCENE_NODES, C_INSTANCES, C_MESH_AABB, C_MESH_QUERIES, C_NODES, C_REFS, C_TRIS, C_MESH_AWAY, C_COUNT };   // (C_MESH_AWAY: not a counter of the reference, see xrt_stats.mesh_queries_facing_away)
 
 constexpr int FLAG_MISS = 0, FLAG_HIT = 1, FLAG_TRANSPARENT = 2;
 

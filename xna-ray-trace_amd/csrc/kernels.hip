@@ -426,6 +426,8 @@ __device__ void count_mesh(const SceneView &S, const RayPre &r, int mesh, int ig
         }
     };
     if (mr.rootBlock < 0) { count_leaf(mr.rootRef, mr.rootCount, key); return; }
+    // (how many of the queries the reference walks below are answered by the mesh's normal box on this library: every triangle faces away)
+    if (all_back_facing(f4{mr.nbMin[0], mr.nbMin[1], mr.nbMin[2], mr.nbMin[3]}, f4{mr.nbMax[0], mr.nbMax[1], mr.nbMax[2], mr.nbMax[3]}, r.d)) c[C_MESH_AWAY]++;
     // explicit DFS over every child of every hit interior node (the reference does not prune): stack of
     // (block, pending mask) words plus the parent box per level
     struct Frame { int blk, mask; v3 bmin, half; };

@@ -473,6 +473,7 @@ void fill_stats(xrt_stats *st, const unsigned long long *c /* 2*C_COUNT: closest
     st->instance_visits = a[C_INSTANCES] + b[C_INSTANCES];
     st->mesh_aabb_tests = a[C_MESH_AABB] + b[C_MESH_AABB];
     st->mesh_queries = a[C_MESH_QUERIES] + b[C_MESH_QUERIES];
+    st->mesh_queries_facing_away = a[C_MESH_AWAY] + b[C_MESH_AWAY];
     st->node_tests = a[C_NODES] + b[C_NODES];
     st->leaf_refs = a[C_REFS] + b[C_REFS];
     st->tri_tests = a[C_TRIS] + b[C_TRIS];
@@ -1570,6 +1571,7 @@ void add_stats(xrt_stats &acc, const xrt_stats &st, bool first) {
     if (first) acc.intersect_launches = st.intersect_launches;
     acc.pieces += 1;
     acc.rays_traversed += st.rays_traversed;
+    acc.mesh_queries_facing_away += st.mesh_queries_facing_away;
 }
 
 int multi_end(xrt_scene *s, int slot, int n, xrt_stats *stats, bool balance) {
