@@ -89,6 +89,8 @@ def intersect_bytes(st):
     return st["algorithmic_bytes"] - 80 * st["shaded_hits"] - 4 * st["pixels"]
 
 
+_LONGEST = [0.0, 0]   # xrt_stats.ms_intersect_longest summed over the frames of the last timed region, and their number
+
 GATHER_EVERY = 4   # N > 1: one RCCL gather moves the tiles of this many frames (the collective's fixed cost is ~a frame's GPU time)
 
 
@@ -129,6 +131,7 @@ def time_frames_sharded(tracer, outs, steps, warmup, rank, world, width, height,
         st = renders[(j // M) % 2][j % M].end(t)   # blocking: this rank's tiles of frame j are in HBM
         acc[0] += st["ms_intersect"]
         acc[1] += st["intersect_launches"]
+        _LONGEST[0] += st.get("ms_intersect_longest", 0.0); _LONGEST[1] += 1
         if j % M == M - 1:
             flush((j // M) % 2, M)
         return j
@@ -156,6 +159,7 @@ def time_frames_sharded(tracer, outs, steps, warmup, rank, world, width, height,
     dist.barrier()
     torch.cuda.synchronize()
     acc[0], acc[1] = 0.0, 0
+    _LONGEST[0], _LONGEST[1] = 0.0, 0
     t0 = time.perf_counter()
     for i in range(steps):
         frame(i)
@@ -182,6 +186,7 @@ def time_frames(tracer, outs, steps, warmup, rank, world, width, height, gathere
         st = renders[j % 2].end(t)                 # blocking: frame j is in HBM
         acc[0] += st["ms_intersect"]
         acc[1] += st["intersect_launches"]
+        _LONGEST[0] += st.get("ms_intersect_longest", 0.0); _LONGEST[1] += 1
 
     def frame(i):
         open_frames.append((renders[i % 2].begin(), i))   # host side of frame i overlaps the GPU side of frame i-1
@@ -196,6 +201,7 @@ def time_frames(tracer, outs, steps, warmup, rank, world, width, height, gathere
     drain()
     torch.cuda.synchronize()
     acc[0], acc[1] = 0.0, 0
+    _LONGEST[0], _LONGEST[1] = 0.0, 0
     t0 = time.perf_counter()
     for i in range(steps):
         frame(i)
@@ -249,6 +255,7 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
             balance = {"by_cost_round_robin": round(float(rr.mean() / rr.max()), 4), "by_cost_table": round(float(loads.mean() / loads.max()), 4), "tiles_per_rank": int(tprb)}
             outs = [torch.zeros(tprb * 512, dtype=torch.int32, device="cuda") for _ in range(2)]
     dt, ms_int, launches = time_frames(tracer, outs, steps, warmup, rank, world, W, H, final, table_dev=table_dev, tiles_per_rank=tprb)
+    ms_longest = _LONGEST[0] / max(_LONGEST[1], 1)   # the frame's longest traversal launch, averaged over the timed frames
     torch.cuda.synchronize()
     mem2 = torch.cuda.mem_get_info()[0]   # after two frames in flight: both frame contexts hold their work buffers
     # the pixels the timed loop's own render objects produced last (read back after the timed region): what main() compares with the oracle
@@ -262,7 +269,7 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
     rays = st0["rays_closest"] + st0["rays_shadow"]
     device_memory = {"scene_GB": round((mem0 - mem1) / 1e9, 3), "frame_work_buffers_GB": round((mem1b - mem2) / 1e9, 3),
                      "what": "hipMemGetInfo differences: scene arrays after the build; work buffers of BOTH frame contexts (two frames in flight) after the timed frames, output buffers excluded"}
-    res = dict(tile_balance=balance, rays=rays, seconds=dt, ms_intersect=ms_int, launches=launches, stats=st0, build_s=build_s, width=W, height=H, last_frame=last_frame, device_memory=device_memory,
+    res = dict(ms_longest=ms_longest, tile_balance=balance, rays=rays, seconds=dt, ms_intersect=ms_int, launches=launches, stats=st0, build_s=build_s, width=W, height=H, last_frame=last_frame, device_memory=device_memory,
                tris=sum(m[0].ntri for m in spec.meshes), instances=len(spec.objects), overlapped=False)
     if world == 1 and dt / max(steps, 1) * 1e3 >= 0.04:
         # The frames of the timed region overlapped pairwise on the GPU (two streams), so a launch's duration includes time
@@ -271,7 +278,7 @@ def run_config(name, scale, steps, warmup, rank, local_rank, world, with_stats=T
         side = torch.cuda.Stream()
         k = max(2, min(steps, 5))
         dt_s, ms_s, l_s = time_frames(tracer, outs, k, 1, rank, world, W, H, final, stream=side.cuda_stream)
-        res.update(overlapped=True, serial_seconds=dt_s, serial_steps=k, serial_ms_intersect=ms_s, serial_launches=l_s)
+        res.update(overlapped=True, serial_seconds=dt_s, serial_steps=k, serial_ms_intersect=ms_s, serial_launches=l_s, serial_ms_longest=_LONGEST[0] / max(_LONGEST[1], 1))
     return res, spec
 
 
@@ -362,7 +369,42 @@ def parity_block(last_frame, oracle_rgba, rows, width):
             "parity_what": "rows of the LAST frame of the timed region (pipelined, two in flight) vs the CPU oracle's render of the same rows, RGBA8 bit for bit"}
 
 
-def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_frame, serial=None):
+def dominant_launch_block(pmc, ms_longest):
+    """The launch class that takes most of a frame's traversal time (on every configuration here: the launch of the primary rays), from the PMC passes
+    grouped by the launches' position in the frame (tools/pmc_collect.py `launch_classes`) over the LIVE duration of the frame's longest traversal
+    launch (xrt_stats.ms_intersect_longest, averaged over the timed frames)."""
+    classes = pmc.get("launch_classes") if pmc else None
+    if not classes or not ms_longest or ms_longest <= 0:
+        return None
+    need = ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES")
+    cand = [(c["SQ_BUSY_CYCLES"], i, c) for i, c in enumerate(classes) if all(k in c for k in need)]
+    if not cand:
+        return None
+    _, idx, c = max(cand)
+    t = ms_longest * 1e-3
+    issue = c["SQ_INSTS_VALU"] * 64.0 / t / 1e12
+    useful = c["SQ_THREAD_CYCLES_VALU"] / t / 1e12
+    out = {"launch_position_in_frame": idx, "ms_per_launch": round(ms_longest, 5), "bound": "valu",
+           "valu_issue_frac": round(issue / VALU_PEAK_TLANEOPS, 4), "valu_useful_frac": round(useful / VALU_PEAK_TLANEOPS, 4),
+           "lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0), 3), "valu_instructions": int(c["SQ_INSTS_VALU"])}
+    cyc = t * CU_CYCLES_PER_S
+    fr = {"valu": out["valu_issue_frac"]}
+    for key, name, peak in (("salu", "SQ_INSTS_SALU", SALU_PEAK_IPC), ("branch", "SQ_INSTS_BRANCH", BRANCH_PEAK_IPC), ("smem", "SQ_INSTS_SMEM", SMEM_PEAK_IPC)):
+        if name in c:
+            out[key + "_frac"] = round(c[name] / cyc / peak, 4)
+            fr[key] = out[key + "_frac"]
+    if "FETCH_SIZE_KB" in c and "WRITE_SIZE_KB" in c:
+        out["traffic"] = int((2.0 * c["FETCH_SIZE_KB"] + c["WRITE_SIZE_KB"]) * 1024)
+        out["hbm_frac"] = round(out["traffic"] / t / 1e9 / HBM_PEAK_GBS, 4)
+        fr["hbm"] = out["hbm_frac"]
+    if c.get("SQ_WAVE_CYCLES"):
+        out["waves_waiting_frac"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)
+    out["bound"] = max(fr, key=fr.get)
+    out["frac"] = fr[out["bound"]]
+    return out
+
+
+def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_frame, serial=None, ms_longest=None):
     """Three fractions for the dominant kernel over the same live launch time:
       algorithmic  the REFERENCE algorithm's bytes (un-pruned node / reference / triangle counts) / time / 8 TB/s -- what the
                    north star's target is quoted in; the GPU prunes and caches, so this is an equivalent rate, not a physical one (may exceed 1);
@@ -420,6 +462,17 @@ def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_fra
                    "SURVEY 8d equivalent rate of the un-pruned reference algorithm, not a physical fraction; durations = every launch of the timed region "
                    "times itself on the device clock, first wave's start to last wave's end (events on the dispatch packets cost ~5 us a launch; "
                    "rocprofv3's dispatch-level durations are ~4 us per launch longer); PMC = rocprofv3 passes of this build (profiles/), per launch"}
+    # The traversal launches of a frame are of different kinds (round 4: the launch of a terrain's shadow rays and reflections mostly ends at the
+    # mesh's normal box), so the averages above describe no launch in particular: `dominant_launch` is the class that takes most of the time.
+    dom = dominant_launch_block(pmc, ms_longest)
+    if dom:
+        out["dominant_launch"] = dom
+        out["all_launches"] = {"bound": out["bound"], "frac": out["frac"], "useful_frac": out["useful_frac"], "lane_utilisation": out["lane_utilisation"],
+                               "ms_per_launch": out["ms_per_launch"], "what": "the same quantities averaged over every traversal launch of a frame"}
+        out["bound"], out["frac"] = dom["bound"], dom["frac"]
+        out["achieved"], out["peak"], out["unit"] = (round(dom["valu_issue_frac"] * VALU_PEAK_TLANEOPS, 2), round(VALU_PEAK_TLANEOPS, 2), "Tlane-op/s") if dom["bound"] == "valu" else (out["achieved"], out["peak"], out["unit"])
+        out["useful_frac"], out["lane_utilisation"] = dom["valu_useful_frac"], dom["lane_utilisation"]
+        out["traffic"] = dom.get("traffic", out["traffic"])
     if serial:
         if pmc and serial.get("ms_per_launch"):   # the same counters over the duration of a launch that has the GPU to itself
             ts = serial["ms_per_launch"] * 1e-3
@@ -429,6 +482,10 @@ def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_fra
             for key, peak in (("salu", SALU_PEAK_IPC), ("branch", BRANCH_PEAK_IPC), ("smem", SMEM_PEAK_IPC)):
                 if key in fr:
                     serial["fractions"][key] = round(fr[key]["instructions_per_launch"] / (ts * CU_CYCLES_PER_S) / peak, 4)
+        if dom and serial.get("ms_longest"):
+            d2 = dominant_launch_block(pmc, serial["ms_longest"])
+            if d2:
+                serial["dominant_launch"] = {k: d2[k] for k in ("ms_per_launch", "bound", "frac", "valu_issue_frac", "valu_useful_frac") if k in d2}
         out["serialised"] = serial
     return out
 
@@ -502,7 +559,8 @@ def main():
             ms_l = res["serial_ms_intersect"] / l_s
             ach_s = intersect_bytes(st) * res["serial_steps"] / l_s / (ms_l * 1e-3) / 1e9 if ms_l > 0 else 0.0
             serial = {"what": "the timed frames overlapped pairwise on two streams, so ms_per_launch includes time shared with the other frame; this is the same launch with the GPU to itself",
-                      "ms_per_launch": round(ms_l, 5), "algorithmic_achieved": round(ach_s, 2), "ms_per_step": round(res["serial_seconds"] / res["serial_steps"] * 1e3, 4)}
+                      "ms_per_launch": round(ms_l, 5), "algorithmic_achieved": round(ach_s, 2), "ms_per_step": round(res["serial_seconds"] / res["serial_steps"] * 1e3, 4),
+                      "ms_longest": res.get("serial_ms_longest")}
         line = {
             "metric": metric if args.scale == 1.0 else "Mrays/sec (scaled image, not a benchmark)",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": args.gpus if in_library else world, "steps": args.steps, "warmup": args.warmup,
@@ -521,7 +579,8 @@ def main():
                                             % (world, res["tile_balance"]["by_cost_table"], res["tile_balance"]["by_cost_round_robin"]) if res.get("tile_balance")
                                             else "image tiles 64x8 round-robin x%d" % world), "scene_build_s": round(res["build_s"], 3), "device_memory": res["device_memory"]},
             "Mrays_per_s_traversed": round(trav_frame * args.steps / seconds / 1e6, 3),
-            "roofline": roofline_block(args.config if (world == 1 and not in_library) else "(N > 1: no PMC pass)", bytes_per_launch, ms_per_launch, launches // max(args.steps, 1), serial),
+            "roofline": roofline_block(args.config if (world == 1 and not in_library) else "(N > 1: no PMC pass)", bytes_per_launch, ms_per_launch, launches // max(args.steps, 1), serial,
+                                       ms_longest=res.get("ms_longest")),
         }
         line["roofline"]["traversed_value"] = line["Mrays_per_s_traversed"]   # Mrays/s of the queries that reach the traversal kernels (`value` counts the primary rays k_raygen answers too)
         solo = world == 1 and not in_library   # the side measurements below are single-GPU figures
@@ -591,11 +650,12 @@ def main():
                     r2, _ = run_config(name, 1.0, k, 3, 0, local_rank, 1)   # (enough frames for the fill and drain of two in flight not to show in the period)
                     # per-launch figures from the serialised pass when the timed frames overlapped
                     ms_i, l2, kk = (r2["serial_ms_intersect"], max(r2["serial_launches"], 1), r2["serial_steps"]) if r2["overlapped"] else (r2["ms_intersect"], max(r2["launches"], 1), k)
-                    rb = roofline_block(name, intersect_bytes(r2["stats"]) * kk / l2, ms_i / l2, l2 // max(kk, 1))
+                    rb = roofline_block(name, intersect_bytes(r2["stats"]) * kk / l2, ms_i / l2, l2 // max(kk, 1),
+                                        ms_longest=r2.get("serial_ms_longest") if r2["overlapped"] else r2.get("ms_longest"))
                     other[name] = {"workload": WORKLOADS[name], "Mrays_per_s": round(r2["rays"] * k / r2["seconds"] / 1e6, 2),
                                    "ms_per_step": round(r2["seconds"] / k * 1e3, 3), "rays_per_frame": int(r2["rays"]),
                                    "frames_overlap": bool(r2["overlapped"]), "ms_per_launch": round(ms_i / l2, 4),
-                                   "bound": rb["bound"], "frac": rb["frac"], "fractions": rb["fractions"], "scene_build_s": round(r2["build_s"], 2)}
+                                   "bound": rb["bound"], "frac": rb["frac"], "dominant_launch": rb.get("dominant_launch"), "fractions": rb["fractions"], "scene_build_s": round(r2["build_s"], 2)}
                     if r2["overlapped"]:
                         other[name]["ms_per_step_serialised"] = round(r2["serial_seconds"] / kk * 1e3, 3)
                 except Exception as e:   # a side measurement must not take the headline down

@@ -57,7 +57,7 @@ namespace RayTraceProject.Native
     {
         public ulong raysClosest, raysShadow, hitsClosest, hitsShadow, sceneNodeTests, instanceVisits, meshAabbTests, meshQueries,
                      nodeTests, leafRefs, triTests, shadedHits, pixels, algorithmicBytes;
-        public double msTotal, msIntersect; public uint intersectLaunches, pieces; public ulong raysTraversed, meshQueriesFacingAway;
+        public double msTotal, msIntersect; public uint intersectLaunches, pieces; public ulong raysTraversed; public double msIntersectLongest; public ulong meshQueriesFacingAway;
     }
 
     public static class Xrt

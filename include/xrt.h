@@ -180,6 +180,8 @@ typedef struct xrt_stats {
                                      the primary rays the ray-generation kernel answers itself because they cannot reach the scene
                                      octree's root box (OSM:318-320 returns false for them before any node is visited).  Not a
                                      counter of the reference: how much of the ray count is real traversal work on this library */
+    double   ms_intersect_longest;   /* the longest single traversal launch of the frame (of those ms_intersect sums): on every configuration here
+                                     the launch that traces the primary rays -- the launch class a roofline of "the dominant kernel" is about */
     uint64_t mesh_queries_facing_away;   /* with collect_stats: of mesh_queries, those whose ray is inside the mesh octree's root box and meets ONLY back
                                      faces in the whole mesh (the box of the mesh's surface normals says so, with the margin of the leaf
                                      test): RE:48-51 rejects every triangle, the reference walks the octree to find that out, this

@@ -35,15 +35,39 @@ def main():
             continue
         cfg = m.group(2)
         tot, n = collections.defaultdict(float), collections.Counter()
-        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        # ... and the same per launch CLASS: the traversal launches of a frame differ (the primary rays' launch walks the octree, the launch of
+        # the shadow rays and reflections of a terrain mostly ends at the mesh's normal box), so the dispatches are also grouped by their position
+        # in the frame (index among the traversal dispatches modulo the launches per frame, which the pass's bench line states)
+        per_frame = 0
+        try:
+            for line in open(d + ".log"):
+                if line.startswith('{"metric"'):
+                    per_frame = int(json.loads(line)["roofline"]["launches_per_frame"])
+        except Exception:
+            per_frame = 0
+        rows = []
+        files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+        for f in files[-1:]:   # (the newest run only: a directory merged back from several gpurun calls holds the older runs' files too)
             for r in csv.DictReader(open(f)):
                 if re.search(args.kernel, r["Kernel_Name"]):
+                    rows.append((int(r["Dispatch_Id"]), r["Counter_Name"], float(r["Counter_Value"])))
                     tot[r["Counter_Name"]] += float(r["Counter_Value"])
                     n[r["Counter_Name"]] += 1
         for k in tot:
             name = k + "_KB" if k in ("FETCH_SIZE", "WRITE_SIZE") else k
             configs[cfg][name] = tot[k] / n[k]
             configs[cfg].setdefault("dispatches", {})[k] = n[k]
+        if per_frame > 1 and rows:
+            ids = sorted(set(i for i, _, _ in rows))
+            pos = {i: j % per_frame for j, i in enumerate(ids)}
+            gt, gn = collections.defaultdict(float), collections.Counter()
+            for i, k, v in rows:
+                gt[(pos[i], k)] += v
+                gn[(pos[i], k)] += 1
+            groups = configs[cfg].setdefault("launch_classes", [dict() for _ in range(per_frame)])
+            if len(groups) == per_frame:
+                for (g, k), v in gt.items():
+                    groups[g][k + "_KB" if k in ("FETCH_SIZE", "WRITE_SIZE") else k] = v / gn[(g, k)]
     out = {"build_id": build_id(), "kernel": args.kernel,
            "note": "per traversal launch (k_intersect and k_packet together), averaged over every launch of `bench.py --config <cfg> --no-extra --no-cpu --no-host` under rocprofv3 --pmc "
                    "(separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*); FETCH_SIZE/WRITE_SIZE in KB, FETCH_SIZE counts half of streamed read bytes on gfx950",

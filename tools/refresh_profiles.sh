@@ -1,7 +1,8 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): refreshes the profile evidence under gpurun_out/final for the current build.
 #   1. separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ wave/VALU set | SQ scalar set) of the bench of every config -> tools/pmc_collect.py ->
-#      profiles/pmc_traversal.json (stamped with the kernel sources' hash; bench.py's roofline block reads it)
+#      profiles/pmc_traversal.json (stamped with the kernel sources' hash; bench.py's roofline block reads it); XRT_SPLIT=0: every launch of a pass is a
+#      whole-frame launch, as in the bench's timed region (blocking frames of two-level scenes are otherwise rendered as two bands)
 #   2. rocprofv3 --kernel-trace --stats of the default `python3 bench.py` command (the bench line is kept next to it)
 # Usage: tools/refresh_profiles.sh [configs...]   (default: C5 C3 C2 C4 G1)
 set -e -o pipefail
@@ -17,7 +18,7 @@ for c in $CFGS; do
   for pass in fetch write sq sc; do
     case $pass in fetch) CTR="FETCH_SIZE";; write) CTR="WRITE_SIZE";; sq) CTR="$SQ";; sc) CTR="$SC";; esac
     echo "== pmc $pass $c"
-    timeout -k 10 400 rocprofv3 --pmc $CTR --output-format csv -d $OUT/pmc_${pass}_$c -- python3 $R/bench.py --config $c --no-extra --no-cpu --no-host --steps 4 --warmup 1 > $OUT/pmc_${pass}_$c.log 2>&1
+    XRT_SPLIT=0 timeout -k 10 400 rocprofv3 --pmc $CTR --output-format csv -d $OUT/pmc_${pass}_$c -- python3 $R/bench.py --config $c --no-extra --no-cpu --no-host --steps 4 --warmup 1 > $OUT/pmc_${pass}_$c.log 2>&1
   done
 done
 python3 $R/tools/pmc_collect.py $OUT --out $OUT/pmc_traversal.json > /dev/null

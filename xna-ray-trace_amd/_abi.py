@@ -81,7 +81,7 @@ class xrt_stats(C.Structure):
         "mesh_aabb_tests", "mesh_queries", "node_tests", "leaf_refs", "tri_tests", "shaded_hits", "pixels",
         "algorithmic_bytes")] + [("ms_total", C.c_double), ("ms_intersect", C.c_double),
                                  ("intersect_launches", C.c_uint32), ("pieces", C.c_uint32), ("rays_traversed", C.c_uint64),
-                                 ("mesh_queries_facing_away", C.c_uint64)]
+                                 ("ms_intersect_longest", C.c_double), ("mesh_queries_facing_away", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

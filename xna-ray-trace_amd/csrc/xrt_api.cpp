@@ -344,8 +344,10 @@ struct xrt_scene {
     // waves were alive 55-60 % of its duration (C4 13.3 -> 10.9 ms), did not in rounds 2 and 3 (the second set of launches cost what the
     // overlap gained: C3 2.74 vs 2.91 ms, C4 7.1 vs 6.9, C5 7.9 vs 8.0), and pays again now that the kernels are faster and a launch's tail
     // is a larger share of it (round 4, one box: C3 1.95 -> 1.72 ms per blocking frame, C4 4.26 -> 4.13, C5 4.48 -> 4.43; three or four
-    // bands no better; profiles/r04/frame_split.txt).
+    // bands no better; profiles/r04/frame_split.txt).  By default only two-level scenes: the two extra frame contexts cost a one-body scene like C5
+    // 6 GB of work buffers for 1 %.
     int splitMode = 1, splitParts = 2;
+    bool splitGiven = false;     // XRT_SPLIT was set: else only two-level scenes are split (a one-body scene gains 1-2 % for two more frame contexts' work buffers)
     bool launchEvents = false;   // XRT_LAUNCH_EVENTS=1: single-chunk frames time their traversal launches with events on the dispatch packets, too
     int maxStampRows = MAX_STAMP_ROWS;   // XRT_STAMP_ROWS=<n> (tests): launches of a frame beyond the n-th carry events instead
     bool adaptiveFastOk = true;  // adaptive frames are enqueued whole (level buffers sized optimistically) until a level overflows; XRT_ADAPTIVE_FAST=0
@@ -1366,17 +1368,23 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
         float ms = 0;
         HIPCHECK(hipEventElapsedTime(&ms, F.events[0], F.events[1]));
         stats->ms_total = ms;
-        double mi = 0;
+        double mi = 0, longest = 0;
         for (auto &pr : F.pairs) {
             float t = 0;
             HIPCHECK(hipEventElapsedTime(&t, F.events[pr.first], F.events[pr.second]));
             mi += t;
+            if (t > longest) longest = t;
         }
         for (int j = 0; j < F.stampRows; j++) {
             const unsigned long long *sp = F.stampHost;
-            if (sp[2 * j + 1] > sp[2 * j]) mi += (double)(sp[2 * j + 1] - sp[2 * j]) / (double)s->wallClockKHz;
+            if (sp[2 * j + 1] > sp[2 * j]) {
+                const double t = (double)(sp[2 * j + 1] - sp[2 * j]) / (double)s->wallClockKHz;
+                mi += t;
+                if (t > longest) longest = t;
+            }
         }
         stats->ms_intersect = mi;
+        stats->ms_intersect_longest = longest;
         stats->intersect_launches = (uint32_t)F.pairs.size() + (uint32_t)F.stampRows;
         stats->pieces = 1;
     }
@@ -1568,6 +1576,7 @@ void add_stats(xrt_stats &acc, const xrt_stats &st, bool first) {
     for (size_t k = 0; k < offsetof(xrt_stats, ms_total) / sizeof(uint64_t); k++) a[k] += b[k];
     if (st.ms_total > acc.ms_total) acc.ms_total = st.ms_total;
     if (st.ms_intersect > acc.ms_intersect) acc.ms_intersect = st.ms_intersect;
+    if (st.ms_intersect_longest > acc.ms_intersect_longest) acc.ms_intersect_longest = st.ms_intersect_longest;
     if (first) acc.intersect_launches = st.intersect_launches;
     acc.pieces += 1;
     acc.rays_traversed += st.rays_traversed;
@@ -1629,7 +1638,7 @@ int open_frame_impl(xrt_scene *s, int slot, const xrt_camera *cam, const xrt_lig
         const bool plain = opts->use_multisampling != XRT_MS_ADAPTIVE && !(s->host->arrays.anyTransparent && opts->max_reflections > 0) && !opts->collect_stats;
         const long long px64 = (long long)px * (opts->use_multisampling == XRT_MS_FIXED16 ? 16 : 1) / (opts->shard_count > 1 ? opts->shard_count : 1);
         const bool alone = !s->frames[slot ^ 1].pending;
-        if (!st && plain && !s->oneStream && s->splitMode > 0 && (s->splitMode == 2 || alone) && s->lastFrameMs >= s->splitMinMs &&
+        if (!st && plain && !s->oneStream && s->splitMode > 0 && (s->splitGiven || s->sceneMode == MODE_SCENE) && (s->splitMode == 2 || alone) && s->lastFrameMs >= s->splitMinMs &&
             s->lastFrameMs >= s->overlapMinMs && px64 >= 8 * 8192 && px64 <= (long long)s->maxChunkPaths)
             nParts = s->splitParts;
         for (int j = 0; j < nParts; j++)
@@ -1746,7 +1755,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
         stats->rays_traversed = stats->rays_closest + stats->rays_shadow;
         float ms = 0;
         if (n > 0) HIPCHECK(hipEventElapsedTime(&ms, a0, a1));
-        stats->ms_total = ms; stats->ms_intersect = ms; stats->intersect_launches = n > 0 ? 1 : 0;
+        stats->ms_total = ms; stats->ms_intersect = ms; stats->ms_intersect_longest = ms; stats->intersect_launches = n > 0 ? 1 : 0;
     }
     return XRT_OK;
 }
@@ -1863,7 +1872,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_PK_STATIC")) { const int v = atoi(e); if (v >= 0 && v <= 64) s->packetStaticDiv = v; }
     if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 31) s->packetMask = v; }
     if (const char *e = getenv("XRT_PACKET_HEAP")) { const int v = atoi(e); if (v >= -1 && v <= 31) s->packetMaskHeap = v; }
-    if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) s->splitMode = v; }
+    if (const char *e = getenv("XRT_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) { s->splitMode = v; s->splitGiven = true; } }
     if (const char *e = getenv("XRT_LAUNCH_EVENTS")) s->launchEvents = atoi(e) != 0;
     if (const char *e = getenv("XRT_HEAP_FAST")) s->heapFastOk = atoi(e) != 0;
     if (const char *e = getenv("XRT_ADAPTIVE_FAST")) s->adaptiveFastOk = atoi(e) != 0;
