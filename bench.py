@@ -658,6 +658,20 @@ def main():
                                    "bound": rb["bound"], "frac": rb["frac"], "dominant_launch": rb.get("dominant_launch"), "fractions": rb["fractions"], "scene_build_s": round(r2["build_s"], 2)}
                     if r2["overlapped"]:
                         other[name]["ms_per_step_serialised"] = round(r2["serial_seconds"] / kk * 1e3, 3)
+                    # one blocking xrt_render_device at a time on the library's own streams (what RenderInternal, RT:103-126, sees: two-level scenes are rendered as two bands)
+                    _, tr_b = xrt.configs.build_product(xrt.configs.config(name), device=local_rank)
+                    sp_b = xrt.configs.config(name)
+                    ob = torch.zeros(sp_b.width * sp_b.height, dtype=torch.int32, device="cuda")
+                    fb = tr_b.PrepareDevice(ob.data_ptr())
+                    for _ in range(4):
+                        fb()
+                    torch.cuda.synchronize()
+                    tb0 = time.perf_counter()
+                    for _ in range(10):
+                        fb()
+                    torch.cuda.synchronize()
+                    other[name]["ms_per_step_blocking"] = round((time.perf_counter() - tb0) / 10 * 1e3, 3)
+                    del tr_b, fb, ob
                 except Exception as e:   # a side measurement must not take the headline down
                     other[name] = {"error": str(e)[:200]}
             line["other_configs"] = other

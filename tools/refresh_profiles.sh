@@ -26,6 +26,11 @@ cp $OUT/pmc_traversal.json $R/profiles/pmc_traversal.json   # so that the bench 
 echo "== kernel trace of the default bench"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py > $OUT/bench_under_rocprof.log 2>&1
 grep '^{"metric"' $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_line_under_rocprof.json
+echo "== kernel trace of the headline config alone: the traversal launches by their position in the frame"
+XRT_SPLIT=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_C5 -- python3 $R/bench.py --config C5 --no-extra --no-cpu --no-host > $OUT/bench_C5_under_rocprof.log 2>&1
+LPF=$(grep '^{"metric"' $OUT/bench_C5_under_rocprof.log | tail -1 | python3 -c "import sys, json; print(json.loads(sys.stdin.read())['roofline']['launches_per_frame'])")
+python3 $R/tools/trace_classes.py $OUT/stats_C5 $LPF > $OUT/C5_launch_classes_kernel_trace.txt
+cat $OUT/C5_launch_classes_kernel_trace.txt
 # keep only the small summaries (gpurun merges at most 64 MiB back)
 find $OUT -name "*counter_collection.csv" -size +20M -delete
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
