@@ -777,12 +777,18 @@ def test_multi_chunk_frames(xrt, monkeypatch):
 def test_launch_timing_device_clock_vs_events(xrt, monkeypatch):
     """Plain single-chunk frames time their traversal launches on the device clock (device_util.h stamp_begin / stamp_end, folded by
     k_compose's epilogue) instead of carrying two events per launch; XRT_LAUNCH_EVENTS=1 is the old way.  Same frame, same launch
-    count (how close the two clocks agree is a measurement, tools/ territory, not an assertion of the parity suite)."""
+    count -- one launch per step where the closest-hit and the shadow rays of a step are both packets (XRT_PK_MERGE=1, the default), two
+    with XRT_PK_MERGE=0 --, and the two clocks agree loosely (bench.py's roofline fractions divide by these durations: a stamp fold that
+    dropped a launch's row would show here; the bound is wide enough for a shared or throttled box)."""
     spec = xrt.configs.config("C3", 0.5)
     scene, tracer = xrt.configs.build_product(spec)
     monkeypatch.setenv("XRT_LAUNCH_EVENTS", "1")
     scene_e, tracer_e = xrt.configs.build_product(spec)
     monkeypatch.delenv("XRT_LAUNCH_EVENTS")
+    monkeypatch.setenv("XRT_PK_MERGE", "0")
+    scene_u, tracer_u = xrt.configs.build_product(spec)
+    monkeypatch.delenv("XRT_PK_MERGE")
+    R = spec.max_reflections
     ms_c, ms_e = [], []
     for i in range(10):
         a = tracer.Render().copy()
@@ -790,12 +796,17 @@ def test_launch_timing_device_clock_vs_events(xrt, monkeypatch):
         b = tracer_e.Render().copy()
         st_e = dict(tracer_e.last_stats)
         assert np.array_equal(a, b)
-        assert st_c["intersect_launches"] == st_e["intersect_launches"] >= spec.max_reflections + 2   # (a step whose two ray populations both go to the packet kernel is two launches)
+        # a two-level scene: every generation is packets -- R + 2 steps, each ONE launch (the first has no shadow rays, the last no closest-hit rays)
+        assert st_c["intersect_launches"] == st_e["intersect_launches"] == R + 2
         if i >= 2:
             ms_c.append(st_c["ms_intersect"]); ms_e.append(st_e["ms_intersect"])
-            assert 0 < st_c["ms_intersect"] < st_c["ms_total"]
-    # (sanity only: the ratio of two GPU timings is not a parity property; a shared or throttled box must not fail the suite)
-    assert min(ms_c) > 0 and min(ms_e) > 0, (ms_c, ms_e)
+            assert 0 < st_c["ms_intersect_longest"] <= st_c["ms_intersect"] < st_c["ms_total"]
+            assert 0 < st_e["ms_intersect_longest"] <= st_e["ms_intersect"]
+    c, e = min(ms_c), min(ms_e)
+    assert 0.5 * e <= c <= 1.5 * e + 0.05, (ms_c, ms_e)
+    a = tracer_u.Render().copy()
+    assert np.array_equal(a, b)
+    assert tracer_u.last_stats["intersect_launches"] == 2 * (R + 2) - 2   # the steps 1 .. R carry two ray populations: two launches each when not merged
 
 
 def test_launch_timing_mixed_stamps_and_events(xrt, monkeypatch):
