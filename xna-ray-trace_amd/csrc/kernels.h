@@ -58,6 +58,9 @@ struct IntersectArgs {
     // unless its scheduling-feedback word is wanted (missRecords); null: every ray gets its full record (seam 1)
     int *flags = nullptr, *flags2 = nullptr;
     int missRecords = 0;
+    // where the answer of ray i goes: hits / flags [scatter[i]] (null: [i]).  The shadow rays of a frame whose producer answered some of them itself
+    // (ShadeArgs::ae) are a compact list, their answers go back to (slot, light).
+    const int *scatter = nullptr, *scatter2 = nullptr;
 };
 
 // Row of device-clock stamps of one traversal launch (device_util.h stamp_begin / stamp_end): [start, waves, end[waves]]
@@ -90,6 +93,7 @@ struct PacketArgs {
     int nMul2 = 0, nCap2 = 0;
     // Cost of the frame's tiles (xrt.h xrt_scene_tile_costs): every packet adds the device-clock ticks it took to the tile of its first ray --
     // tileCost[(tileBase + path) >> tileShift], path = pathOf1[ray] (or slotOf1[ray / nL1].path, or the ray's index) for the first segment, slotOf2[ray / nL2].path for the second.
+    const int *scatter = nullptr, *scatter2 = nullptr;   // as IntersectArgs::scatter
     unsigned *tileCost = nullptr;
     int tileShift = 9, nL1 = 1, nL2 = 1, tileBase = 0;   // (tileBase: first path of this launch's part of the frame)
     const int *pathOf1 = nullptr;
@@ -131,6 +135,13 @@ struct ShadeArgs {
     unsigned epoch = 0;
     // hit / miss words of `hits` and `shadowHits` (IntersectArgs::flags): the 48-byte record of a miss does not exist
     const int *hitFlags = nullptr, *shadowFlags = nullptr;
+    // Answered at emission (one-body scenes, plain frames): part A asks, for every ray it is about to emit, what the traversal kernel would ask
+    // first once it has the object-space ray -- do ALL the mesh's triangles face away from it (traverse.h all_back_facing on MeshRec::nbMin/nbMax)?
+    // RE:48-51 then rejects every triangle, the query's answer is "no intersection", and the ray is not emitted: a shadow ray's hit / miss word is
+    // written here (shadowFlagsOut), a reflection's level record too (the path ends, RT:729-733).  The rays that are left form COMPACT lists: shadow
+    // rays at shadowRays[0 .. *shadowCnt) with shadowOut[i] = slot * nLights + light (where their answers go), reflections at nextRays[0 .. *nextCnt).
+    int ae = 0;
+    int *shadowCnt = nullptr, *shadowOut = nullptr, *shadowFlagsOut = nullptr;
 };
 
 int  intersect_stack_capacity(int needed);   // smallest compiled capacity >= needed, or -1

@@ -345,7 +345,9 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? 4 : 5) void k_intersect(Sc
         if (L.state == ST_FINISH) {
             const HitOut h = lane_result(L, C, S, M);
             const bool seg2 = L.rayIndex < 0;
-            const int at = seg2 ? ~L.rayIndex : L.rayIndex;
+            const int ati = seg2 ? ~L.rayIndex : L.rayIndex;
+            const int *const sc = seg2 ? A.scatter2 : A.scatter;
+            const int at = sc ? sc[ati] : ati;
             int *const fl = seg2 ? A.flags2 : A.flags;
             if (fl) fl[at] = h.hit;
             if (!fl || h.hit || A.missRecords) store_hit((seg2 ? A.hits2 : A.hits) + at, h);
@@ -757,6 +759,18 @@ __device__ __forceinline__ v3 lookup_uv(const ShadeView &V, const MaterialRec &M
 }
 
 // CastRay's shading for one step of the wavefront.  After intersect launch #k two independent pieces of work exist and
+// ShadeArgs::ae: would the one body's one mesh answer this world-space ray "no intersection" because all its triangles face away from it?  The
+// object-space direction is formed exactly as the traversal kernels form it (traverse.h lane_begin, OSM:358-364), the test is theirs
+// (all_back_facing on the mesh's normal box, with its margin; a NaN anywhere makes it false: such a ray is traced).
+__device__ __forceinline__ bool faces_away_single(const SceneView &S, v3 o, v3 d) {
+    const ObjRec &ob = S.objects[0];
+    const MeshRec &mr = S.meshes[0];
+    const v3 v1 = transform(o, ob.invWorld);
+    const v3 v2 = transform(add(o, d), ob.invWorld);
+    const v3 dir = normalize(sub(v2, v1));
+    return all_back_facing(f4{mr.nbMin[0], mr.nbMin[1], mr.nbMin[2], mr.nbMin[3]}, f4{mr.nbMax[0], mr.nbMax[1], mr.nbMax[2], mr.nbMax[3]}, dir);
+}
+
 // one kernel does both:
 //   part A, generation k   : the closest-hit answers.  Misses end their path (RT:729-733); every hit takes a slot, emits one
 //                            shadow ray per light (RT:535-537 -> RT:482-485) and -- the reflected / refracted directions
@@ -826,8 +840,24 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
         }
         const int slot = block_append(X.scnt, hit != 0, ldsCounts);
         if (hit && slot >= X.shadowCap) { *X.overflow = 1; hit = 0; }   // more rays than the chunk's buffers hold: the host retries with fewer paths
-        if (hit) {
+        if (X.ae) {   // (grid-uniform) shadow rays: answered here where the whole mesh faces away, else appended to the compact list
             for (int l = 0; l < V.nLights; l++) {
+                v3 dir = mk(0, 0, 0); float dist;
+                bool emit = false;
+                if (hit) {
+                    light_dir(V.lights[l], w, dir, dist);
+                    emit = !faces_away_single(S, w, dir);
+                    if (!emit) X.shadowFlagsOut[(size_t)slot * V.nLights + l] = 0;   // IsLightPathObstructed's query finds nothing (RT:482-485)
+                }
+                const int pos = block_append(X.shadowCnt, emit, ldsCounts);
+                if (emit) {
+                    store_ray(X.shadowRays + pos, w, dir, mesh, tri);   // ignore = shaded triangle (RT:485)
+                    X.shadowOut[pos] = slot * V.nLights + l;
+                }
+            }
+        }
+        if (hit) {
+            for (int l = 0; l < V.nLights && !X.ae; l++) {
                 v3 dir; float dist;
                 light_dir(V.lights[l], w, dir, dist);
                 store_ray(X.shadowRays + (size_t)slot * V.nLights + l, w, dir, mesh, tri);   // ignore = shaded triangle (RT:485)
@@ -876,6 +906,21 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
             }
         }
         if (!emitNext) continue;
+        if (!X.heap && X.ae) {   // chain of reflections, answered at emission: a reflection the whole mesh faces away from ends its path here
+            const bool emit = hit && !faces_away_single(S, w, rdir);
+            if (hit && !emit) X.lvlB[(size_t)(X.level + 1) * P + p] = f4{0, 0, 0, i2f(FLAG_MISS)};   // what part A of the next step writes for a miss (RT:729-733)
+            const int pos = block_append(X.nextCnt, emit, ldsCounts);
+            const bool heavy = emit && X.heavy.list && pos < X.nextCap && long_ray(S, X.heavy, p, w, rdir);
+            if (emit && pos < X.nextCap) {   // (pos <= the parent's slot < cap: a guard, not a code path)
+                store_ray(X.nextRays + pos, w, rdir, mesh, heavy ? (tri ^ HEAVY_BIT) : tri);   // origin = result.triangle (RT:559)
+                X.nextPath[pos] = p;
+            }
+            if (X.heavy.list) {
+                const int hs = block_append(X.heavy.count, heavy, ldsCounts);
+                if (heavy) X.heavy.list[hs] = pos;
+            }
+            continue;
+        }
         if (!X.heap) {   // chain of reflections: the ray of generation k+1 sits at its parent's slot
             const bool heavy = hit && X.heavy.list && long_ray(S, X.heavy, p, w, rdir);
             if (hit) {

@@ -577,8 +577,10 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
                 const HitOut h = lane_result(L, C, Sr, M);
                 xrt_hit *const hitsS = seg2 ? KA.args()->hits2 : KA.args()->hits;
                 int *const flagsS = seg2 ? KA.args()->flags2 : KA.args()->flags;
-                if (flagsS) flagsS[idx] = h.hit;
-                if (!flagsS || h.hit) store_hit(hitsS + idx, h);
+                const int *const scat = seg2 ? KA.args()->scatter2 : KA.args()->scatter;
+                const int at = scat ? scat[idx] : idx;   // (a compact list of rays whose answers belong elsewhere: ShadeArgs::ae)
+                if (flagsS) flagsS[at] = h.hit;
+                if (!flagsS || h.hit) store_hit(hitsS + at, h);
             }
         } else {
             // ---- OSM:312-455, wave-uniform: scene octree in DFS order, bodies and meshes in list order ---------------------------
@@ -713,8 +715,10 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
                 const HitOut h = lane_result(L, C, Sr, M);
                 xrt_hit *const hitsS = seg2 ? KA.args()->hits2 : KA.args()->hits;
                 int *const flagsS = seg2 ? KA.args()->flags2 : KA.args()->flags;
-                if (flagsS) flagsS[idx] = h.hit;
-                if (!flagsS || h.hit) store_hit(hitsS + idx, h);
+                const int *const scat = seg2 ? KA.args()->scatter2 : KA.args()->scatter;
+                const int at = scat ? scat[idx] : idx;   // (a compact list of rays whose answers belong elsewhere: ShadeArgs::ae)
+                if (flagsS) flagsS[at] = h.hit;
+                if (!flagsS || h.hit) store_hit(hitsS + at, h);
             }
         }
         if (costed) {   // the tile this packet's first ray belongs to pays for the packet (scheduling feedback for the next frame's tile table)
@@ -744,7 +748,9 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
                 const int first = (seg2 ? pk - nPk1 : pk) * 64;
                 const SlotRec *const sl = seg2 ? a->slotOf2 : a->slotOf1;
                 const int *const po = a->pathOf1;
-                const int path = sl ? sl[first / (seg2 ? a->nL2 : a->nL1)].path : (po ? po[first] : first);
+                const int *const scat = seg2 ? a->scatter2 : a->scatter;
+                const int firstAt = (sl && scat) ? scat[first] : first;   // (shadow rays in a compact list: where the first one's answer goes = slot * lights + light)
+                const int path = sl ? sl[firstAt / (seg2 ? a->nL2 : a->nL1)].path : (po ? po[first] : first);
                 atomicAdd(a->tileCost + ((a->tileBase + path) >> a->tileShift), dt);
             }
         }

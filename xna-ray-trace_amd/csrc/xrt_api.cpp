@@ -243,6 +243,7 @@ struct xrt_scene {
     int heavyShift = 3;        // listed long rays are dealt one in 2^n work items (0: 64 to a wave); scene_upload: 0 for two-level scenes; XRT_HEAVY_SHIFT
     bool heavyShiftGiven = false;
     bool packetMerge = true;   // the closest-hit and the shadow packets of a step share one launch (XRT_PK_MERGE=0: two launches, as round 2)
+    bool noAnswerAtEmission = false;   // XRT_AE=0: k_shade emits every ray (kernels.h ShadeArgs::ae off)
     int packetCullMin = 4;     // XRT_PK_CULL_MIN (development): leaves with fewer references skip the tight-box test
     int packetGrabMax = 2;     // XRT_PK_GRAB (development): 8 -> 2 shortened the tail of a launch (C5 blocking 9.0 -> 7.8 ms); 1 loses to contention on the queue word
     int packetStaticDiv = 4;   // XRT_PK_STATIC (development): 1/2 .. 1/8 measured within 2 % of each other on C5
@@ -264,6 +265,9 @@ struct xrt_scene {
         DevBuf<int> node0, node1, heapFlag;     // ray-tree frames: heap node of every ray; heapFlag[0]: a generation overflowed its buffers
         DevBuf<float> ref0, ref1, lvlAlpha;     // ... refraction index of the medium a ray travels in; alpha per level record
         DevBuf<int> hitFlags0, shadowFlags;   // hit / miss word per ray of hits, shadowHits (a miss has no record)
+        DevBuf<int> shadowOut;                // ShadeArgs::ae: where the answer of the i-th emitted shadow ray goes (slot * lights + light)
+        DevBuf<int> shadowFlags1;             // ShadeArgs::ae: part A of step k answers some shadow queries of generation k ITSELF while part B of the same launch still reads
+                                              // generation k-1's words: the generations alternate between shadowFlags and this
         DevBuf<unsigned long long> stamps;      // device-clock stamps of the traversal launches (device_util.h), STAMP_STRIDE per launch
         DevBuf<SlotRec> slot0, slot1;
         DevBuf<int> slotNode0, slotNode1;   // ray-tree frames: the node of a slot's hit
@@ -282,7 +286,7 @@ struct xrt_scene {
         hipStream_t lastStream = nullptr;       // the stream the context's last frame ran on
         void release() {
             rays0.release(); rays1.release(); shadowRays.release(); hits.release(); shadowHits.release();
-            path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); stamps.release(); hitFlags0.release(); shadowFlags.release();
+            path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); stamps.release(); hitFlags0.release(); shadowFlags.release(); shadowOut.release(); shadowFlags1.release();
             node0.release(); node1.release(); heapFlag.release(); ref0.release(); ref1.release(); lvlAlpha.release(); slot0.release(); slot1.release(); slotNode0.release(); slotNode1.release();
             lvlA.release(); lvlB.release(); sampleColor.release(); sampleF32.release(); lights.release();
             for (auto &l : levels) { l.color.release(); l.childBase.release(); l.childMask.release(); l.cx.release(); l.cy.release(); }
@@ -325,6 +329,8 @@ struct xrt_scene {
         unsigned long long *stampHost = nullptr, *stampHostDev = nullptr;   // their (start, end) clock pairs: mapped pinned memory and its device view
         // deferred accounting
         int tallyChunks = 0, cntStride = 0, R = 0, nL = 0;
+        bool ae = false;             // ShadeArgs::ae: rays answered at emission are not in the ray lists
+        unsigned long long answered = 0;   // ... their number (frame_finish)
         bool collect = false;
         unsigned long long shaded = 0, closestDeep = 0, livePaths = 0, live0 = 0, validPixels = 0;
         size_t liveCap = 0;   // room of the generation-0 ray arrays (k_raygen writes no live ray past it: a count above it is a wrong bound, reported)
@@ -728,7 +734,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                  (rc = W.lvlAlpha.ensure((size_t)P * nodes))))
         return rc;
     if (wantF32 && (rc = W.sampleF32.ensure((size_t)P * 3))) return rc;
-    const int cntStride = 3 * (R + 2);          // per chunk: cnt[R+2], scnt[R+2], then the long-ray list lengths [R+2]
+    const int cntStride = 4 * (R + 2);          // per chunk: cnt[R+2], scnt[R+2], the long-ray list lengths [R+2], the shadow rays really emitted [R+2] (ShadeArgs::ae)
     constexpr int QW = 1 + 2 * PACKET_QUEUE_WORDS;   // per launch step k: the lane kernel's queue word and the heads of each packet launch (closest, shadow)
     const int qStride = QW * (R + 2);
     // The common frame (one chunk, no supersampling levels, no ray tree, no counting pass) puts nothing but its kernels
@@ -744,6 +750,15 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     const bool adaptiveFast = adaptive && !heap && heapFastAllowed && s->adaptiveFastOk && nParts == 1 && !opts->collect_stats && totalPixels * 4 <= chunkPaths &&
                               (quality + 2) * (R + 2) * 2 + 2 <= MAX_STAMP_ROWS;
     const bool fast = (adaptive ? adaptiveFast : (!heap || heapFast)) && firstPaths <= chunkPaths && !opts->collect_stats;
+    // Answered at emission (kernels.h ShadeArgs::ae): plain one-chunk frames of one-body scenes whose mesh CAN face away from a ray as a whole (its normal
+    // box does not hold the origin).  Not with the counting pass -- it counts the reference's work for every query from the ray lists --, not for ray trees.
+    bool ae = fast && !heap && !adaptive && nParts == 1 && s->sceneMode == MODE_SINGLE && s->view.nodeCull != 0 && !s->noAnswerAtEmission;
+    if (ae) {
+        const MeshRec &m0 = s->host->arrays.meshes[0];
+        ae = m0.nbMin[3] == 0.0f && (m0.nbMin[0] > 0.0f || m0.nbMax[0] < 0.0f || m0.nbMin[1] > 0.0f || m0.nbMax[1] < 0.0f || m0.nbMin[2] > 0.0f || m0.nbMax[2] < 0.0f);
+    }
+    F.ae = ae;
+    if (ae && ((rc = W.shadowOut.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = W.shadowFlags1.ensure(rayCap * (nL > 0 ? nL : 1))))) return rc;
     F.fast = fast;
     F.heap = heap;
     F.redone = false;
@@ -862,6 +877,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     s->progress.store(0.0f);
     unsigned long long &shaded = F.shaded, &closestDeep = F.closestDeep, &livePaths = F.livePaths, &live0 = F.live0;
     shaded = closestDeep = livePaths = live0 = 0;
+    F.answered = 0;
     unsigned long long *hcntHost = F.hcnt;
     std::memset(hcntHost, 0, sizeof(F.hcnt));
     F.tallyChunks = 0; F.cntStride = cntStride; F.R = R; F.nL = nL; F.collect = opts->collect_stats != 0;
@@ -885,7 +901,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
     // frame epilogue this chunk's compose kernel carries, if any)
     auto enqueue_chunk = [&](const RayGenParams &gp, int *cnt, unsigned *q, int Pc, long long pathBase, uint32_t *sampleOut = nullptr,
                              const FrameEpilogue *epi = nullptr) -> int {
-        int *scnt = cnt + (R + 2), *hcnt = cnt + 2 * (R + 2);
+        int *scnt = cnt + (R + 2), *hcnt = cnt + 2 * (R + 2), *acnt = cnt + 3 * (R + 2);   // (acnt[k]: shadow rays of generation k that were really emitted, ShadeArgs::ae)
         const int chunkRow0 = F.stampRows;
         // "long ray first" (kernels.hip): the producer of generation k lists its long rays, launch #k takes them first
         const bool feedback = fast && s->deepMeshes && s->costMap.p != nullptr;
@@ -916,14 +932,16 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             const int cur = k & 1, prv = cur ^ 1;
             const bool hasClosest = k <= R, hasShadow = k >= 1 && nL > 0;
             // a reflection chain keeps the ray of generation k at its parent's slot: their number is scnt[k-1]
-            const int *nClosest = (k == 0 || heap) ? cnt + k : scnt + (k - 1);
+            const int *nClosest = (k == 0 || heap || ae) ? cnt + k : scnt + (k - 1);   // (ae: the reflections that were emitted are a compact list, counted by part A)
             IntersectArgs C, B;   // closest-hit segment, shadow segment
             C.rays = rays[cur]; C.hits = hitsOf[cur]; C.index = nullptr; C.nDev = nClosest; C.nMul = 1; C.n = Pc;   // (generation 0: cnt[0] live rays, compact)
             C.nCap = (int)rayCap;
-            C.flags = flagsOf[cur]; B.flags = W.shadowFlags.p;
+            int *const shadowFlagsOf[2] = {W.shadowFlags.p, ae ? W.shadowFlags1.p : W.shadowFlags.p};   // (the words of generation g: [g & 1])
+            C.flags = flagsOf[cur]; B.flags = shadowFlagsOf[(k + 1) & 1];   // launch #k traces the shadow rays of generation k - 1
             C.missRecords = (feedback && !packet_closest(k)) ? 1 : 0;   // k_shade #k reads the cost word of every ray of the generation
             { const HeavyArgs H = heavy_for(k); C.heavyIdx = H.list; C.nHeavy = H.count; }
             B.rays = W.shadowRays.p; B.hits = W.shadowHits.p; B.index = nullptr; B.nDev = hasShadow ? scnt + (k - 1) : nullptr; B.nMul = nL; B.n = 0;
+            if (ae && hasShadow) { B.nDev = acnt + (k - 1); B.nMul = 1; B.scatter = W.shadowOut.p; }   // the emitted shadow rays, compact; answers go back to (slot, light)
             B.nCap = (int)((long long)shadowCap * nL);
             for (IntersectArgs *a : {&C, &B}) {
                 a->queue = q + QW * k; a->mode = s->sceneMode; a->meshId = 0;
@@ -935,7 +953,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             auto launch_pk = [&](const IntersectArgs &I, int word, long long nHost, const IntersectArgs *I2 = nullptr) -> int {
                 PacketArgs PA;
                 PA.rays = I.rays; PA.hits = I.hits; PA.flags = I.flags; PA.index = I.index; PA.nDev = I.nDev; PA.nMul = I.nMul; PA.n = I.n; PA.nCap = I.nCap;
-                if (I2) { PA.rays2 = I2->rays; PA.hits2 = I2->hits; PA.flags2 = I2->flags; PA.nDev2 = I2->nDev; PA.nMul2 = I2->nMul; PA.nCap2 = I2->nCap; }
+                PA.scatter = I.scatter;
+                if (I2) { PA.rays2 = I2->rays; PA.hits2 = I2->hits; PA.flags2 = I2->flags; PA.nDev2 = I2->nDev; PA.nMul2 = I2->nMul; PA.nCap2 = I2->nCap; PA.scatter2 = I2->scatter; }
                 if (tileCostDev) {   // which tile pays for a packet: the path of its first ray (closest-hit rays: the path list; shadow rays: their hit's slot record)
                     PA.tileCost = tileCostDev; PA.tileBase = (int)pathBase; PA.tileShift = 9 + (gp.samples == 16 ? 4 : (gp.samples == 4 ? 2 : 0));
                     if (&I == &B) { PA.slotOf1 = slotOf[prv]; PA.nL1 = nL; }
@@ -963,7 +982,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             const bool laneC = hasClosest && !pkC, laneB = hasShadow && !pkB;
             if (laneC || laneB) {
                 IntersectArgs A = laneC ? C : B;
-                if (laneC && laneB) { A.rays2 = B.rays; A.hits2 = B.hits; A.flags2 = B.flags; A.nDev2 = B.nDev; A.nMul2 = B.nMul; A.nCap2 = B.nCap; }
+                if (laneC && laneB) { A.rays2 = B.rays; A.hits2 = B.hits; A.flags2 = B.flags; A.nDev2 = B.nDev; A.nMul2 = B.nMul; A.nCap2 = B.nCap; A.scatter2 = B.scatter; }
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 const int grid = k == 0 ? persistent_grid(s, Pc) : persistent_grid(s, hint(s->genRays, k), 16);
@@ -983,12 +1002,13 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             std::memset(&X, 0, sizeof(X));
             X.level = k; X.doA = hasClosest ? 1 : 0; X.doB = k >= 1 ? 1 : 0;
             X.maxReflections = R; X.P = P; X.heap = heap ? 1 : 0; X.overflow = overflowFlag;
-            X.rays = rays[cur]; X.hits = hitsOf[cur]; X.hitFlags = flagsOf[cur]; X.shadowFlags = W.shadowFlags.p; X.nDev = nClosest; X.nHost = Pc; X.cap = (int)rayCap;
+            X.rays = rays[cur]; X.hits = hitsOf[cur]; X.hitFlags = flagsOf[cur]; X.shadowFlags = shadowFlagsOf[(k + 1) & 1]; X.nDev = nClosest; X.nHost = Pc; X.cap = (int)rayCap;
             X.index = nullptr; X.rayPath = k == 0 ? W.index0.p : paths[cur];   // (generation 0: the j-th live ray belongs to path index0[j])
             X.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; X.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
             X.slotOut = slotOf[cur]; X.slotNodeOut = heap ? slotNodeOf[cur] : nullptr; X.scnt = scnt + k; X.shadowCap = (int)shadowCap; X.shadowRays = W.shadowRays.p;
             X.nextRays = rays[prv]; X.nextPath = paths[prv]; X.nextNode = heap ? nodesOf[prv] : nullptr; X.nextRef = heap ? refOf[prv] : nullptr;
             X.nextCnt = cnt + k + 1; X.nextCap = (int)rayCap;
+            if (ae) { X.ae = 1; X.shadowCnt = acnt + k; X.shadowOut = W.shadowOut.p; X.shadowFlagsOut = shadowFlagsOf[k & 1]; }
             X.slotPrev = slotOf[prv]; X.slotNodePrev = heap ? slotNodeOf[prv] : nullptr; X.scntPrev = k >= 1 ? scnt + (k - 1) : nullptr; X.shadowHits = W.shadowHits.p;
             X.lvlA = W.lvlA.p; X.lvlB = W.lvlB.p; X.lvlAlpha = heap ? W.lvlAlpha.p : nullptr;
             if (k < R) X.heavy = heavy_for(k + 1);
@@ -1310,6 +1330,10 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
                 F.shaded += (unsigned long long)hc[(R + 2) + k];
                 if (k > 0) F.closestDeep += (unsigned long long)(F.heap ? hc[k] : hc[(R + 2) + k - 1]);   // reflection chain: one ray per parent hit
                 else F.live0 += (unsigned long long)hc[0];
+                if (F.ae) {   // queries part A answered itself: the hits' shadow rays that were not emitted, and (not in the last generation) their reflections
+                    F.answered += (unsigned long long)hc[(R + 2) + k] * (unsigned long long)F.nL - (unsigned long long)hc[3 * (R + 2) + k];
+                    if (k < R) F.answered += (unsigned long long)(hc[(R + 2) + k] - hc[k + 1]);
+                }
             }
         }
         if (!F.fast) std::memcpy(F.hcnt, (char *)F.pinned + nb, sizeof(F.hcnt));
@@ -1317,7 +1341,7 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
         if (F.fast && F.tallyChunks == 1 && !F.adaptiveFast) {   // sizes of this frame's generations: grid hints for the next one (sizing only)
             const int *hc = (const int *)F.pinned + F.cntBase;
             for (int k = 0; k <= R + 1 && k < 68; k++) {
-                const long long closest = (k == 0 || (F.heap && k <= R)) ? hc[k] : (k <= R ? hc[(R + 2) + k - 1] : 0), shaded = k >= 1 ? hc[(R + 2) + k - 1] : 0;
+                const long long closest = (k == 0 || ((F.heap || F.ae) && k <= R)) ? hc[k] : (k <= R ? hc[(R + 2) + k - 1] : 0), shaded = k >= 1 ? hc[(R + 2) + k - 1] : 0;
                 // (a hint shrinks by an eighth per frame at most: a camera that looks away for a frame, or alternates between two views,
                 // must not leave the next full view with a grid of sixteen blocks)
                 const bool same = s->genKey == F.framePaths * 64 + F.nL;
@@ -1363,7 +1387,7 @@ int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats) {
             hcnt[C_COUNT + C_RAYS] = F.shaded * (unsigned long long)F.nL;
         }
         fill_stats(stats, hcnt, F.shaded, F.validPixels);
-        stats->rays_traversed = stats->rays_closest + stats->rays_shadow - (F.livePaths - F.live0);   // all but the primary rays k_raygen answered
+        stats->rays_traversed = stats->rays_closest + stats->rays_shadow - (F.livePaths - F.live0) - F.answered;   // all but the primary rays k_raygen answered and the rays k_shade answered at emission
         if (!F.collect) stats->algorithmic_bytes = 0;   // needs the counting pass
         float ms = 0;
         HIPCHECK(hipEventElapsedTime(&ms, F.events[0], F.events[1]));
@@ -1404,7 +1428,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->shadowBytes = s->shadowBytes; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->packetMerge = s->packetMerge; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->shadowBytes = s->shadowBytes; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->noAnswerAtEmission = s->noAnswerAtEmission; r->packetMerge = s->packetMerge; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1883,6 +1907,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_SPLIT_MS")) s->splitMinMs = (float)atof(e);
     if (const char *e = getenv("XRT_SPLIT_PARTS")) { const int v = atoi(e); if (v >= 2 && v <= 4) s->splitParts = v; }
     if (const char *e = getenv("XRT_PK_CULL_MIN")) s->packetCullMin = atoi(e);
+    if (const char *e = getenv("XRT_AE")) s->noAnswerAtEmission = atoi(e) == 0;
     if (const char *e = getenv("XRT_PK_MERGE")) s->packetMerge = atoi(e) != 0;
 #ifdef XRT_DEV   // (make DEV=1) the two margin factors are the only switches that can change a result: below their proven values the skips
                  // are no longer exact.  A shipped library does not read them from the environment of its host process.
