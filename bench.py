@@ -643,7 +643,7 @@ def main():
                 parity_failed = not line["parity_ok"]
         if solo and not args.no_extra and args.scale == 1.0:
             other = {}
-            for name, k in (("C2", 20), ("C3", 20), ("C4", 12), ("G1", 20)):   # G1: the scene the reference's own Stopwatch would time (Game1.cs)
+            for name, k in (("C2", 200), ("C3", 30), ("C4", 12), ("G1", 60)):   # (frames of 0.1-0.3 ms: enough of them for the clocks to have ramped up)   # G1: the scene the reference's own Stopwatch would time (Game1.cs)
                 if name == args.config:
                     continue
                 try:
