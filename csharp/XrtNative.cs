@@ -121,6 +121,8 @@ namespace RayTraceProject.Native
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_generate_primary_rays(IntPtr scene, ref XrtCamera camera, [Out] XrtRay[] raysOut);
         // can n_gpus > 1 load RCCL?  OK or E_RCCL (-6) with the loader's message; no device is touched
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_rccl_probe();
+        // diagnostics of the split walks of long packets (results never depend on them): subtrees handed over, taken, packets split, packets written by a taker
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int xrt_split_stats(IntPtr scene, [Out] ulong[] out4, int reset);
 
         // error convention of the reference: InvalidOperationException when busy (RayTracer.cs:26-27,62-63),
         // ArgumentException for bad arguments (SceneObject.cs:123-124, Material.cs:85,97)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define XRT_VERSION 202
+#define XRT_VERSION 203
 
 /* error codes (C# shim: BUSY -> InvalidOperationException (RT:26-27,62-63),
  * INVALID_ARG -> ArgumentException (SO:123-124, MAT:85,97)) */
@@ -366,6 +366,12 @@ int xrt_detile_device(int32_t width, int32_t height, int32_t shard_count, const 
  * xrt_last_error().  Touches no device: a host can ask before it offers the option (the reference has no counterpart; the call
  * exists so that the failure a C# host would otherwise meet inside RenderInternal, RT:103-126, can be met up front). */
 int xrt_rccl_probe(void);
+
+/* Diagnostics of the split walks of long packets (no counterpart in the reference: its scanline threads never share a ray).  The traversal kernel
+ * of one-body scenes lets a packet whose octree walk has outlasted its budget hand pending subtrees to other wavefronts; results never depend on it.
+ * out[0] subtrees handed over, out[1] taken by another (or, at the end of a launch, the same) wavefront, out[2] packets that were split, out[3] packets
+ * whose results were written by a taker -- counted on the scene's device since the library was loaded or since the last call with reset != 0. */
+int xrt_split_stats(xrt_scene *scene, uint64_t out[4], int32_t reset);
 
 /* RayTracer.Progress (RT:43-46): fraction of the frame's ray generations completed; callable from
  * another thread during xrt_render. */

@@ -1448,6 +1448,55 @@ def test_wave_packet_kernel_against_the_oracle(xrt, orc, monkeypatch):
     assert np.array_equal(tracer.Render(), o_rgba)
 
 
+@pytest.mark.parametrize("env", [{"XRT_PK_SPLIT": "1", "XRT_PK_BUDGET": "0", "XRT_PK_BUDGET_ITEM": "0"}, {"XRT_PK_SPLIT": "1", "XRT_PK_BUDGET": "0", "XRT_PK_BUDGET_ITEM": "0", "XRT_PK_SPLIT_ITEMS": "48"},
+                                 {"XRT_PK_SPLIT": "1", "XRT_PK_BUDGET": "0", "XRT_PK_BUDGET_ITEM": "1000000"}, {"XRT_PK_SPLIT": "1", "XRT_PK_BUDGET": "2", "XRT_PK_BUDGET_ITEM": "1"},
+                                 {"XRT_PK_SPLIT": "1", "XRT_PK_LONG": "1", "XRT_PK_BUDGET_LONG": "0"}, {"XRT_PK_SPLIT": "0"}])
+def test_split_walks_never_change_results(xrt, orc, monkeypatch, env):
+    """Split walks (packet.hip): a packet whose walk has outlasted its budget hands the pending subtrees of its stacked levels to other
+    waves, takers may split again, the last participant merges the partial answers.  With a budget of ZERO every block a walk enters
+    with something pending above gives all of it away (until the packet's record or the launch's arena is full -- a tiny arena is
+    one of the cases), so nearly every (leaf, triangle) test of a packet is made by another wave than the one that writes the result:
+    answers must still be the oracle's bit for bit -- seam-1 batches of primary, incoherent, axis-parallel / zero / non-finite rays and rays
+    leaving surfaces with an ignored triangle, and whole frames with 1 and 16 sub-rays (shadow rays in a compact list with scattered
+    answers, two populations in one launch)."""
+    monkeypatch.setenv("XRT_PACKET", "31")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    specs = {"h224": xrt.configs.heightfield_scene(160, 90, m=224), "soup_deep": soup_spec(xrt, 300, 5, 4, 0.5), "soup": soup_spec(xrt, 2000, 7, 20, 0.15)}
+    nan = float("nan")
+    for name, spec in specs.items():
+        scene, tracer = xrt.configs.build_product(spec)
+        scene.SplitStats()
+        o = orc.OracleScene(spec)
+        prim = tracer.GeneratePrimaryRays()
+        sets = [prim, random_rays(xrt, 20000, 5, radius=60.0 if name.startswith("h") else 3.0),
+                xrt.rays_array([(0, 50, 0), (0, 50, 0), (0, 50, 0), (1e30, 0, 0), (0, 50, 0), (0, 4.0, 0), (0, 2, 0), (1, 2, 1)] * 9,
+                               [(0, 0, 0), (nan, -1, 0), (0, -1, 0), (-1, 0, 0), (1e-7, -1, 1e-7), (0, 1, 0), (1, 0, 0), (0, 0, -1)] * 9)]
+        for rays in sets:
+            ho = o.intersect(rays)
+            assert hits_equal(ho, scene.IntersectBatch(rays)) == {}, name
+            sec = secondary_rays(xrt, ho, seed=4)
+            if len(sec):
+                assert hits_equal(o.intersect(sec), scene.IntersectBatch(sec)) == {}, name
+        rgba, rgbf = tracer_render(tracer, 2)
+        o_rgba, o_rgbf, o_st = orc.OracleScene(spec_with(spec, 2)).render(nthreads=8)
+        assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+        for k in ("rays_closest", "rays_shadow", "hits_closest", "shaded_hits"):
+            assert tracer.last_stats[k] == o_st[k], (name, k)
+        given, taken, packets, by_taker = scene.SplitStats()
+        if env.get("XRT_PK_SPLIT") == "0": assert (given, taken, packets, by_taker) == (0, 0, 0, 0)
+        else:   # every subtree handed over was walked by someone; with a budget of zero the walks really were split and takers wrote results
+            assert given == taken and given >= packets, (name, given, taken, packets, by_taker)
+            if env.get("XRT_PK_BUDGET") == "0": assert packets > 0 and by_taker > 0, (name, given, taken, packets, by_taker)
+    spec = xrt.configs.heightfield_scene(96, 54, m=224, multisampling=xrt.abi.MS_FIXED16)
+    scene, tracer = xrt.configs.build_product(spec)
+    o_rgba, _, _ = orc.OracleScene(spec).render(nthreads=8, want_float=False)
+    for _ in range(4):   # (frames in a row: the arena is reused, only the launch's serial number tells old items from new; from the second frame of a
+        assert np.array_equal(tracer.Render(), o_rgba)   # context on, the packets that cost more than XRT_PK_LONG microseconds last time are split from the start)
+    given, taken, packets, _ = scene.SplitStats()
+    assert given == taken and (env.get("XRT_PK_BUDGET") != "0" or packets > 0) and (env.get("XRT_PK_SPLIT") != "0" or packets == 0)
+
+
 def test_scene_packets_against_the_oracle(xrt, orc, monkeypatch):
     """k_packet<MODE_SCENE> (packet.hip): one wavefront walks the SCENE octree, the bodies of its leaves and each body's mesh
     octree once for 64 rays (OSM:312-455 -> MO:259-353).  XRT_PACKET=31 routes every ray population of two-level scenes through

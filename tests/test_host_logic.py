@@ -22,7 +22,7 @@ def test_abi_exports_every_declared_symbol(xrt):
     declared -= {"xrt_scene"}
     assert declared == set(xrt.abi.SYMBOLS), declared ^ set(xrt.abi.SYMBOLS)
     lib = xrt.abi.lib()                      # resolves all of them or raises
-    assert lib.xrt_version() == 202
+    assert lib.xrt_version() == 203
     assert C.sizeof(xrt.abi.xrt_ray) == 32 and C.sizeof(xrt.abi.xrt_hit) == 48
     assert lib.xrt_last_error() is not None
 

@@ -126,7 +126,7 @@ def test_packet_kernel_argument_offsets():
         byval = [x for x in offs if x[2] == "by_value"]
         assert [o for o, _, _ in ptrs] == [8 * i for i in range(8)] and len(byval) == 2
         assert byval[0][0] == 64 and byval[1][0] == 64 + byval[0][1]          # SceneView at 64, PacketArgs right behind it (sizeof(SceneView) % 8 == 0)
-    assert seen == 3
+    assert seen == 5   # the three modes, and the split-walk variants of the two one-body modes
 
 
 def test_packet_kernel_resources(isa):
@@ -138,9 +138,12 @@ def test_packet_kernel_resources(isa):
     hi, lo = re.search(r"constexpr int PK_SGPRS = PK_SINGLE_WAVES >= 7 \? (\d+) : (\d+);", src).groups()
     budget = int(hi) if waves >= 7 else int(lo)
     blocks = re.findall(r"Function Name: (\S*k_packet\S*).*?TotalSGPRs: (\d+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", usage, flags=re.S)
-    assert len(blocks) == 3   # MODE_SCENE (0), MODE_MESH (1), MODE_SINGLE (2)
+    assert len(blocks) == 5   # MODE_SCENE (0), MODE_MESH (1), MODE_SINGLE (2), and the split-walk variants of the one-body modes
     for name, sgprs, vgprs, scratch in blocks:
-        mode = int(re.search(r"k_packetILi(\d)E", name).group(1))
+        mode, sp = (int(x) for x in re.search(r"k_packetILi(\d)ELb(\d)E", name).groups())
+        if sp:   # the split-walk variant (off by default) is compiled for six waves per SIMD as well and pays for it with a few dwords of scratch per lane
+            assert int(sgprs) <= budget and int(vgprs) <= 80 and int(scratch) <= 64, (name, sgprs, vgprs, scratch)
+            continue
         # 112 SGPRs allow six waves per SIMD, and so do up to 80 VGPRs (one-body variants); the two-level variant also carries the
         # scene cursor and the body's transform: four waves per SIMD (128 registers), its scene-level answer parked in LDS
         # (round 3: five waves per SIMD -- 96 registers and a few dwords of scratch per lane that are touched once per packet, measured faster than 4 x 106)

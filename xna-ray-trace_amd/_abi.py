@@ -93,7 +93,7 @@ class xrt_node_info(C.Structure):
 
 
 assert C.sizeof(xrt_ray) == 32 and C.sizeof(xrt_hit) == 48 and C.sizeof(xrt_render_opts) == 48
-XRT_VERSION = 202
+XRT_VERSION = 203
 
 # every symbol include/xrt.h declares: name -> (restype, argtypes)
 _P = C.POINTER
@@ -129,6 +129,7 @@ SYMBOLS = {
     "xrt_detile_table_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "xrt_progress": (C.c_float, [C.c_void_p]),
     "xrt_rccl_probe": (C.c_int, []),
+    "xrt_split_stats": (C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_int32]),
     "xrt_generate_primary_rays": (C.c_int, [C.c_void_p, _P(xrt_camera), _P(xrt_ray)]),
 }
 

@@ -278,6 +278,12 @@ class OctreeSpatialManager(ISpatialManager):
     def mesh_id(self, mesh):
         return self._mesh_ids[id(mesh)]
 
+    def SplitStats(self, reset=True):
+        """xrt_split_stats: (subtrees handed over, taken, packets split, packets written by a taker) -- diagnostics of the split walks of long packets."""
+        out = (C.c_uint64 * 4)()
+        abi.check(abi.lib().xrt_split_stats(self.handle, out, 1 if reset else 0))
+        return tuple(int(x) for x in out)
+
     def IntersectBatch(self, rays, stats=False):
         """Batched ISpatialManager.GetRayIntersection (ISM:15): xrt_ray array -> xrt_hit array."""
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)

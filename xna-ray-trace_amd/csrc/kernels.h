@@ -99,9 +99,34 @@ struct PacketArgs {
     const int *pathOf1 = nullptr;
     const SlotRec *slotOf1 = nullptr;   // (a launch whose FIRST segment is shadow rays)
     const SlotRec *slotOf2 = nullptr;
+    // Split walks (packet.hip "split walks"): a walk that has outlasted splitBudget ticks of the 100 MHz device clock hands the pending subtrees of its
+    // upper levels to other waves as ITEMS of this launch; the last participant of a packet merges the partial answers (the arg-min rule of DESIGN.md §3
+    // does not depend on who visited what).  splitCtl == nullptr: off.
+    unsigned *splitCtl = nullptr;      // 128-byte aligned, zeroed with the queue heads: a 128-byte line per XCD x -- [32 x] items reserved, [32 x + 1] items taken in the XCD's
+                                       // share of the arena -- and on a ninth line [256] records allocated.  An item is taken by a wave of the XCD it was given on (a packet's
+                                       // participants share an L2), and every wave asking for work asks one of eight addresses instead of one
+    unsigned *splitItems = nullptr;    // SPLIT_ITEM_WORDS per item
+    unsigned *splitRecs = nullptr;     // SPLIT_REC_WORDS per packet that was split
+    int splitNI = 0, splitNR = 0;      // capacities
+    unsigned splitSerial = 0;          // this launch's number: the value of an item's `ready` word (the arena is never cleared)
+    int splitBudget = 0, splitBudgetItem = 0;   // ticks a packet / an item may walk before it looks for pending subtrees to hand over
+    // ... and which packets are split EAGERLY: a packet remembers what it cost (ticks; a split packet keeps the larger of that and what it remembered) in
+    // splitCost[packet number], and the same packet of the context's next frame, if that is above splitLong, hands pending subtrees over every splitBudgetLong
+    // ticks from the start, as do the takers of its items.  (Waiting for a walk to PROVE long costs half of it; splitting every walk early is speculation --
+    // the far siblings of a ray that is about to find a near hit would have been pruned: measured 2-3 x the frame time, profiles/r04/split_walks.txt.)
+    unsigned *splitCost = nullptr;
+    int splitLong = 0, splitBudgetLong = 0;
 };
 constexpr int PACKET_QUEUE_HEADS = 8, PACKET_HEAD_STRIDE = 64;   // every head on a 256-byte line of its own: atomics on one line serialise whatever the word
-constexpr int PACKET_QUEUE_WORDS = PACKET_QUEUE_HEADS * PACKET_HEAD_STRIDE;
+constexpr int PACKET_SPLIT_WORDS = 320;                          // ... and behind the heads the lines of the split-walk counters (PacketArgs::splitCtl: 9 x 128 bytes, aligned)
+constexpr int PACKET_QUEUE_WORDS = PACKET_QUEUE_HEADS * PACKET_HEAD_STRIDE + PACKET_SPLIT_WORDS;
+// an item: [0] ready (== PacketArgs::splitSerial), [1] packet, [2] record, [3] block, [4] pending children (front-to-back bits), [5..6] lanes, [7] the taker's budget, [32..95] the lanes' accepted
+// children of that block (cb), [96..] the lanes' best answers so far, 7 words each ([word][lane]: found, key, distance, u, v, reference, leaf) -- on the way in what the
+// giver had when it gave, on the way out what the taker has; a record: [0] units outstanding (the packet itself + its items), [1] items -- a line that only atomics
+// touch --, [32..63] their indices, [64..] the packet's own partial answers
+constexpr int SPLIT_HEAD_WORDS = 32, SPLIT_PART_WORDS = 7 * 64, SPLIT_ITEM_WORDS = SPLIT_HEAD_WORDS + 64 + SPLIT_PART_WORDS, SPLIT_REC_HEAD = 64, SPLIT_REC_WORDS = SPLIT_REC_HEAD + SPLIT_PART_WORDS;
+constexpr int SPLIT_REC_ITEMS = 32;
+int  packet_split_stats(unsigned long long out[4], bool reset);   // (packet.hip g_splitStats on the current device)
 bool packet_supported(int mode, int meshDepth, int sceneDepth);
 int  packet_blocks_per_cu(int mode);
 void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);

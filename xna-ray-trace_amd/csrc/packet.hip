@@ -40,7 +40,8 @@ namespace xrt {
 constexpr int PK_LEVELS = 24;        // deeper octrees than this fall back to k_intersect (scene_build limits depth to 20)
 constexpr int PK_FRAME_WORDS = 4;    // blk, pending children (the first lane's order is found again from the lanes), lanes (2): one 16-byte LDS access
 // a wave's stack: PK_LEVELS frames, then per level one byte per lane -- which children of that level's block the lane's own box tests accepted
-constexpr int PK_STACK_WORDS = PK_LEVELS * (PK_FRAME_WORDS + 16);
+constexpr int PK_SPLIT_AT = PK_LEVELS * (PK_FRAME_WORDS + 16);   // ... and behind them the wave's split-walk words (pk_walk): record, item, budget, budget clock, packet
+constexpr int PK_STACK_WORDS = PK_SPLIT_AT + 8;
 constexpr int PK_SLEVELS = 12;       // scene octree levels a packet can stack (deeper scene trees: k_intersect)
 constexpr int PK_SFRAME_WORDS = 4;   // scene block, pending children, lanes (2)
 #ifndef XRT_PK_QUEUES
@@ -70,8 +71,19 @@ __device__ unsigned g_pkCur[8 * 65536];         // (per resident wave: this pack
 #define PKC(i) ((void)0)
 #endif
 
+__device__ unsigned long long g_splitStats[4];   // split walks (pk_walk): subtrees handed over, taken, packets split, packets whose results a taker wrote (xrt_split_stats)
 struct alignas(4) TriWords { float w[16]; };   // a 13-word record of refT and the first three words of the next one
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Data that waves hand each other inside a launch (split walks): every word of it is written with an agent-scope store and read with an agent-scope load (sc1: past the
+// CU's L1 and whatever the XCD's L2 holds), ordered by waiting for the stores -- no cache-wide operation.  Measured on the way here (profiles/r04/split_walks.txt):
+// __threadfence() (write the whole L2 back, invalidate it) costs every CU of the XCD ~1 us per call; a workgroup-scope (sc0) load may be served by the CU's L1 for ever;
+// a workgroup-scope release fence is no instruction at all outside threadgroup-split mode, and two stores of one wave to two L2 channels do overtake each other.
+__device__ __forceinline__ unsigned ld_ag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_ag(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void loads_after() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// the XCD this wave runs on (HW_REG_XCC_ID = 20, bits 3:0; gfx950: eight XCDs with an L2 each)
+__device__ __forceinline__ unsigned xcc_id() { return (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u; }
 __device__ __forceinline__ float rflf(float v) { return i2f(__builtin_amdgcn_readfirstlane(f2i(v))); }
 
 struct PkUniform {   // wave-uniform cursor
@@ -217,14 +229,55 @@ __device__ __forceinline__ void pk_scan_leaf(const float *__restrict__ refT, int
     }
 }
 
+// Arguments a packet needs once -- its ray / hit arrays, the queue, the tile-cost words, the arrays lane_result reads -- are RE-READ from the
+// kernel-argument segment where they are used (scalar loads from constant memory, the pointer passed through an empty asm per packet so
+// that the loads stay inside the loop) instead of living in scalar registers across the walk: the allocator kept them in SGPRs spilled to
+// vector-register lanes (v_writelane / v_readlane) around every walk.  Offsets: the eight pointer parameters, then SceneView, then PacketArgs,
+// each at its natural alignment (checked against the code object's metadata in tests/test_numerics_contract.py).
+constexpr unsigned PK_KERNARG_SCENE = 8 * 8, PK_KERNARG_ARGS = PK_KERNARG_SCENE + (unsigned)sizeof(SceneView);
+static_assert(sizeof(SceneView) % 8 == 0 && alignof(PacketArgs) == 8, "kernel-argument offsets of k_packet");
+typedef const __attribute__((address_space(4))) PacketArgs *PkArgsK;
+typedef const __attribute__((address_space(4))) SceneView *PkSceneK;
+struct PkKernarg {
+    unsigned long long base;
+    __device__ __forceinline__ PkKernarg() : base((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr()) {}
+    // (the loads that follow cannot be hoisted above this point: the pointer's halves go through an empty asm; the readfirstlane in front
+    // of it guarantees the asm's scalar-register operand whatever register class the allocator keeps `base` in)
+    __device__ __forceinline__ void fresh() {
+        unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
+        asm volatile("" : "+s"(lo), "+s"(hi));
+        base = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    }
+    __device__ __forceinline__ PkArgsK args() const { return (PkArgsK)(base + PK_KERNARG_ARGS); }
+    __device__ __forceinline__ PkSceneK scene() const { return (PkSceneK)(base + PK_KERNARG_SCENE); }
+    // what lane_result (traverse.h) reads of the scene
+    __device__ __forceinline__ SceneView result_view() const {
+        const PkSceneK k = scene();
+        SceneView v = {};
+        v.refG = k->refG; v.refN = k->refN; v.meshes = k->meshes; v.childDfs = k->childDfs; v.objects = k->objects;
+        return v;
+    }
+};
+
 // One shared walk of the mesh octree whose root block is `rootBlock` for the lanes `lanes0`: the lanes whose ray passed the root's own
 // box test (MO:265 / MO:331).  On return every lane's L.mfound / mKey / mDist / mU / mV / mRef / mLeaf hold its answer of
 // MeshOctree.GetRayIntersection (the caller cleared mfound).  Everything the walk reads comes from three arrays -- pblocks (descriptor +
 // child planes per block), lrec (per node: normal box, tight box, first run; the run records behind them), refT (triangles) --: three base
 // pointers in scalar registers where round 3 held six, no parent box, no child box arithmetic.
+//
+// Split walks (`budget` != 0, PacketArgs::splitCtl).  A launch ends when its longest packet does, and packets are heavy-tailed: rays that skim a terrain near the
+// horizon walk tens of times the median (a 1/8 tile shard of C5: median ~50 us, the longest 722 us -- longer than the whole launch should take).  The walk is one
+// instruction stream, but the arg-min it computes does not care who visits what: a walk that has outlasted `budget` ticks of the 100 MHz device clock hands the
+// PENDING children of its stacked levels (the later siblings of the path it is on) to other waves -- per level one ITEM (block, pending children, lanes, the lanes'
+// accepted children, the lanes' best answers so far as a pruning hint) in this launch's item queue -- and walks on with what is left.  A wave that takes an item
+// sets the packet's rays up again, seeds level 0 of its stack with the item and starts by "coming back" to it (`resume`); it may split again.  Every participant
+// leaves its lanes' answers in the arena; the one that finishes last (PacketArgs::splitRecs [0], a count of units outstanding: nobody ever waits for anybody)
+// merges them with the rule of DESIGN.md §3 and writes the packet's results.
+template <bool SPLIT>
 __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const float *__restrict__ refT, const float *__restrict__ lrec,
                                         const SceneView &S, int cullMin, unsigned *stk, int lane, Lane &L,
-                                        const RayCull &RC, bool fastL, int rootBlock, unsigned long long lanes0, bool nodeCull) {
+                                        const RayCull &RC, bool fastL, int rootBlock, unsigned long long lanes0, bool nodeCull,
+                                        bool resume = false) {
 #ifdef XRT_PK_COUNTERS
     unsigned pkc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     pkc[0] = 1;
@@ -235,10 +288,66 @@ __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const
     U.lanes = lanes0;
     U.p = 0; U.dm0 = 0;
     unsigned char *const cbOf = reinterpret_cast<unsigned char *>(stk + PK_LEVELS * PK_FRAME_WORDS) + lane;   // [level * 64]: this lane's byte
-    int sp = 0;
-    bool entering = true, anyFound = false;   // anyFound: some lane of the wave has a candidate
+    int sp = resume ? 1 : 0;   // (resume: level 0 holds the item, the walk starts by coming back to it)
+    bool entering = !resume, anyFound = resume && __any(L.mfound != 0);   // anyFound: some lane of the wave has a candidate
     PkBlockWords B;
     int cb = 0;
+    unsigned *const sst = stk + PK_SPLIT_AT;   // [0] the packet's record (-1: none), [1] the item being traced (-1: the packet itself), [2] budget (0: off), [3] the clock it counts from, [4] packet
+    // Hand the pending children of levels 0 .. sp-1 to other waves of this XCD (wave-uniform, rare).  What they read of it has arrived (stores_done) before the item's
+    // `ready` word is written; the counters -- queue, units outstanding, items of a record -- are only ever touched by atomics and agent-scope loads.
+    auto spill = [&]() {
+        PkKernarg K;
+        K.fresh();
+        const PkArgsK a = K.args();
+        unsigned *const ctl = a->splitCtl, *const itemsB = a->splitItems, *const recsB = a->splitRecs;
+        const int NR = a->splitNR;
+        const unsigned serial = a->splitSerial, xcc = xcc_id(), NIx = (unsigned)a->splitNI / 8u;
+        const unsigned myBudget = (unsigned)rfl((int)sst[2]), takerBudget = myBudget == (unsigned)a->splitBudgetLong ? myBudget : (unsigned)a->splitBudgetItem;   // (an eagerly split packet stays one)
+        int rec = rfl((int)sst[0]);
+        for (int lvl = 0; lvl < sp; lvl++) {
+            const Frame4 f = *reinterpret_cast<const Frame4 *>(stk + lvl * PK_FRAME_WORDS);
+            const unsigned p = (unsigned)rfl((int)f.b);
+            if (p == 0u) continue;
+            if (rec < 0) {   // the packet's record: one unit outstanding (whoever traces the packet itself), no items yet
+                unsigned r = 0u;
+                if (lane == 0) r = atomicAdd(ctl + 256, 1u);
+                rec = rfl((int)r);
+                if (rec >= NR) { rec = -1; break; }
+                if (lane == 0) {
+                    unsigned *const R0 = recsB + (size_t)rec * SPLIT_REC_WORDS;
+                    (void)atomicExch(R0, 1u); (void)atomicExch(R0 + 1, 0u);
+                    sst[0] = (unsigned)rec;
+                    atomicAdd(&g_splitStats[2], 1ull);
+                }
+            }
+            unsigned *const R = recsB + (size_t)rec * SPLIT_REC_WORDS;
+            unsigned j = 0u, idx = 0u;
+            if (lane == 0) j = atomicAdd(R + 1, 1u);
+            j = (unsigned)rfl((int)j);
+            if (j >= (unsigned)SPLIT_REC_ITEMS) break;   // (readers clamp the count)
+            if (lane == 0) idx = atomicAdd(ctl + 32u * xcc, 1u);
+            idx = (unsigned)rfl((int)idx);
+            if (idx >= NIx) { if (lane == 0) st_ag(R + 32 + j, 0xffffffffu); break; }   // (takers clamp the tail)
+            idx += xcc * NIx;
+            unsigned *const I = itemsB + (size_t)idx * SPLIT_ITEM_WORDS;
+            if (lane == 0) {
+                st_ag(I + 1, sst[4]); st_ag(I + 2, (unsigned)rec); st_ag(I + 3, (unsigned)rfl((int)f.a)); st_ag(I + 4, p); st_ag(I + 5, (unsigned)rfl((int)f.c)); st_ag(I + 6, (unsigned)rfl((int)f.d)); st_ag(I + 7, takerBudget);
+                st_ag(R + 32 + j, idx);
+                (void)atomicAdd(R, 1u);                  // one more unit outstanding, before anybody can take it
+                atomicAdd(&g_splitStats[0], 1ull);
+                stk[lvl * PK_FRAME_WORDS + 1] = 0u;      // these children are no longer this walk's
+            }
+            st_ag(I + SPLIT_HEAD_WORDS + lane, (unsigned)cbOf[lvl * 64]);
+            unsigned *const P = I + SPLIT_HEAD_WORDS + 64 + lane;
+            st_ag(P, (unsigned)L.mfound); st_ag(P + 64, (unsigned)f2i(L.mKey)); st_ag(P + 128, (unsigned)f2i(L.mDist)); st_ag(P + 192, (unsigned)f2i(L.mU)); st_ag(P + 256, (unsigned)f2i(L.mV));
+            st_ag(P + 320, (unsigned)L.mRef); st_ag(P + 384, (unsigned)L.mLeaf);
+            stores_done();
+            if (lane == 0) st_ag(I, serial);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     // The scalar unit is shared by the CU's four SIMDs, so scalar instructions are the scarce resource of this kernel
     // (measured: 3,900 per packet against 4,000 vector ones made it scalar-bound): the pending children are a bit mask
     // walked with ctz, the lanes of a leaf are selected once for the whole leaf, a triangle costs one wave-level branch.
@@ -246,6 +355,13 @@ __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const
         const bool in = ((U.lanes >> lane) & 1ull) != 0;
         if (entering) {
             PKC(1);
+            if (SPLIT && sp > 0) {   // (wave-uniform) has this walk been going on for long?  Then let others have what is pending above
+                const unsigned budget = (unsigned)rfl((int)sst[2]);
+                if (budget != 0u && (unsigned)wall_clock64() - (unsigned)rfl((int)sst[3]) > budget) {
+                    spill();
+                    if (lane == 0) sst[3] = (unsigned)wall_clock64();
+                }
+            }
             B = *reinterpret_cast<const PkBlockWords *>(pblocks + (size_t)U.blk * PBLOCK_WORDS);
             cb = 0;
             if (in) cb = fastL ? pk_hit8_fast(L.r, B) : pk_hit8_slow(L.r, B);
@@ -421,41 +537,14 @@ template <int M> __device__ __forceinline__ unsigned *scene_frames() {
     else return nullptr;
 }
 
-// Arguments a packet needs once -- its ray / hit arrays, the queue, the tile-cost words, the arrays lane_result reads -- are RE-READ from the
-// kernel-argument segment where they are used (scalar loads from constant memory, the pointer passed through an empty asm per packet so
-// that the loads stay inside the loop) instead of living in scalar registers across the walk: the allocator kept them in SGPRs spilled to
-// vector-register lanes (v_writelane / v_readlane) around every walk.  Offsets: the eight pointer parameters, then SceneView, then PacketArgs,
-// each at its natural alignment (checked against the code object's metadata in tests/test_numerics_contract.py).
-constexpr unsigned PK_KERNARG_SCENE = 8 * 8, PK_KERNARG_ARGS = PK_KERNARG_SCENE + (unsigned)sizeof(SceneView);
-static_assert(sizeof(SceneView) % 8 == 0 && alignof(PacketArgs) == 8, "kernel-argument offsets of k_packet");
-typedef const __attribute__((address_space(4))) PacketArgs *PkArgsK;
-typedef const __attribute__((address_space(4))) SceneView *PkSceneK;
-struct PkKernarg {
-    unsigned long long base;
-    __device__ __forceinline__ PkKernarg() : base((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr()) {}
-    // (the loads that follow cannot be hoisted above this point: the pointer's halves go through an empty asm; the readfirstlane in front
-    // of it guarantees the asm's scalar-register operand whatever register class the allocator keeps `base` in)
-    __device__ __forceinline__ void fresh() {
-        unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
-        asm volatile("" : "+s"(lo), "+s"(hi));
-        base = (unsigned long long)lo | ((unsigned long long)hi << 32);
-    }
-    __device__ __forceinline__ PkArgsK args() const { return (PkArgsK)(base + PK_KERNARG_ARGS); }
-    __device__ __forceinline__ PkSceneK scene() const { return (PkSceneK)(base + PK_KERNARG_SCENE); }
-    // what lane_result (traverse.h) reads of the scene
-    __device__ __forceinline__ SceneView result_view() const {
-        const PkSceneK k = scene();
-        SceneView v = {};
-        v.refG = k->refG; v.refN = k->refN; v.meshes = k->meshes; v.childDfs = k->childDfs; v.objects = k->objects;
-        return v;
-    }
-};
-
 #ifndef PK_SCENE_WAVES
 #define PK_SCENE_WAVES 5   // waves per SIMD the scene variant is compiled for: 96 VGPRs + 44 bytes of scratch per lane, touched per packet (not per step): C3 -5 %, C4 -7.5 % against 4 waves at 106 VGPRs (profiles/r03/packet_scene_five_waves.txt; at 111 VGPRs the same switch lost)
 #endif
-template <int M>
-__global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGLE_WAVES >= 7 ? 7 : 1)) __attribute__((amdgpu_num_sgpr(PK_SGPRS))) void k_packet(const float *__restrict__ pblocks, const float *__restrict__ refT,
+// SP: the split-walk variant (pk_walk: PacketArgs::splitCtl != nullptr selects it at launch).  The variant without it is the kernel of round 3 / 4 instruction for
+// instruction: the one-body kernel sits at the edge of its register budget (80 vector registers for six waves per SIMD, ~80 spilled scalars), and code that merely
+// EXISTS beside the walk moved spills into its loops (measured: a frame of twice the length with the switch off).
+template <int M, bool SP>
+__global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGLE_WAVES >= 7 ? 7 : (SP ? 6 : 1))) __attribute__((amdgpu_num_sgpr(PK_SGPRS))) void k_packet(const float *__restrict__ pblocks, const float *__restrict__ refT,
                                                 const float *__restrict__ lrec, const MeshRec *__restrict__ meshes,
                                                 const f4 *__restrict__ snodes, const f4 *__restrict__ scull, const ObjRec *__restrict__ objects,
                                                 const int *__restrict__ objMesh, SceneView S, PacketArgs A) {
@@ -498,45 +587,108 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
     for (int h = 0; h < PK_QUEUES; h++) if (dynTotal - h <= 0) dead |= 1u << h;
     int cur = waveId % PK_QUEUES, seen = 0, curR = cur;   // the head this wave draws from, the last ticket it saw there; curR: head of the range in hand
     int sNext = 0, dNext = 0, dEnd = 0;   // dNext .. dEnd: tickets of head curR
+    // Split walks (pk_walk): the launch's items come first -- they are what a long packet's critical path is made of -- and a wave leaves only when it
+    // has seen the item queue empty AFTER its own last walk (whatever a walk hands over late is taken by someone who is still there, at the latest by
+    // the giver itself).  Nobody waits: taking is a compare-and-swap on the count of items taken.
+    constexpr bool splitOn = SP && M != MODE_SCENE;
+    unsigned *const sst = stk + PK_SPLIT_AT;
+    if (splitOn && lane == 0) sst[2] = 0u;   // (no budget: the walks of this wave are not split until a packet says so)
+    bool mainDone = false;
     for (;;) {
-        int pk;
-        if (sNext < staticPer) {
-            pk = sNext * nWaves + waveId; sNext++;
-            if (pk >= nPk) { if (qBase >= nPk) break; continue; }   // (only where the static share is the one packet per wave above)
-        }
-        else {
-            if (qBase >= nPk) break;
-            if (dNext >= dEnd) {
-                bool got = false;
-                while (dead != (1u << PK_QUEUES) - 1u) {   // at most PK_QUEUES failed requests per wave and launch
-                    if ((dead >> cur) & 1u) {
-                        const unsigned alive = ~dead & ((1u << PK_QUEUES) - 1u);
-                        const unsigned rot = ((alive >> cur) | (alive << (PK_QUEUES - cur))) & ((1u << PK_QUEUES) - 1u);
-                        cur = (cur + (int)__builtin_ctz(rot)) % PK_QUEUES;
-                        seen = 0;
-                    }
-                    const int len = (dynTotal - cur + PK_QUEUES - 1) / PK_QUEUES;   // tickets of this head
-                    int want = (len - seen) / (nWaves / PK_QUEUES * 2 + 1);   // guided: a share of what is left of this head's tickets
-                    KA.fresh();
-                    const int grabMax = KA.args()->grabMax;
-                    want = want < 1 ? 1 : (want > grabMax ? grabMax : want);
-                    unsigned g = 0;
-                    if (lane == 0) g = atomicAdd(KA.args()->queue + cur * PACKET_HEAD_STRIDE, (unsigned)want);
-                    const int head = rfl((int)g);
-                    if (head >= 0 && head < len) { dNext = head; dEnd = min(head + want, len); seen = dEnd; curR = cur; got = true; break; }
-                    dead |= 1u << cur;
-                }
-                if (!got) break;
+        int pk = -1, item = -1;
+        bool contended = false;   // an item was there but another wave took it
+        if (splitOn) {
+            KA.fresh();
+            const unsigned xcc = xcc_id(), NIx = (unsigned)KA.args()->splitNI / 8u;
+            // this XCD's queue.  Control words live on the memory side: atomics execute there, and these loads (agent scope: past the L2, which
+            // keeps whatever it read before) look there; one lane asks -- 64 lanes asking one address are served one after the other.  ONE attempt:
+            // hundreds of waves retrying at once are hundreds of atomics on one address, ~12 ns each, for every item (measured: a frame of six times the length).
+            unsigned *const ctl = KA.args()->splitCtl + 32u * xcc;
+            unsigned long long th = 0ull;
+            if (lane == 0) th = __hip_atomic_load(reinterpret_cast<unsigned long long *>(ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned t = (unsigned)rfl((int)(unsigned)th), h = (unsigned)rfl((int)(unsigned)(th >> 32));
+            if (h < (t < NIx ? t : NIx)) {
+                unsigned old = 0u;
+                if (lane == 0) old = atomicCAS(ctl + 1, h, h + 1u);
+                if ((unsigned)rfl((int)old) == h) item = (int)(xcc * NIx + h);
+                else contended = true;
             }
-            pk = qBase + PK_QUEUES * dNext + curR;
-            dNext++;
+        }
+        if (item < 0) {
+            if (mainDone) {   // on the way out: only a queue SEEN empty lets a wave leave
+                if (!contended) break;
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            if (sNext < staticPer) {
+                pk = sNext * nWaves + waveId; sNext++;
+                if (pk >= nPk) {   // (only where the static share is the one packet per wave above)
+                    if (qBase >= nPk) { if constexpr (!splitOn) break; else mainDone = true; }
+                    continue;
+                }
+            }
+            else {
+                if (qBase >= nPk) { if constexpr (!splitOn) break; else { mainDone = true; continue; } }
+                if (dNext >= dEnd) {
+                    bool got = false;
+                    while (dead != (1u << PK_QUEUES) - 1u) {   // at most PK_QUEUES failed requests per wave and launch
+                        if ((dead >> cur) & 1u) {
+                            const unsigned alive = ~dead & ((1u << PK_QUEUES) - 1u);
+                            const unsigned rot = ((alive >> cur) | (alive << (PK_QUEUES - cur))) & ((1u << PK_QUEUES) - 1u);
+                            cur = (cur + (int)__builtin_ctz(rot)) % PK_QUEUES;
+                            seen = 0;
+                        }
+                        const int len = (dynTotal - cur + PK_QUEUES - 1) / PK_QUEUES;   // tickets of this head
+                        int want = (len - seen) / (nWaves / PK_QUEUES * 2 + 1);   // guided: a share of what is left of this head's tickets
+                        KA.fresh();
+                        const int grabMax = KA.args()->grabMax;
+                        want = want < 1 ? 1 : (want > grabMax ? grabMax : want);
+                        unsigned g = 0;
+                        if (lane == 0) g = atomicAdd(KA.args()->queue + cur * PACKET_HEAD_STRIDE, (unsigned)want);
+                        const int head = rfl((int)g);
+                        if (head >= 0 && head < len) { dNext = head; dEnd = min(head + want, len); seen = dEnd; curR = cur; got = true; break; }
+                        dead |= 1u << cur;
+                    }
+                    if (!got) { if constexpr (!splitOn) break; else { mainDone = true; continue; } }
+                }
+                pk = qBase + PK_QUEUES * dNext + curR;
+                dNext++;
+            }
+        }
+        // an item: wait for its giver to have finished writing it (it is between reserving the index and this store, and waits for nobody), then its header
+        unsigned *itemW = nullptr;
+        if (item >= 0) {
+            KA.fresh();
+            itemW = KA.args()->splitItems + (size_t)item * SPLIT_ITEM_WORDS;
+            const unsigned serial = KA.args()->splitSerial;
+            for (;;) {
+                unsigned rdy = 0u;
+                if (lane == 0) rdy = ld_ag(itemW);
+                if ((unsigned)rfl((int)rdy) == serial) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            loads_after();
+            pk = rfl((int)ld_ag(itemW + 1));
+            if (lane == 0) atomicAdd(&g_splitStats[1], 1ull);
+        }
+        if (splitOn && lane == 0) {
+            sst[0] = item >= 0 ? ld_ag(itemW + 2) : 0xffffffffu;
+            unsigned budget = (unsigned)KA.args()->splitBudget, pred = 0u;
+            if (item >= 0) budget = ld_ag(itemW + 7);
+            else if (KA.args()->splitCost) { pred = KA.args()->splitCost[pk]; if (pred > (unsigned)KA.args()->splitLong) budget = (unsigned)KA.args()->splitBudgetLong; }   // (what this packet cost in the context's last frame)
+            sst[1] = (unsigned)item; sst[2] = budget; sst[3] = (unsigned)wall_clock64(); sst[4] = (unsigned)pk; sst[5] = pred;
+        }
+        if (splitOn) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         // ---- the packet's 64 rays ------------------------------------------------------------------------------------
         KA.fresh();
 #ifdef XRT_PK_TICKS
         const bool costed = true;
 #else
-        const bool costed = KA.args()->tileCost != nullptr;
+        const bool costed = KA.args()->tileCost != nullptr || (splitOn && KA.args()->splitCost != nullptr);
 #endif
         const unsigned long long tPacket = costed ? wall_clock64() : 0ull;
         const bool seg2 = pk >= nPk1;   // wave-uniform
@@ -568,11 +720,65 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
             // (S.nodeCull: 1 = packets of rays that leave a surface -- the shadow rays and reflections of a frame --, 2 = every packet)
             const bool nodeCull = S.nodeCull == 2 || (S.nodeCull == 1 && __any(valid && L.ignoreId >= 0));
             const bool meshAway = nodeCull && all_back_facing(f4{mr.nbMin[0], mr.nbMin[1], mr.nbMin[2], mr.nbMin[3]}, f4{mr.nbMax[0], mr.nbMax[1], mr.nbMax[2], mr.nbMax[3]}, L.r.d);
-            const unsigned long long lanes0 = mr.rootBlock < 0 ? 0ull : __ballot(valid && L.state == ST_NODE && L.mask != 0 && !meshAway);
-            pk_walk(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, lanes0, nodeCull);
+            unsigned long long lanes0 = mr.rootBlock < 0 ? 0ull : __ballot(valid && L.state == ST_NODE && L.mask != 0 && !meshAway);
+            if (splitOn) {
+                if (item >= 0) {   // level 0 of the stack := the item; the lanes' answers so far := what its giver had (a pruning hint, and a candidate like any other)
+                    const unsigned *const P = itemW + SPLIT_HEAD_WORDS + 64 + lane;
+                    L.mfound = (int)ld_ag(P); L.mKey = i2f((int)ld_ag(P + 64)); L.mDist = i2f((int)ld_ag(P + 128)); L.mU = i2f((int)ld_ag(P + 192)); L.mV = i2f((int)ld_ag(P + 256));
+                    L.mRef = (int)ld_ag(P + 320); L.mLeaf = (int)ld_ag(P + 384);
+                    reinterpret_cast<unsigned char *>(stk + PK_LEVELS * PK_FRAME_WORDS)[lane] = (unsigned char)ld_ag(itemW + SPLIT_HEAD_WORDS + lane);
+                    const unsigned hw = lane < 4 ? ld_ag(itemW + 3 + lane) : 0u;   // block, pending children, lanes (2)
+                    if (lane < 4) stk[lane] = hw;
+                    lanes0 = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hw, 2) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hw, 3) << 32);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+            pk_walk<splitOn>(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, lanes0, nodeCull, splitOn && item >= 0);
             L.mesh = mesh;
             KA.fresh();
-            if (valid) {
+            bool mine = true;   // this wave writes the packet's results
+            if (splitOn) {
+                const int rec = rfl((int)sst[0]);
+                if (rec >= 0) {   // the packet was split: leave this participant's answers, and if it is the last one merge them all
+                    const int itemA = rfl((int)sst[1]);
+                    unsigned *const R = KA.args()->splitRecs + (size_t)rec * SPLIT_REC_WORDS;
+                    unsigned *const P = (itemA >= 0 ? KA.args()->splitItems + (size_t)itemA * SPLIT_ITEM_WORDS + SPLIT_HEAD_WORDS + 64 : R + SPLIT_REC_HEAD) + lane;
+                    st_ag(P, (unsigned)L.mfound); st_ag(P + 64, (unsigned)f2i(L.mKey)); st_ag(P + 128, (unsigned)f2i(L.mDist)); st_ag(P + 192, (unsigned)f2i(L.mU)); st_ag(P + 256, (unsigned)f2i(L.mV));
+                    st_ag(P + 320, (unsigned)L.mRef); st_ag(P + 384, (unsigned)L.mLeaf);
+                    stores_done();
+                    unsigned left = 0u;
+                    if (lane == 0) left = atomicSub(R, 1u);
+                    mine = rfl((int)left) == 1;
+                    if (mine) {
+                        loads_after();
+                        if (itemA >= 0 && lane == 0) atomicAdd(&g_splitStats[3], 1ull);
+                        const SceneView Sr = KA.result_view();
+                        int nIt = rfl((int)__hip_atomic_load(R + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if (nIt > SPLIT_REC_ITEMS) nIt = SPLIT_REC_ITEMS;
+                        for (int j = -1; j < nIt; j++) {   // (-1: the packet's own partial answers)
+                            const unsigned *Q = R + SPLIT_REC_HEAD + lane;
+                            if (j >= 0) {
+                                const unsigned ix = (unsigned)rfl((int)ld_ag(R + 32 + j));
+                                if (ix == 0xffffffffu) continue;
+                                Q = KA.args()->splitItems + (size_t)ix * SPLIT_ITEM_WORDS + SPLIT_HEAD_WORDS + 64 + lane;
+                            }
+                            const int qf = (int)ld_ag(Q), qRef = (int)ld_ag(Q + 320), qLeaf = (int)ld_ag(Q + 384);
+                            const float qKey = i2f((int)ld_ag(Q + 64)), qD = i2f((int)ld_ag(Q + 128)), qU = i2f((int)ld_ag(Q + 192)), qV = i2f((int)ld_ag(Q + 256));
+                            // the rule of pk_candidate / leaf_candidate between two candidates of different participants: key, distance, then the leaves' DFS numbers
+                            // (a leaf belongs to one participant; the same candidate may arrive twice: a taker starts from its giver's)
+                            if (qf != 0) {   // (the words of a lane without a candidate mean nothing)
+                                bool better = (L.mfound == 0) | (qKey < L.mKey) | ((qKey == L.mKey) & (qD < L.mDist));
+                                if ((L.mfound != 0) & (qKey == L.mKey) & (qD == L.mDist))
+                                    better = qLeaf != L.mLeaf ? node_dfs(Sr, qLeaf) < node_dfs(Sr, L.mLeaf) : qRef < L.mRef;
+                                if (better) { L.mfound = 1; L.mKey = qKey; L.mDist = qD; L.mU = qU; L.mV = qV; L.mRef = qRef; L.mLeaf = qLeaf; }
+                            }
+                        }
+                    }
+                }
+            }
+            if (valid && mine) {
                 const SceneView Sr = KA.result_view();
                 const HitOut h = lane_result(L, C, Sr, M);
                 xrt_hit *const hitsS = seg2 ? KA.args()->hits2 : KA.args()->hits;
@@ -697,7 +903,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
                                 const bool meshAway = nodeCull && all_back_facing(f4{mr.nbMin[0], mr.nbMin[1], mr.nbMin[2], mr.nbMin[3]}, f4{mr.nbMax[0], mr.nbMax[1], mr.nbMax[2], mr.nbMax[3]}, L.r.d);
                                 const unsigned long long lanes0 = __ballot(inRoot && !meshAway);
                                 if (lanes0 != 0ull)
-                                    pk_walk(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, lanes0, nodeCull);
+                                    pk_walk<false>(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, lanes0, nodeCull);
                             }
                             if (L.mfound) {   // OSM:370-378
                                 L.mesh = m; C.obj = o;
@@ -742,7 +948,13 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
             }
             if (lane == 0 && KA.args()->tileCost) {
 #else
-            if (lane == 0) {
+            if constexpr (splitOn) {   // what the packet cost, for the same packet of the context's next frame (kernels.h PacketArgs::splitCost): items do not write, a split packet stays long
+                if (splitOn && lane == 0 && KA.args()->splitCost && (int)sst[1] < 0) {
+                    const unsigned pred = sst[5];
+                    KA.args()->splitCost[pk] = ((int)sst[0] >= 0 && pred > dt) ? pred : dt;
+                }
+            }
+            if (lane == 0 && KA.args()->tileCost) {
 #endif
                 const PkArgsK a = KA.args();
                 const int first = (seg2 ? pk - nPk1 : pk) * 64;
@@ -759,6 +971,12 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
     stamp_end(KA.args()->stamps);
 }
 
+int packet_split_stats(unsigned long long out[4], bool reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_splitStats), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_splitStats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+
 bool packet_supported(int mode, int meshDepth, int sceneDepth) {
     if (mode == MODE_SCENE) return meshDepth + 1 < PK_LEVELS && sceneDepth + 1 < PK_SLEVELS;   // (meshes whose root is a leaf are handled here)
     return (mode == MODE_SINGLE || mode == MODE_MESH) && meshDepth > 0 && meshDepth + 1 < PK_LEVELS;
@@ -766,9 +984,9 @@ bool packet_supported(int mode, int meshDepth, int sceneDepth) {
 
 int packet_blocks_per_cu(int mode) {
     int nb = 0;
-    hipError_t e = mode == MODE_MESH ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_packet<MODE_MESH>, 256, 0)
-                   : (mode == MODE_SCENE ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_packet<MODE_SCENE>, 256, 0)
-                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_packet<MODE_SINGLE>, 256, 0));
+    hipError_t e = mode == MODE_MESH ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_packet<MODE_MESH, false>, 256, 0)
+                   : (mode == MODE_SCENE ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_packet<MODE_SCENE, false>, 256, 0)
+                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_packet<MODE_SINGLE, false>, 256, 0));
     if (e != hipSuccess || nb < 1) nb = 1;
     // 800 SGPRs per SIMD, allocated in sixteens plus sixteen per wave: the API does not account for it in the 81-112 range
     const int bySgpr = 800 / (((PK_SGPRS + 15) / 16) * 16 + 16);
@@ -798,12 +1016,16 @@ extern "C" int xrt_debug_packet_counters(unsigned long long *out16, int reset) {
 
 void launch_packet(const SceneView &S, const PacketArgs &A, int gridBlocks, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     dim3 g((unsigned)gridBlocks), b(256);
-    if (A.mode == MODE_MESH)
-        hipExtLaunchKernelGGL((k_packet<MODE_MESH>), g, b, 0, st, e0, e1, 0, S.pblocks, S.refT, S.lrec, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
-    else if (A.mode == MODE_SCENE)
-        hipExtLaunchKernelGGL((k_packet<MODE_SCENE>), g, b, 0, st, e0, e1, 0, S.pblocks, S.refT, S.lrec, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
-    else
-        hipExtLaunchKernelGGL((k_packet<MODE_SINGLE>), g, b, 0, st, e0, e1, 0, S.pblocks, S.refT, S.lrec, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
+    const bool sp = A.splitCtl != nullptr;   // (one-body scenes only: xrt_api.cpp split_arena)
+    if (A.mode == MODE_MESH) {
+        if (sp) hipExtLaunchKernelGGL((k_packet<MODE_MESH, true>), g, b, 0, st, e0, e1, 0, S.pblocks, S.refT, S.lrec, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
+        else hipExtLaunchKernelGGL((k_packet<MODE_MESH, false>), g, b, 0, st, e0, e1, 0, S.pblocks, S.refT, S.lrec, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
+    } else if (A.mode == MODE_SCENE)
+        hipExtLaunchKernelGGL((k_packet<MODE_SCENE, false>), g, b, 0, st, e0, e1, 0, S.pblocks, S.refT, S.lrec, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
+    else {
+        if (sp) hipExtLaunchKernelGGL((k_packet<MODE_SINGLE, true>), g, b, 0, st, e0, e1, 0, S.pblocks, S.refT, S.lrec, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
+        else hipExtLaunchKernelGGL((k_packet<MODE_SINGLE, false>), g, b, 0, st, e0, e1, 0, S.pblocks, S.refT, S.lrec, S.meshes, S.snodes, S.scull, S.objects, S.objMesh, S, A);
+    }
 }
 
 }  // namespace xrt

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -245,6 +246,13 @@ struct xrt_scene {
     bool packetMerge = true;   // the closest-hit and the shadow packets of a step share one launch (XRT_PK_MERGE=0: two launches, as round 2)
     bool noAnswerAtEmission = false;   // XRT_AE=0: k_shade emits every ray (kernels.h ShadeArgs::ae off)
     int packetCullMin = 4;     // XRT_PK_CULL_MIN (development): leaves with fewer references skip the tight-box test
+    // Split walks (packet.hip): one-body scenes; a packet / an item that has walked for this many microseconds looks for pending subtrees to hand to other waves
+    // (XRT_PK_SPLIT=0: off; XRT_PK_BUDGET / XRT_PK_BUDGET_ITEM in microseconds; XRT_PK_SPLIT_ITEMS: capacity of a frame context's arena)
+    bool packetSplit = false;   // (measured: no gain yet -- profiles/r04/split_walks.txt; XRT_PK_SPLIT=1 switches the split-walk variant of the packet kernel on)
+    int packetBudgetUs = 350, packetBudgetItemUs = 150, packetSplitItems = 8192;
+    int packetLongUs = 0, packetBudgetLongUs = 40;   // XRT_PK_LONG / XRT_PK_BUDGET_LONG: a packet that cost more than the first in the context's last frame hands subtrees over every <second> microseconds from the start (XRT_PK_LONG=0: no prediction)
+    unsigned splitSerial = 0;
+    std::map<int, std::pair<DevBuf<unsigned>, DevBuf<unsigned>>> apiSplit;   // seam 1 (testing aid, XRT_PACKET & 8): an arena per stream
     int packetGrabMax = 2;     // XRT_PK_GRAB (development): 8 -> 2 shortened the tail of a launch (C5 blocking 9.0 -> 7.8 ms); 1 loses to contention on the queue word
     int packetStaticDiv = 4;   // XRT_PK_STATIC (development): 1/2 .. 1/8 measured within 2 % of each other on C5
     int sceneMode = MODE_SCENE;   // MODE_SINGLE when the scene is one SceneObject with one Mesh
@@ -265,6 +273,9 @@ struct xrt_scene {
         DevBuf<int> node0, node1, heapFlag;     // ray-tree frames: heap node of every ray; heapFlag[0]: a generation overflowed its buffers
         DevBuf<float> ref0, ref1, lvlAlpha;     // ... refraction index of the medium a ray travels in; alpha per level record
         DevBuf<int> hitFlags0, shadowFlags;   // hit / miss word per ray of hits, shadowHits (a miss has no record)
+        DevBuf<unsigned> splitCost;               // ... what every packet of every packet launch of the context's last plain frame cost (PacketArgs::splitCost)
+        size_t splitCostStride = 0;               // (packets a launch may have; a frame of another size starts the memory afresh)
+        DevBuf<unsigned> splitItems, splitRecs;   // split walks (kernels.h PacketArgs::splitItems): the arena of this context's packet launches (they run one after the other)
         DevBuf<int> shadowOut;                // ShadeArgs::ae: where the answer of the i-th emitted shadow ray goes (slot * lights + light)
         DevBuf<int> shadowFlags1;             // ShadeArgs::ae: part A of step k answers some shadow queries of generation k ITSELF while part B of the same launch still reads
                                               // generation k-1's words: the generations alternate between shadowFlags and this
@@ -288,7 +299,7 @@ struct xrt_scene {
             rays0.release(); rays1.release(); shadowRays.release(); hits.release(); shadowHits.release();
             path0.release(); path1.release(); index0.release(); heavyList.release(); cnts.release(); stamps.release(); hitFlags0.release(); shadowFlags.release(); shadowOut.release(); shadowFlags1.release();
             node0.release(); node1.release(); heapFlag.release(); ref0.release(); ref1.release(); lvlAlpha.release(); slot0.release(); slot1.release(); slotNode0.release(); slotNode1.release();
-            lvlA.release(); lvlB.release(); sampleColor.release(); sampleF32.release(); lights.release();
+            lvlA.release(); lvlB.release(); sampleColor.release(); sampleF32.release(); lights.release(); splitItems.release(); splitRecs.release(); splitCost.release(); splitCostStride = 0;
             for (auto &l : levels) { l.color.release(); l.childBase.release(); l.childMask.release(); l.cx.release(); l.cy.release(); }
             if (stream) (void)hipStreamDestroy(stream);
             stream = nullptr;
@@ -621,6 +632,7 @@ int make_raygen(const xrt_camera *cam, const xrt_render_opts *o, RayGenParams &g
 // The frame: for every chunk of paths  raygen -> [intersect(closest k + shadow k-1) -> shade(A: k, B: k-1)] x (R+2) -> compose,
 // then resolve (pixel grid, fixed 16 sub-rays) or the quadrant levels of adaptive supersampling (RT:170-311).
 int frame_finish(xrt_scene *s, xrt_scene::FrameCtx &F, xrt_stats *stats);
+int split_arena(xrt_scene *s, DevBuf<unsigned> &items, DevBuf<unsigned> &recs, PacketArgs &PA, hipStream_t st);
 
 // Enqueues one frame on `st`.  On return the frame's kernels and its counter read-back are in flight (F.pending);
 // frame_finish waits for them.  Adaptive supersampling and ray-tree frames need host decisions between their passes and
@@ -962,6 +974,19 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                     if (I2) { PA.slotOf2 = slotOf[prv]; PA.nL2 = nL; }
                 }
                 PA.queue = q + QW * k + 1 + PACKET_QUEUE_WORDS * word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv; PA.grabMax = s->packetGrabMax; PA.cullMin = s->packetCullMin;
+                if (s->packetSplit && s->sceneMode != MODE_SCENE) {
+                    if ((rc = split_arena(s, W.splitItems, W.splitRecs, PA, st))) return rc;
+                    if (fast && !adaptive && !heap && s->packetLongUs > 0) {   // plain frames: the packets of launch #k are the same from frame to frame while the camera stands still, and nearly so while it moves
+                        const size_t stride = (rayCap + 63) / 64 + ((size_t)shadowCap * (size_t)(nL > 0 ? nL : 1) + 63) / 64 + 2;
+                        if (W.splitCostStride != stride || !W.splitCost.p) {
+                            if ((rc = W.splitCost.ensure(stride * 2 * (size_t)(R + 2)))) return rc;
+                            HIPCHECK(hipMemsetAsync(W.splitCost.p, 0, stride * 2 * (size_t)(R + 2) * sizeof(unsigned), st));
+                            W.splitCostStride = stride;
+                        }
+                        PA.splitCost = W.splitCost.p + stride * (size_t)(2 * k + word);
+                        PA.splitLong = s->packetLongUs * 100; PA.splitBudgetLong = std::max(1, s->packetBudgetLongUs * 100);
+                    }
+                }
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 int grid = s->numCUs * s->blocksPerCUPacket;
@@ -1428,7 +1453,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->shadowBytes = s->shadowBytes; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->noAnswerAtEmission = s->noAnswerAtEmission; r->packetMerge = s->packetMerge; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->shadowBytes = s->shadowBytes; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->noAnswerAtEmission = s->noAnswerAtEmission; r->packetMerge = s->packetMerge; r->packetSplit = s->packetSplit; r->packetBudgetUs = s->packetBudgetUs; r->packetBudgetItemUs = s->packetBudgetItemUs; r->packetSplitItems = s->packetSplitItems; r->packetLongUs = s->packetLongUs; r->packetBudgetLongUs = s->packetBudgetLongUs; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1723,6 +1748,24 @@ int close_frame_impl(xrt_scene *s, int slot, xrt_stats *stats) {
     return rc;
 }
 
+// Split walks (packet.hip): the arena of a context's packet launches and this launch's control words (they sit behind the queue heads and are cleared with them).
+// The arena is cleared once, when it is made: an item counts as written when its first word holds the launch's serial number.
+int split_arena(xrt_scene *s, DevBuf<unsigned> &items, DevBuf<unsigned> &recs, PacketArgs &PA, hipStream_t st) {
+    int rc;
+    const size_t NI = ((size_t)s->packetSplitItems + 7) / 8 * 8, NR = NI / 4 + 1;   // (an eighth of the items per XCD)
+    if (!items.p || items.cap < NI * SPLIT_ITEM_WORDS) {
+        if ((rc = items.ensure(NI * SPLIT_ITEM_WORDS)) || (rc = recs.ensure(NR * SPLIT_REC_WORDS))) return rc;
+        HIPCHECK(hipMemsetAsync(items.p, 0, NI * SPLIT_ITEM_WORDS * sizeof(unsigned), st));
+        HIPCHECK(hipMemsetAsync(recs.p, 0, NR * SPLIT_REC_WORDS * sizeof(unsigned), st));
+    }
+    PA.splitItems = items.p; PA.splitRecs = recs.p; PA.splitNI = (int)NI; PA.splitNR = (int)NR;
+    if (++s->splitSerial == 0u) s->splitSerial = 1u;
+    PA.splitSerial = s->splitSerial;
+    PA.splitBudget = std::max(1, s->packetBudgetUs * 100); PA.splitBudgetItem = std::max(1, s->packetBudgetItemUs * 100);   // ticks of the 100 MHz device clock (0 would mean "off")
+    PA.splitCtl = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(PA.queue + PACKET_QUEUE_HEADS * PACKET_HEAD_STRIDE) + 127) & ~(uintptr_t)127);
+    return XRT_OK;
+}
+
 // The work-queue word of launches on `st` (launches of one stream are ordered, so they can share a word; launches on
 // different streams may overlap and must not).  Caller holds apiMutex.
 int queue_word_for(xrt_scene *s, hipStream_t st, unsigned **word) {
@@ -1761,6 +1804,10 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
     if (n > 0 && s->packetMask >= 0 && (s->packetMask & 8) && packet_supported(mode, s->host->arrays.meshDepth, s->host->arrays.sceneDepth) && meshOk) {   // (testing aid: arbitrary batches through the packet kernel)
         PacketArgs PA;
         PA.rays = d_rays; PA.hits = d_hits; PA.n = (int)n; PA.queue = queue + 1; PA.mode = mode; PA.meshId = meshId;
+        if (s->packetSplit && mode != MODE_SCENE) {
+            auto &ar = s->apiSplit[(int)((queue - s->queues.p) / (1 + PACKET_QUEUE_WORDS))];
+            if ((rc = split_arena(s, ar.first, ar.second, PA, st))) return rc;
+        }
         int grid = s->numCUs * packet_blocks_per_cu(mode);
         const long long want = (n + 255) / 256;
         if (want < grid) grid = (int)want;
@@ -1892,6 +1939,12 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_BATCH_MIN")) { const int v = atoi(e); if (v >= 16 && v <= 64 && v % 16 == 0) s->batchMin = v; }
     if (const char *e = getenv("XRT_HEAVY_SHIFT")) { const int v = atoi(e); if (v >= 0 && v <= 6) { s->heavyShift = v; s->heavyShiftGiven = true; } }
     if (const char *e = getenv("XRT_BATCH_MAX")) { const int v = atoi(e); if (v >= 16 && v <= 4096 && v % 16 == 0) s->batchMax = v; }
+    if (const char *e = getenv("XRT_PK_SPLIT")) s->packetSplit = atoi(e) != 0;
+    if (const char *e = getenv("XRT_PK_BUDGET")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) s->packetBudgetUs = v; }   // (0: a walk looks for pending subtrees at every block it enters)
+    if (const char *e = getenv("XRT_PK_BUDGET_ITEM")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) s->packetBudgetItemUs = v; }
+    if (const char *e = getenv("XRT_PK_LONG")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) s->packetLongUs = v; }
+    if (const char *e = getenv("XRT_PK_BUDGET_LONG")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) s->packetBudgetLongUs = v; }
+    if (const char *e = getenv("XRT_PK_SPLIT_ITEMS")) { const int v = atoi(e); if (v >= 1 && v <= (1 << 20)) s->packetSplitItems = v; }
     if (const char *e = getenv("XRT_PK_GRAB")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->packetGrabMax = v; }
     if (const char *e = getenv("XRT_PK_STATIC")) { const int v = atoi(e); if (v >= 0 && v <= 64) s->packetStaticDiv = v; }
     if (const char *e = getenv("XRT_PACKET")) { const int v = atoi(e); if (v >= -1 && v <= 31) s->packetMask = v; }
@@ -2235,6 +2288,20 @@ int xrt_rccl_probe(void) {
 }
 
 float xrt_progress(const xrt_scene *scene) { return scene ? scene->progress.load() : 0.0f; }
+
+int xrt_split_stats(xrt_scene *scene, uint64_t out[4], int32_t reset) {
+    return guarded("xrt_split_stats", [&]() -> int {
+        int rc = need_device(scene, "xrt_split_stats");
+        if (rc != XRT_OK) return rc;
+        if (!out) return fail(XRT_E_INVALID_ARG, "xrt_split_stats: null argument");
+        unsigned long long v[4] = {0, 0, 0, 0};
+        HIPCHECK(hipSetDevice(scene->device));
+        HIPCHECK(hipDeviceSynchronize());
+        if (packet_split_stats(v, reset != 0) != 0) return fail(XRT_E_HIP, "xrt_split_stats: %s", hipGetErrorString(hipGetLastError()));
+        for (int i = 0; i < 4; i++) out[i] = v[i];
+        return XRT_OK;
+    });
+}
 
 int xrt_generate_primary_rays(xrt_scene *scene, const xrt_camera *camera, xrt_ray *rays_out) {
     int rc = need_device(scene, "xrt_generate_primary_rays");
