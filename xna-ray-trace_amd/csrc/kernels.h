@@ -82,6 +82,7 @@ struct PacketArgs {
     int staticDiv = 4;            // 1/staticDiv of the packets are dealt statically (0: none)
     int grabMax = 2;              // most packets a wave takes per queue atomic
     int *flags = nullptr;         // inside a frame: hit / miss word per ray, no record for a miss (IntersectArgs::flags)
+    int bundle = 1;               // one-body scenes: big leaves are scanned through the bundle prefilter (packet.hip; XRT_PK_BUNDLE=0: run by run as in round 3)
     int cullMin = 4;              // leaves of at least this many references are tested against their tight box first (the test costs about two triangles)
     unsigned long long *stamps = nullptr;   // this launch's row of device-clock stamps (device_util.h), or null
     // optional second segment traced by the same launch (the shadow rays of generation k-1 beside the closest-hit rays of generation k, as

@@ -41,7 +41,15 @@ constexpr int PK_LEVELS = 24;        // deeper octrees than this fall back to k_
 constexpr int PK_FRAME_WORDS = 4;    // blk, pending children (the first lane's order is found again from the lanes), lanes (2): one 16-byte LDS access
 // a wave's stack: PK_LEVELS frames, then per level one byte per lane -- which children of that level's block the lane's own box tests accepted
 constexpr int PK_SPLIT_AT = PK_LEVELS * (PK_FRAME_WORDS + 16);   // ... and behind them the wave's split-walk words (pk_walk): record, item, budget, budget clock, packet
-constexpr int PK_STACK_WORDS = PK_SPLIT_AT + 8;
+// make variant NAME=bundle DEFS=-DXRT_PK_BUNDLE: the bundle prefilter of big leaves (below).  Not in the shipped kernel: it needs 106 vector registers where the walk has 80
+// (four waves per SIMD instead of six: +19 %), and at equal occupancy it gains 5 % (profiles/r04/bundle_prefilter.txt).
+#ifdef XRT_PK_BUNDLE
+constexpr bool PK_BUNDLE = true;
+#else
+constexpr bool PK_BUNDLE = false;
+#endif
+constexpr int PK_BUNDLE_AT = PK_SPLIT_AT + 8;    // ... and the packet's ray bundle (xrt_core.h RayBundle: 20 words) + [20] "the bundle may be used"
+constexpr int PK_STACK_WORDS = PK_BUNDLE_AT + 24;
 constexpr int PK_SLEVELS = 12;       // scene octree levels a packet can stack (deeper scene trees: k_intersect)
 constexpr int PK_SFRAME_WORDS = 4;   // scene block, pending children, lanes (2)
 #ifndef XRT_PK_QUEUES
@@ -74,6 +82,94 @@ __device__ unsigned g_pkCur[8 * 65536];         // (per resident wave: this pack
 __device__ unsigned long long g_splitStats[4];   // split walks (pk_walk): subtrees handed over, taken, packets split, packets whose results a taker wrote (xrt_split_stats)
 struct alignas(4) TriWords { float w[16]; };   // a 13-word record of refT and the first three words of the next one
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// min / max of v over the 64 lanes (DPP row shifts + the two row broadcasts, as wave_or; a lane without a source keeps its own value): wave-uniform
+__device__ __forceinline__ float wave_fmin(float v) {
+    const int inf = 0x7f800000;
+    v = fminf(v, i2f(__builtin_amdgcn_update_dpp(inf, f2i(v), 0x111, 0xf, 0xf, false)));
+    v = fminf(v, i2f(__builtin_amdgcn_update_dpp(inf, f2i(v), 0x112, 0xf, 0xf, false)));
+    v = fminf(v, i2f(__builtin_amdgcn_update_dpp(inf, f2i(v), 0x114, 0xf, 0xf, false)));
+    v = fminf(v, i2f(__builtin_amdgcn_update_dpp(inf, f2i(v), 0x118, 0xf, 0xf, false)));
+    v = fminf(v, i2f(__builtin_amdgcn_update_dpp(inf, f2i(v), 0x142, 0xa, 0xf, false)));
+    v = fminf(v, i2f(__builtin_amdgcn_update_dpp(inf, f2i(v), 0x143, 0xc, 0xf, false)));
+    return i2f(__builtin_amdgcn_readlane(f2i(v), 63));
+}
+__device__ __forceinline__ float wave_fmax(float v) { return -wave_fmin(-v); }
+// The packet's ray bundle (xrt_core.h RayBundle) over the lanes `part`: bounds of the origins and directions by wave reductions; the inverse directions, |D|_2 and
+// the slack follow from the direction bounds (1f / d is correctly rounded, hence monotone; so are the sums of squares and of absolute values, evaluated in
+// make_ray_cull's association).  Usable when every lane of `part` may use the fast box test and takes part in the tight-box tests (RayCull::d2 > 0) and every
+// axis has one sign for all of them.  Lane 0 leaves it in the wave's LDS words bw[0..19], bw[20] = usable.
+__device__ __forceinline__ void pk_bundle(unsigned *bw, int lane, bool part, bool okL, const RayPre &r) {
+    const float inf = i2f(0x7f800000);
+    const bool allOk = !__any(part && !okL) && __any(part);
+    float v[12];
+    v[0] = wave_fmin(part ? r.o.x : inf); v[1] = wave_fmin(part ? r.o.y : inf); v[2] = wave_fmin(part ? r.o.z : inf);
+    v[3] = wave_fmax(part ? r.o.x : -inf); v[4] = wave_fmax(part ? r.o.y : -inf); v[5] = wave_fmax(part ? r.o.z : -inf);
+    v[6] = wave_fmin(part ? r.d.x : inf); v[7] = wave_fmin(part ? r.d.y : inf); v[8] = wave_fmin(part ? r.d.z : inf);
+    v[9] = wave_fmax(part ? r.d.x : -inf); v[10] = wave_fmax(part ? r.d.y : -inf); v[11] = wave_fmax(part ? r.d.z : -inf);
+    if (lane == 0) {
+        bool ok = allOk;
+        for (int k = 0; k < 3; k++) ok = ok && ((v[6 + k] > 0.0f) || (v[9 + k] < 0.0f));   // one sign per axis, no zero (NaN: false)
+        for (int k = 0; k < 12; k++) bw[k] = (unsigned)f2i(v[k]);
+        for (int k = 0; k < 3; k++) {   // inverse directions: 1 / d falls as d grows
+            bw[12 + k] = (unsigned)f2i(1.0f / v[9 + k]); bw[15 + k] = (unsigned)f2i(1.0f / v[6 + k]);
+        }
+        const float mx = fmaxf(fabsf(v[6]), fabsf(v[9])), my = fmaxf(fabsf(v[7]), fabsf(v[10])), mz = fmaxf(fabsf(v[8]), fabsf(v[11]));
+        bw[18] = (unsigned)f2i(sqrtf((mx * mx + my * my) + mz * mz) * 1.000001f);   // >= RayCull::d2 of every lane
+        bw[19] = (unsigned)f2i(((mx + my) + mz) * 4.7683716e-7f);                  // >= RayCull::slack
+        bw[20] = ok ? 1u : 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// xrt_core.h bundle_certainly_missed, the same arithmetic, shaped for the register budget of k_packet (80 vector registers): the bundle's 20 words sit in the
+// lanes of ONE vector register (lane k holds word k: a v_readlane hands a word to the scalar operand of the instruction that needs it), the record's four
+// quarters are loaded where they are used, and the three phases -- rho, then one axis at a time -- are kept apart for the scheduler.
+__device__ __forceinline__ float bword(int vB, int k) { return i2f(__builtin_amdgcn_readlane(vB, k)); }
+__device__ __forceinline__ bool pk_bundle_missed(int vB, const f4 *__restrict__ t) {
+    auto far1 = [](float o0, float o1, float lo, float hi) { return fmaxf(fmaxf(fabsf(o0 - lo), fabsf(o1 - lo)), fmaxf(fabsf(o0 - hi), fabsf(o1 - hi))); };
+    const f4 a = t[0], b = t[1];
+    float rho, ok;
+    {
+        const float fx = far1(bword(vB, 0), bword(vB, 3), a.x, b.x), fy = far1(bword(vB, 1), bword(vB, 4), a.y, b.y), fz = far1(bword(vB, 2), bword(vB, 5), a.z, b.z);
+        const float tmax = sqrtf((fx * fx + fy * fy) + fz * fz) * 1.000001f;
+        const f4 nl = t[2], nh = t[3];
+        float lo, hi;
+        {
+            const float d0 = bword(vB, 6), d1 = bword(vB, 9);
+            const float x0 = d0 * nl.x, x1 = d0 * nh.x, x2 = d1 * nl.x, x3 = d1 * nh.x;
+            lo = min4(x0, x1, x2, x3); hi = max4(x0, x1, x2, x3);
+        }
+        {
+            const float d0 = bword(vB, 7), d1 = bword(vB, 10);
+            const float y0 = d0 * nl.y, y1 = d0 * nh.y, y2 = d1 * nl.y, y3 = d1 * nh.y;
+            lo = lo + min4(y0, y1, y2, y3); hi = hi + max4(y0, y1, y2, y3);
+        }
+        {
+            const float d0 = bword(vB, 8), d1 = bword(vB, 11);
+            const float z0 = d0 * nl.z, z1 = d0 * nh.z, z2 = d1 * nl.z, z3 = d1 * nh.z;
+            lo = lo + min4(z0, z1, z2, z3); hi = hi + max4(z0, z1, z2, z3);
+        }
+        const float cmin = fmaxf(lo, -hi) - bword(vB, 19);
+        rho = (((a.w * (b.w + tmax)) * bword(vB, 18)) * (__builtin_amdgcn_rcpf(cmin) * 1.000001f)) * 1.00001f;
+        ok = (nl.w > 0.0f && bword(vB, 18) > 0.0f && cmin > 0.0f && rho < 1.0e15f) ? 1.0f : 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float tn = 0.0f, tf = FLT_MAX;
+    auto axis = [&](float alo, float bhi, int k) {
+        const float o0 = bword(vB, k), o1 = bword(vB, 3 + k), i0 = bword(vB, 12 + k), i1 = bword(vB, 15 + k);
+        const float v1lo = (alo - rho) - o1, v1hi = alo - o0, v2lo = bhi - o1, v2hi = (bhi + rho) - o0;
+        const float p0 = v1lo * i0, p1 = v1lo * i1, p2 = v1hi * i0, p3 = v1hi * i1;
+        const float q0 = v2lo * i0, q1 = v2lo * i1, q2 = v2hi * i0, q3 = v2hi * i1;
+        tn = fmaxf(tn, fminf(min4(p0, p1, p2, p3), min4(q0, q1, q2, q3)));
+        tf = fminf(tf, fmaxf(max4(p0, p1, p2, p3), max4(q0, q1, q2, q3)));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    axis(a.x, b.x, 0); axis(a.y, b.y, 1); axis(a.z, b.z, 2);
+    return ok != 0.0f && tn > tf;
+}
+
 // Data that waves hand each other inside a launch (split walks): every word of it is written with an agent-scope store and read with an agent-scope load (sc1: past the
 // CU's L1 and whatever the XCD's L2 holds), ordered by waiting for the stores -- no cache-wide operation.  Measured on the way here (profiles/r04/split_walks.txt):
 // __threadfence() (write the whole L2 back, invalidate it) costs every CU of the XCD ~1 us per call; a workgroup-scope (sc0) load may be served by the CU's L1 for ever;
@@ -273,7 +369,7 @@ struct PkKernarg {
 // sets the packet's rays up again, seeds level 0 of its stack with the item and starts by "coming back" to it (`resume`); it may split again.  Every participant
 // leaves its lanes' answers in the arena; the one that finishes last (PacketArgs::splitRecs [0], a count of units outstanding: nobody ever waits for anybody)
 // merges them with the rule of DESIGN.md §3 and writes the packet's results.
-template <bool SPLIT>
+template <bool SPLIT, bool BUNDLE = PK_BUNDLE>
 __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const float *__restrict__ refT, const float *__restrict__ lrec,
                                         const SceneView &S, int cullMin, unsigned *stk, int lane, Lane &L,
                                         const RayCull &RC, bool fastL, int rootBlock, unsigned long long lanes0, bool nodeCull,
@@ -434,6 +530,55 @@ __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const
             // A leaf of LEAF_RUN_MIN references or more is scanned run by run (LEAF_RUN references each): every run has a
             // tight box of its own and a run no lane can reach is passed over -- the octree stops splitting at 50 triangles (MO:42) and a
             // coherent packet comes near only a few of them.  Smaller leaves are one run.
+            // Bundle prefilter (xrt_core.h bundle_certainly_missed): 64 lanes look at 64 TRIANGLES of the leaf at once -- can any ray of the packet reach this one? -- and
+            // only the triangles some ray may reach get the rays' own tests (in list order: MO:293-294's strict '<' holds).  A leaf's triangles fill a thin sheet of its
+            // cube and the 64 rays of a packet are a narrow beam: of C5's 56 triangle steps per primary packet most were made for triangles no lane comes near.
+            if (BUNDLE && r1 - r0 >= cullMin && rfl((int)stk[PK_BUNDLE_AT + 20]) != 0) {
+                const int vB = (int)stk[PK_BUNDLE_AT + (lane & 31)];   // lane k < 20: word k of the bundle
+                PkKernarg K;
+                K.fresh();
+                const f4 *const triTB = K.scene()->triTB;
+                L.leafKey = key; L.leafNode = node;
+                for (int base = r0; base < r1; base += 64) {
+                    const int rr = base + lane;
+                    bool maybe = false;
+                    if (rr < r1) {
+                        const f4 *const t = triTB + 4 * (size_t)rr;
+                        maybe = !pk_bundle_missed(vB, t);
+                    }
+                    unsigned long long M = __ballot(maybe);
+                    PKC(6);
+                    if (M == 0ull) continue;
+                    PKC(7);
+                    auto test = [&](const TriWords &q, int r) {
+                        float u, v, t;
+                        PkTriMid m;
+                        if (go && pk_tri_pre(q, L, m)) {
+                            if (pk_tri_hit(q, L, m, u, v, t)) {
+                                if (!keyed) L.leafKey = entry_key();
+                                pk_candidate(L, S, r, u, v, t);
+                            }
+                        }
+                    };
+                    int j = (int)__builtin_ctzll(M);
+                    M &= M - 1ull;
+                    TriWords qA = *reinterpret_cast<const TriWords *>(reinterpret_cast<const char *>(refT) + (size_t)(base + j) * TRI_REC_BYTES);
+                    for (;;) {
+                        const bool more = M != 0ull;
+                        int j2 = j;
+                        if (more) { j2 = (int)__builtin_ctzll(M); M &= M - 1ull; }
+                        const TriWords qB = *reinterpret_cast<const TriWords *>(reinterpret_cast<const char *>(refT) + (size_t)(base + j2) * TRI_REC_BYTES);   // (the next one, requested before this one's arithmetic)
+#ifdef XRT_PK_COUNTERS
+                        pkc[8]++; pkc[14] += (unsigned)__popcll(__ballot(go));
+#endif
+                        test(qA, base + j);
+                        if (!more) break;
+                        qA = qB; j = j2;
+                    }
+                }
+                if (!keyed) anyFound = __any(L.mfound != 0);
+                continue;
+            }
             int nRuns = 1, rb = -1;
             if (r1 - r0 >= LEAF_RUN_MIN) { rb = f2i(lrec[(size_t)node * LREC_WORDS + 24]); if (rb >= 0) nRuns = (r1 - r0 + LEAF_RUN - 1) / LEAF_RUN; }
             for (int jr = 0; jr < nRuns; jr++) {
@@ -735,6 +880,10 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
             }
+            if constexpr (PK_BUNDLE) {
+                if (A.bundle) pk_bundle(stk + PK_BUNDLE_AT, lane, ((lanes0 >> lane) & 1ull) != 0ull, fastL && RC.d2 > 0.0f, L.r);   // (wave-uniform switch)
+                else if (lane == 0) stk[PK_BUNDLE_AT + 20] = 0u;
+            }
             pk_walk<splitOn>(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, lanes0, nodeCull, splitOn && item >= 0);
             L.mesh = mesh;
             KA.fresh();
@@ -903,7 +1052,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
                                 const bool meshAway = nodeCull && all_back_facing(f4{mr.nbMin[0], mr.nbMin[1], mr.nbMin[2], mr.nbMin[3]}, f4{mr.nbMax[0], mr.nbMax[1], mr.nbMax[2], mr.nbMax[3]}, L.r.d);
                                 const unsigned long long lanes0 = __ballot(inRoot && !meshAway);
                                 if (lanes0 != 0ull)
-                                    pk_walk<false>(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, lanes0, nodeCull);
+                                    pk_walk<false, false>(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, lanes0, nodeCull);
                             }
                             if (L.mfound) {   // OSM:370-378
                                 L.mesh = m; C.obj = o;

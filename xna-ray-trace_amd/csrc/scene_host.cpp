@@ -329,6 +329,11 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
             }
             if (!meshAny) meshNBlo.w = 1.0f;   // (a mesh whose root is a leaf, or without triangles: no record, never culled)
         }
+        for (size_t li = 0; buildTriTB && li < t.leafRefs.size(); li++) {   // ... and the tight box of every single reference (the bound holds for any set of triangles, also for one)
+            f4 rr[4] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
+            tight_box_record(m, t.leafRefs, (int)li, (int)li + 1, leafCullSafety, rr);
+            for (const f4 &q : rr) A.triTB.push_back(q);
+        }
         for (int tri : t.leafRefs) {   // leaf references in leaf order: normal stream + geometry stream
             const float *p = &m.v[(size_t)tri * 9];
             const float *sn = &m.sn[(size_t)tri * 3];
@@ -397,6 +402,8 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
     // never hand out empty arrays (a zero-size allocation has no address)
     // two dummy references at the end: the wave-packet kernel requests the next triangle's record before it knows the leaf has ended
     for (int k = 0; k < 2; k++) { A.refN.push_back(f4{0, 0, 0, i2f(-1)}); for (int j = 0; j < 3; j++) A.refG.push_back(g3{0, 0, 0}); }
+    if (buildTriTB) A.triTB.resize(A.refN.size() * 4 + 64 * 4, f4{0, 0, 0, 0});
+    else A.triTB.assign(4, f4{0, 0, 0, 0});   // (the dummy references, and a wave's worth of padding: 64 lanes read 64 consecutive records)
     A.refT.resize(A.refN.size() * TRI_REC_WORDS + 16, 0.0f);
     for (size_t r = 0; r < A.refN.size(); r++) {
         float *q = &A.refT[r * TRI_REC_WORDS];

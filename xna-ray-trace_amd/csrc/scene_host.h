@@ -17,6 +17,7 @@ constexpr int SHADE_F4 = 6;   // f4 per triangle shading record:
 struct SceneArrays {
     std::vector<f4> blocks, refN, snodes, shade, leafNB;   // leafNB: 2 per node: component-wise min / max of the leaf's surface normals
     std::vector<float> refT;                               // refN + refG as one 13-word record per reference, 16 words of padding at the end
+    std::vector<f4> triTB;                                 // 4 per leaf reference: the tight box of that one triangle (xrt_core.h bundle_certainly_missed)
     std::vector<f4> runTB;                                 // 4 per run of LEAF_RUN references of a big leaf: the run's tight box (same record as leafTB)
     std::vector<int> runBase;                              // per node: index of the leaf's first run in runTB / 4, or -1 (small leaf, interior, empty)
     std::vector<f4> scull;                                 // 4 per scene leaf reference (traverse.h SceneView::scull)
@@ -43,6 +44,11 @@ struct HostScene {
     FlatTree sceneTree;
     SceneArrays arrays;
     bool built = false;
+#ifdef XRT_PK_BUNDLE
+    bool buildTriTB = true;        // the per-reference tight boxes of the bundle prefilter (packet.hip, a build variant): 64 bytes per leaf reference
+#else
+    bool buildTriTB = false;
+#endif
     double leafCullSafety = 1.0;   // factor on the tight-leaf-box margin (xrt_core.h LEAF_CULL_C): 0 switches the skip off, below 1 the bound is no longer proven (tests)
     double cullSafety = 2.0;   // factor S of the object pre-cull margin (scene_host.cpp); tests lower it to see the bound bite
 

@@ -26,6 +26,7 @@ struct SceneView {
     const f4 *runTB;        // 4 per run of LEAF_RUN consecutive references: the run's tight box (same form as leafTB)
     const f4 *refN;         // per leaf reference: (surfaceNormal.xyz, global triangle id)
     const g3 *refG;         // 3 per leaf reference: v1, E1, E2
+    const f4 *triTB;        // 4 per leaf reference: the tight-box record of that ONE triangle (same form as leafTB; packet.hip: the bundle prefilter of big leaves)
     const float *refT;      // the same two streams as one record of TRI_REC_WORDS words per reference (k_packet's scalar loads)
     const float *pblocks;   // k_packet: PBLOCK_WORDS per block -- the descriptor and the child planes (below)
     const float *lrec;      // k_packet: LREC_WORDS per node (leafNB | leafTB | first run's word offset), the run records behind them

@@ -206,7 +206,7 @@ struct xrt_scene {
     HostScene hs;
     const HostScene *host = &hs;   // what the frame code reads; a replica on another device points at its primary's
     // HBM-resident scene
-    DevBuf<f4> blocks, refN, snodes, shade, leafNB, leafTB, scull, runTB;
+    DevBuf<f4> blocks, refN, snodes, shade, leafNB, leafTB, scull, runTB, triTB;
     DevBuf<float> refT, pblocks, lrec;
     DevBuf<g3> refG;
     DevBuf<int> childDfs, srefs, objMesh, runBase;
@@ -245,6 +245,7 @@ struct xrt_scene {
     bool heavyShiftGiven = false;
     bool packetMerge = true;   // the closest-hit and the shadow packets of a step share one launch (XRT_PK_MERGE=0: two launches, as round 2)
     bool noAnswerAtEmission = false;   // XRT_AE=0: k_shade emits every ray (kernels.h ShadeArgs::ae off)
+    bool packetBundle = true;  // XRT_PK_BUNDLE=0: no bundle prefilter (kernels.h PacketArgs::bundle)
     int packetCullMin = 4;     // XRT_PK_CULL_MIN (development): leaves with fewer references skip the tight-box test
     // Split walks (packet.hip): one-body scenes; a packet / an item that has walked for this many microseconds looks for pending subtrees to hand to other waves
     // (XRT_PK_SPLIT=0: off; XRT_PK_BUDGET / XRT_PK_BUDGET_ITEM in microseconds; XRT_PK_SPLIT_ITEMS: capacity of a frame context's arena)
@@ -429,7 +430,7 @@ struct xrt_scene {
             }
             if (stream) (void)hipStreamDestroy(stream);
             blocks.release(); leafNB.release(); leafTB.release(); refT.release(); refN.release(); refG.release(); snodes.release(); shade.release();
-            childDfs.release(); srefs.release(); scull.release(); runTB.release(); runBase.release(); pblocks.release(); lrec.release(); objMesh.release(); meshes.release();
+            childDfs.release(); srefs.release(); scull.release(); runTB.release(); triTB.release(); runBase.release(); pblocks.release(); lrec.release(); objMesh.release(); meshes.release();
             objects.release(); materials.release(); texels.release();
             apiRays.release(); apiHits.release();
 
@@ -973,7 +974,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                     else PA.pathOf1 = k == 0 ? W.index0.p : paths[cur];
                     if (I2) { PA.slotOf2 = slotOf[prv]; PA.nL2 = nL; }
                 }
-                PA.queue = q + QW * k + 1 + PACKET_QUEUE_WORDS * word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv; PA.grabMax = s->packetGrabMax; PA.cullMin = s->packetCullMin;
+                PA.queue = q + QW * k + 1 + PACKET_QUEUE_WORDS * word; PA.mode = s->sceneMode; PA.meshId = 0; PA.unmark = 0; PA.staticDiv = s->packetStaticDiv; PA.grabMax = s->packetGrabMax; PA.cullMin = s->packetCullMin; PA.bundle = s->packetBundle ? 1 : 0;
                 if (s->packetSplit && s->sceneMode != MODE_SCENE) {
                     if ((rc = split_arena(s, W.splitItems, W.splitRecs, PA, st))) return rc;
                     if (fast && !adaptive && !heap && s->packetLongUs > 0) {   // plain frames: the packets of launch #k are the same from frame to frame while the camera stands still, and nearly so while it moves
@@ -1453,7 +1454,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->shadowBytes = s->shadowBytes; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->noAnswerAtEmission = s->noAnswerAtEmission; r->packetMerge = s->packetMerge; r->packetSplit = s->packetSplit; r->packetBudgetUs = s->packetBudgetUs; r->packetBudgetItemUs = s->packetBudgetItemUs; r->packetSplitItems = s->packetSplitItems; r->packetLongUs = s->packetLongUs; r->packetBudgetLongUs = s->packetBudgetLongUs; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->shadowBytes = s->shadowBytes; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->packetBundle = s->packetBundle; r->noAnswerAtEmission = s->noAnswerAtEmission; r->packetMerge = s->packetMerge; r->packetSplit = s->packetSplit; r->packetBudgetUs = s->packetBudgetUs; r->packetBudgetItemUs = s->packetBudgetItemUs; r->packetSplitItems = s->packetSplitItems; r->packetLongUs = s->packetLongUs; r->packetBudgetLongUs = s->packetBudgetLongUs; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1803,7 +1804,7 @@ int run_intersect(xrt_scene *s, const xrt_ray *d_rays, int64_t n, xrt_hit *d_hit
     const bool meshOk = mode != MODE_MESH || (meshId >= 0 && meshId < (int)s->host->meshTrees.size() && !s->host->meshTrees[(size_t)meshId].rootIsLeaf);
     if (n > 0 && s->packetMask >= 0 && (s->packetMask & 8) && packet_supported(mode, s->host->arrays.meshDepth, s->host->arrays.sceneDepth) && meshOk) {   // (testing aid: arbitrary batches through the packet kernel)
         PacketArgs PA;
-        PA.rays = d_rays; PA.hits = d_hits; PA.n = (int)n; PA.queue = queue + 1; PA.mode = mode; PA.meshId = meshId;
+        PA.rays = d_rays; PA.hits = d_hits; PA.n = (int)n; PA.queue = queue + 1; PA.mode = mode; PA.meshId = meshId; PA.bundle = s->packetBundle ? 1 : 0;
         if (s->packetSplit && mode != MODE_SCENE) {
             auto &ar = s->apiSplit[(int)((queue - s->queues.p) / (1 + PACKET_QUEUE_WORDS))];
             if ((rc = split_arena(s, ar.first, ar.second, PA, st))) return rc;
@@ -1842,13 +1843,13 @@ int scene_upload(xrt_scene *scene) {
     int rc;
     if ((rc = upload(scene->blocks, A.blocks)) || (rc = upload(scene->leafNB, A.leafNB)) || (rc = upload(scene->leafTB, A.leafTB)) || (rc = upload(scene->refT, A.refT)) || (rc = upload(scene->pblocks, A.pblocks)) || (rc = upload(scene->lrec, A.lrec)) || (rc = upload(scene->refN, A.refN)) || (rc = upload(scene->refG, A.refG)) ||
         (rc = upload(scene->snodes, A.snodes)) || (rc = upload(scene->shade, A.shade)) || (rc = upload(scene->childDfs, A.childDfs)) ||
-        (rc = upload(scene->srefs, A.srefs)) || (rc = upload(scene->scull, A.scull)) || (rc = upload(scene->runTB, A.runTB)) || (rc = upload(scene->runBase, A.runBase)) || (rc = upload(scene->objMesh, A.objMesh)) ||
+        (rc = upload(scene->srefs, A.srefs)) || (rc = upload(scene->scull, A.scull)) || (rc = upload(scene->runTB, A.runTB)) || (rc = upload(scene->triTB, A.triTB)) || (rc = upload(scene->runBase, A.runBase)) || (rc = upload(scene->objMesh, A.objMesh)) ||
         (rc = upload(scene->meshes, A.meshes)) || (rc = upload(scene->objects, A.objects)) || (rc = upload(scene->materials, A.materials)) ||
         (rc = upload(scene->texels, A.texels)))
         return rc;
     SceneView &S = scene->view;
     S.blocks = scene->blocks.p; S.childDfs = scene->childDfs.p; S.leafNB = scene->leafNB.p; S.leafTB = scene->leafTB.p; S.refT = scene->refT.p; S.pblocks = scene->pblocks.p; S.lrec = scene->lrec.p; S.refN = scene->refN.p; S.refG = scene->refG.p;
-    S.meshes = scene->meshes.p; S.snodes = scene->snodes.p; S.srefs = scene->srefs.p; S.scull = scene->scull.p; S.runTB = scene->runTB.p; S.runBase = scene->runBase.p;
+    S.meshes = scene->meshes.p; S.snodes = scene->snodes.p; S.srefs = scene->srefs.p; S.scull = scene->scull.p; S.runTB = scene->runTB.p; S.triTB = scene->triTB.p; S.runBase = scene->runBase.p;
     S.objects = scene->objects.p; S.objMesh = scene->objMesh.p;
     S.nMeshes = (int)scene->host->meshes.size(); S.nObjects = (int)scene->host->objects.size();
     S.sceneDepth = A.sceneDepth + 1; S.meshDepth = A.meshDepth + 1;
@@ -1959,6 +1960,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_LAUNCH_TIMING")) s->noLaunchTiming = atoi(e) == 0;
     if (const char *e = getenv("XRT_SPLIT_MS")) s->splitMinMs = (float)atof(e);
     if (const char *e = getenv("XRT_SPLIT_PARTS")) { const int v = atoi(e); if (v >= 2 && v <= 4) s->splitParts = v; }
+    if (const char *e = getenv("XRT_PK_BUNDLE")) s->packetBundle = atoi(e) != 0;
     if (const char *e = getenv("XRT_PK_CULL_MIN")) s->packetCullMin = atoi(e);
     if (const char *e = getenv("XRT_AE")) s->noAnswerAtEmission = atoi(e) == 0;
     if (const char *e = getenv("XRT_PK_MERGE")) s->packetMerge = atoi(e) != 0;
