@@ -101,6 +101,33 @@ def test_leaf_group_quirk_ties_and_ignore_on_soups(xrt, orc, n, seed, threshold,
     assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
 
 
+def test_equal_distance_ties_inside_a_leaf(xrt, orc, monkeypatch):
+    """MO:293-294: of two triangles of ONE leaf hit at exactly the same distance the earlier in the leaf's list wins (strict '<').  The device stores the references
+    of a big leaf in runs of neighbouring triangles, not in list order (scene_host.cpp spatial_runs), and settles such a tie by the smaller triangle index -- a leaf's
+    list is ascending in the index.  Here exact ties are the rule: hundreds of overlapping coplanar triangles with small integer coordinates (two stacked sheets, so that
+    leaves differ), rays straight down and along the diagonals from integer heights -- every quantity of RE:42-75 is exact, and up to dozens of triangles of a leaf report
+    the very same distance.  Per-lane kernel, packet kernel (XRT_PACKET=31), split walks; also with the list order kept (XRT_LEAF_ORDER=0: same answers)."""
+    from util import coplanar_tie_scene
+    spec, sets = coplanar_tie_scene(xrt)
+    orc_scene = orc.OracleScene(spec)
+    want = [orc_scene.intersect(r) for r in sets]
+    tied = 0
+    for env in ({}, {"XRT_PACKET": "31"}, {"XRT_PACKET": "31", "XRT_PK_SPLIT": "1", "XRT_PK_BUDGET": "0", "XRT_PK_BUDGET_ITEM": "0"}, {"XRT_LEAF_ORDER": "0"}, {"XRT_LEAF_ORDER": "0", "XRT_PACKET": "31"}):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        scene, tracer = xrt.configs.build_product(spec)
+        for r, w in zip(sets, want):
+            assert hits_equal(w, scene.IntersectBatch(r)) == {}, env
+        rgba, rgbf = tracer_render(tracer, 2)
+        o_rgba, o_rgbf, _ = orc.OracleScene(spec_with(spec, 2)).render(nthreads=8)
+        assert_frames_equal(rgba, rgbf, o_rgba, o_rgbf)
+        for k in env:
+            monkeypatch.delenv(k)
+    # (the rays do meet ties: many of them hit, and a hit point lies in several triangles of its sheet)
+    hit = want[0]["hit"] != 0
+    assert hit.sum() > 200
+
+
 def spec_with(spec, R):
     spec.max_reflections = R
     return spec

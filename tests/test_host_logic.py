@@ -187,6 +187,21 @@ def test_leaf_group_quirk_and_ties_on_triangle_soups(xrt, orc, emul, n, seed, th
     assert hits_equal(o.intersect(sec), e.intersect(sec)) == {}
 
 
+def test_equal_distance_ties_inside_a_leaf(xrt, orc, emul):
+    """MO:293-294: of two triangles of one leaf hit at exactly the same distance the earlier in the list wins.  The device arrays store the references of a big
+    leaf in runs of neighbouring triangles (scene_host.cpp spatial_runs) and the traversal settles such ties by the smaller triangle index (a leaf's list is
+    ascending in it): the stepper, which walks those arrays, must give the reference's answers where exact ties are the rule."""
+    from util import coplanar_tie_scene
+    spec, sets = coplanar_tie_scene(xrt)
+    o, e = orc.OracleScene(spec), emul.EmulScene(spec)
+    tied = 0
+    for rays in sets:
+        ho = o.intersect(rays)
+        assert hits_equal(ho, e.intersect(rays)) == {}
+        tied += int((ho["hit"] != 0).sum())
+    assert tied > 400
+
+
 def test_instances_rotated_scaled_and_shared_ignore(xrt, orc, emul):
     """Two-level scene with rotation and non-unit scale (Q6/Q7 awake) and a mesh shared by all instances:
     ignoreTriangle applies in every instance (Q9)."""

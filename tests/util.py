@@ -214,3 +214,33 @@ def build_c_host():
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), src, "-L", lib, "-lxrt",
                                "-Wl,-rpath," + lib, "-o", exe])
     return exe
+
+
+def coplanar_tie_scene(xrt):
+    """(spec, ray sets) in which exact ties of distance inside one leaf are the rule (MO:293-294: the earlier in the leaf's list wins): hundreds of overlapping
+    coplanar triangles with small integer coordinates in two stacked sheets, rays straight down / up / at 45 degrees from integer heights -- every quantity of
+    RE:42-75 is exact, and many triangles of a leaf report the very same distance."""
+    rng = np.random.default_rng(11)
+    n = 600
+    base = rng.integers(-8, 8, size=(n, 1, 2))
+    ext = rng.integers(1, 7, size=(n, 2, 2)) * np.array([[1, 0], [0, 1]])   # right triangles with integer legs ...
+    xz = np.concatenate([base, base + ext[:, 0:1], base + ext[:, 1:2]], axis=1).astype(np.float32)
+    flip = rng.integers(0, 2, size=n).astype(bool)
+    xz[flip] = xz[flip][:, [0, 2, 1]]                                           # ... of both windings (back faces are culled, RE:48-51)
+    y = np.where(np.arange(n) % 3 == 0, 0.0, -2.0).astype(np.float32)          # two sheets
+    v = np.stack([xz[:, :, 0], np.repeat(y[:, None], 3, axis=1), xz[:, :, 1]], axis=2).astype(np.float32)
+    md = xrt.fixtures.MeshData(v, np.zeros((n, 3, 3), dtype=np.float32), rng.uniform(0, 1, size=(n, 3, 2)).astype(np.float32), rng.uniform(0, 1, size=(n, 4)).astype(np.float32))
+    md.n = np.repeat(md.surface_normal[:, None, :], 3, axis=1).copy()
+    spec = xrt.configs.SceneSpec("ties")
+    spec.meshes.append((md, xrt.configs.material(0.5)))
+    spec.objects.append(([0], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    spec.camera = xrt.configs.camera((0, 24, 24), (0, 0, 0))
+    spec.lights = [xrt.configs.spot((0, 30, 10))]
+    spec.mesh_threshold = 50
+    spec = spec.with_size(64, 64)
+    gx, gz = np.meshgrid(np.arange(-10, 14) + 0.25, np.arange(-10, 14) + 0.25)
+    o = np.stack([gx.ravel(), np.full(gx.size, 4.0), gz.ravel()], axis=1).astype(np.float32)
+    sets = [xrt.rays_array(o, np.tile([0, -1, 0], (len(o), 1))), xrt.rays_array(o * [1, -1, 1], np.tile([0, 1, 0], (len(o), 1)))]
+    od = o.copy(); od[:, 0] -= 4.0                                               # 45 degrees in the x-y plane: |d| = (sqrt 1/2, sqrt 1/2, 0)
+    sets.append(xrt.rays_array(od, np.tile(np.float32([np.sqrt(0.5), -np.sqrt(0.5), 0]), (len(o), 1))))
+    return spec, sets

@@ -286,6 +286,7 @@ __device__ __forceinline__ void pk_candidate(Lane &L, const SceneView &S, int r,
     bool better = (L.mfound == 0) | (L.leafKey < L.mKey) | (eq & (t < L.mDist));
     if (eq & (t == L.mDist)) {   // (rare)
         if ((L.mfound != 0) & (L.leafNode != L.mLeaf)) better = node_dfs(S, L.leafNode) < node_dfs(S, L.mLeaf);
+        else if (L.mfound != 0) better = f2i(S.refN[r].w) < f2i(S.refN[L.mRef].w);   // one leaf: the earlier in the reference's list = the smaller triangle index (scene_host.cpp spatial_runs)
     }
     L.mfound = 1;   // (every lane here has a candidate now, its old one or this)
     L.mKey = better ? L.leafKey : L.mKey; L.mDist = better ? t : L.mDist; L.mU = better ? u : L.mU; L.mV = better ? v : L.mV;
@@ -920,7 +921,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
                             if (qf != 0) {   // (the words of a lane without a candidate mean nothing)
                                 bool better = (L.mfound == 0) | (qKey < L.mKey) | ((qKey == L.mKey) & (qD < L.mDist));
                                 if ((L.mfound != 0) & (qKey == L.mKey) & (qD == L.mDist))
-                                    better = qLeaf != L.mLeaf ? node_dfs(Sr, qLeaf) < node_dfs(Sr, L.mLeaf) : qRef < L.mRef;
+                                    better = qLeaf != L.mLeaf ? node_dfs(Sr, qLeaf) < node_dfs(Sr, L.mLeaf) : f2i(Sr.refN[qRef].w) < f2i(Sr.refN[L.mRef].w);
                                 if (better) { L.mfound = 1; L.mKey = qKey; L.mDist = qD; L.mU = qU; L.mV = qV; L.mRef = qRef; L.mLeaf = qLeaf; }
                             }
                         }

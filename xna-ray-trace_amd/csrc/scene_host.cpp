@@ -1,6 +1,8 @@
 // scene_host.cpp — see scene_host.h.
 #include "scene_host.h"
 
+#include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -184,6 +186,60 @@ static void tight_box_record(const HostMesh &m, const std::vector<int> &leafRefs
     }
 }
 
+// Storage order of a big leaf's references.  The walk tests a leaf of >= LEAF_RUN_MIN references run by run (LEAF_RUN consecutive references, each run with a tight box of
+// its own), and a run of consecutive LIST entries is a strip -- the builder hands triangles down in index order (MO:225-233), a heightfield's leaf holds them row by row --
+// that a ray crossing the leaf touches whatever its direction.  Here the references of such a leaf are stored in runs of NEIGHBOURS instead: the set is cut at the middle of
+// its longest extent (centroids; the cut at a multiple of LEAF_RUN) until a part fits one run.  Order matters to the reference in one place only -- of two triangles of a leaf
+// hit at exactly the same distance the EARLIER in the list wins (MO:293-294, strict '<') -- and the list of a leaf is ascending in the triangle index (checked here; a leaf
+// that is not keeps its order), so the kernels settle such a tie by the smaller index (traverse.h leaf_candidate, packet.hip pk_candidate) and the answers do not depend on
+// the storage order.  xrt_scene_get_tree still shows the reference's order.
+// (a leaf keeps its list order where that already gives the smaller runs: the sum of the surface areas of the runs' vertex boxes decides -- the twelve triangles of a
+// crate's face pairs lie better in the order they were modelled in)
+static double run_boxes_area(const HostMesh &m, const std::vector<int> &lr, int b0, int b1) {
+    double sum = 0;
+    for (int ra = b0; ra < b1; ra += LEAF_RUN) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int r = ra; r < ra + LEAF_RUN && r < b1; r++) {
+            const float *p = &m.v[(size_t)lr[(size_t)r] * 9];
+            for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) { const double x = p[3 * j + k]; if (x == x) { lo[k] = std::fmin(lo[k], x); hi[k] = std::fmax(hi[k], x); } }
+        }
+        const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx >= 0 && dy >= 0 && dz >= 0) sum += dx * dy + dy * dz + dz * dx;
+    }
+    return sum;
+}
+static void spatial_runs_cut(const HostMesh &m, std::vector<int> &lr, int b0, int b1);
+static void spatial_runs(const HostMesh &m, std::vector<int> &lr, int b0, int b1) {
+    for (int r = b0 + 1; r < b1; r++) if (lr[(size_t)r] <= lr[(size_t)r - 1]) return;
+    const std::vector<int> before(lr.begin() + b0, lr.begin() + b1);
+    const double a0 = run_boxes_area(m, lr, b0, b1);
+    spatial_runs_cut(m, lr, b0, b1);
+    if (!(run_boxes_area(m, lr, b0, b1) < a0)) std::copy(before.begin(), before.end(), lr.begin() + b0);
+}
+static void spatial_runs_cut(const HostMesh &m, std::vector<int> &lr, int b0, int b1) {
+    struct Part { int a, b; };
+    std::vector<Part> todo{Part{b0, b1}};
+    std::vector<std::pair<float, int>> key;
+    while (!todo.empty()) {
+        const Part q = todo.back();
+        todo.pop_back();
+        if (q.b - q.a <= LEAF_RUN) { std::sort(lr.begin() + q.a, lr.begin() + q.b); continue; }
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        auto centroid = [&](int tri, int k) { const float *p = &m.v[(size_t)tri * 9]; return (p[k] + p[3 + k]) + p[6 + k]; };
+        for (int r = q.a; r < q.b; r++)
+            for (int k = 0; k < 3; k++) { const float c = centroid(lr[(size_t)r], k); if (c == c) { lo[k] = std::fmin(lo[k], c); hi[k] = std::fmax(hi[k], c); } }
+        int ax = 0;
+        for (int k = 1; k < 3; k++) if (hi[k] - lo[k] > hi[ax] - lo[ax]) ax = k;
+        key.clear();
+        for (int r = q.a; r < q.b; r++) { const float c = centroid(lr[(size_t)r], ax); key.push_back({c == c ? c : FLT_MAX, lr[(size_t)r]}); }
+        std::sort(key.begin(), key.end());   // (ties by triangle index: deterministic)
+        for (int r = q.a; r < q.b; r++) lr[(size_t)r] = key[(size_t)(r - q.a)].second;
+        const int n = q.b - q.a, runs = (n + LEAF_RUN - 1) / LEAF_RUN, left = (runs / 2) * LEAF_RUN;   // (runs >= 2 here)
+        todo.push_back(Part{q.a, q.a + left});
+        todo.push_back(Part{q.a + left, q.b});
+    }
+}
+
 bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
     if (meshThreshold <= 0) meshThreshold = 50;    // MO:42
     if (sceneThreshold <= 0) sceneThreshold = 20;  // OSM:50
@@ -196,6 +252,31 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
         const HostMesh &m = meshes[mi];
         FlatTree &t = meshTrees[mi];
         if (!build_mesh_tree(m, meshThreshold, t, err)) return false;   // Mesh.Init (MESH:27-32)
+        std::vector<int> lr = t.leafRefs;   // the references in STORAGE order (spatial_runs)
+        for (size_t bi = 0; bi < t.blocks.size() / 2; bi++) {   // what the kernels' tie rule relies on: every leaf's list is ascending in the triangle index (MO:225-233 hands lists down in order)
+            const f4 lo = t.blocks[2 * bi], hi = t.blocks[2 * bi + 1];
+            const int lref = f2i(lo.y), masks = f2i(lo.z), total = f2i(lo.w);
+            const int offw[4] = {f2i(hi.x), f2i(hi.y), f2i(hi.z), f2i(hi.w)};
+            auto off = [&](int q) { int w = offw[q >> 1]; return (q & 1) ? (int)((unsigned)w >> 16) : (w & 0xffff); };
+            for (int c = 0; c < 8; c++) {
+                if ((masks >> c) & 1) continue;
+                const int b0 = lref + off(c), b1 = lref + (c == 7 ? total : off(c + 1));
+                for (int r = b0 + 1; r < b1; r++) if (lr[(size_t)r] <= lr[(size_t)r - 1]) { err = "internal: a leaf's triangle list is not ascending"; return false; }
+            }
+        }
+        if (t.rootIsLeaf) for (int r = 1; r < t.rootCount; r++) if (lr[(size_t)r] <= lr[(size_t)r - 1]) { err = "internal: a leaf's triangle list is not ascending"; return false; }
+        if (spatialRuns)
+            for (size_t bi = 0; bi < t.blocks.size() / 2; bi++) {
+                const f4 lo = t.blocks[2 * bi], hi = t.blocks[2 * bi + 1];
+                const int lref = f2i(lo.y), masks = f2i(lo.z), total = f2i(lo.w);
+                const int offw[4] = {f2i(hi.x), f2i(hi.y), f2i(hi.z), f2i(hi.w)};
+                auto off = [&](int q) { int w = offw[q >> 1]; return (q & 1) ? (int)((unsigned)w >> 16) : (w & 0xffff); };
+                for (int c = 0; c < 8; c++) {
+                    if ((masks >> c) & 1) continue;
+                    const int b0 = lref + off(c), b1 = lref + (c == 7 ? total : off(c + 1));
+                    if (b1 - b0 >= LEAF_RUN_MIN) spatial_runs(m, lr, b0, b1);
+                }
+            }
         const int blockBase = (int)(A.blocks.size() / 2);
         const int refBase = (int)A.refN.size();
         for (size_t bi = 0; bi < t.blocks.size() / 2; bi++) {   // local -> global indices
@@ -245,7 +326,7 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
                 if (!((masks >> c) & 1)) {
                     const int b0 = lref + off(c), b1 = lref + (c == 7 ? total : off(c + 1));
                     for (int r = b0; r < b1; r++) {
-                        const float *sn = &m.sn[(size_t)t.leafRefs[r] * 3];
+                        const float *sn = &m.sn[(size_t)lr[(size_t)r] * 3];
                         if (r == b0) { mn = f4{sn[0], sn[1], sn[2], 0}; mx = mn; }
                         else {
                             mn.x = sn[0] < mn.x ? sn[0] : mn.x; mn.y = sn[1] < mn.y ? sn[1] : mn.y; mn.z = sn[2] < mn.z ? sn[2] : mn.z;
@@ -261,14 +342,14 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
                 int runFirst = -1;
                 if (!((masks >> c) & 1)) {
                     const int b0 = lref + off(c), b1 = lref + (c == 7 ? total : off(c + 1));
-                    tight_box_record(m, t.leafRefs, b0, b1, leafCullSafety, rec);
+                    tight_box_record(m, lr, b0, b1, leafCullSafety, rec);
                     // ... and the same record for every run of LEAF_RUN consecutive references of a leaf of at least LEAF_RUN_MIN (the
                     // bound holds for any set of triangles): a ray that reaches the leaf's box still tests only the runs it can reach
                     if (b1 - b0 >= LEAF_RUN_MIN) {
                         runFirst = (int)(A.runTB.size() / 4);
                         for (int ra = b0; ra < b1; ra += LEAF_RUN) {
                             f4 rr[4] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
-                            tight_box_record(m, t.leafRefs, ra, ra + LEAF_RUN < b1 ? ra + LEAF_RUN : b1, leafCullSafety, rr);
+                            tight_box_record(m, lr, ra, ra + LEAF_RUN < b1 ? ra + LEAF_RUN : b1, leafCullSafety, rr);
                             for (const f4 &q : rr) A.runTB.push_back(q);
                         }
                     }
@@ -329,12 +410,12 @@ bool HostScene::build(int meshThreshold, int sceneThreshold, std::string &err) {
             }
             if (!meshAny) meshNBlo.w = 1.0f;   // (a mesh whose root is a leaf, or without triangles: no record, never culled)
         }
-        for (size_t li = 0; buildTriTB && li < t.leafRefs.size(); li++) {   // ... and the tight box of every single reference (the bound holds for any set of triangles, also for one)
+        for (size_t li = 0; buildTriTB && li < lr.size(); li++) {   // ... and the tight box of every single reference (the bound holds for any set of triangles, also for one)
             f4 rr[4] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
-            tight_box_record(m, t.leafRefs, (int)li, (int)li + 1, leafCullSafety, rr);
+            tight_box_record(m, lr, (int)li, (int)li + 1, leafCullSafety, rr);
             for (const f4 &q : rr) A.triTB.push_back(q);
         }
-        for (int tri : t.leafRefs) {   // leaf references in leaf order: normal stream + geometry stream
+        for (int tri : lr) {   // leaf references in storage order: normal stream + geometry stream
             const float *p = &m.v[(size_t)tri * 9];
             const float *sn = &m.sn[(size_t)tri * 3];
             A.refN.push_back(f4{sn[0], sn[1], sn[2], i2f(triBase + tri)});

@@ -49,6 +49,7 @@ struct HostScene {
 #else
     bool buildTriTB = false;
 #endif
+    bool spatialRuns = true;       // the references of a big leaf are stored in runs of neighbouring triangles (scene_host.cpp spatial_runs; XRT_LEAF_ORDER=0: in list order)
     double leafCullSafety = 1.0;   // factor on the tight-leaf-box margin (xrt_core.h LEAF_CULL_C): 0 switches the skip off, below 1 the bound is no longer proven (tests)
     double cullSafety = 2.0;   // factor S of the object pre-cull margin (scene_host.cpp); tests lower it to see the bound bite
 

@@ -524,7 +524,9 @@ XRT_HD void leaf_candidate(Lane &L, const SceneView &S, int r, int triId, bool p
             if (!L.mfound || L.leafKey < L.mKey) better = true;
             else if (L.leafKey == L.mKey) {
                 if (dist < L.mDist) better = true;
-                else if (dist == L.mDist) better = (L.leafNode != L.mLeaf) && (node_dfs(S, L.leafNode) < node_dfs(S, L.mLeaf));
+                // (two leaves: the earlier in DFS order; one leaf: the earlier in the reference's list, which is ascending in the triangle index -- the
+                // storage order of a big leaf is not the list order, scene_host.cpp spatial_runs)
+                else if (dist == L.mDist) better = (L.leafNode != L.mLeaf) ? (node_dfs(S, L.leafNode) < node_dfs(S, L.mLeaf)) : (f2i(S.refN[r].w) < f2i(S.refN[L.mRef].w));
                 else better = false;
             } else better = false;
             if (better) {

@@ -1964,6 +1964,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_PK_CULL_MIN")) s->packetCullMin = atoi(e);
     if (const char *e = getenv("XRT_AE")) s->noAnswerAtEmission = atoi(e) == 0;
     if (const char *e = getenv("XRT_PK_MERGE")) s->packetMerge = atoi(e) != 0;
+    if (const char *e = getenv("XRT_LEAF_ORDER")) s->hs.spatialRuns = atoi(e) != 0;   // 0: the references of big leaves in list order (tools: A/B of the storage order, results never change)
 #ifdef XRT_DEV   // (make DEV=1) the two margin factors are the only switches that can change a result: below their proven values the skips
                  // are no longer exact.  A shipped library does not read them from the environment of its host process.
     if (const char *e = getenv("XRT_LEAF_CULL")) { const double v = atof(e); if (v >= 0.0 && v <= 1e6) s->hs.leafCullSafety = v; }   // 0 = no tight leaf boxes, 1 = the proven margin
