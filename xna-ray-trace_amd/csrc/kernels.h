@@ -82,6 +82,8 @@ struct PacketArgs {
     int staticDiv = 4;            // 1/staticDiv of the packets are dealt statically (0: none)
     int grabMax = 2;              // most packets a wave takes per queue atomic
     int *flags = nullptr;         // inside a frame: hit / miss word per ray, no record for a miss (IntersectArgs::flags)
+    int prefetch = 0;             // small launches (a tile shard, a late generation): a block's children and a leaf's triangle records are asked for with one vector load each,
+                                  // a level ahead of the scalar loads that use them (packet.hip pk_prefetch) -- their walks go through parts of the tree no other wave keeps warm
     int bundle = 1;               // one-body scenes: big leaves are scanned through the bundle prefilter (packet.hip; XRT_PK_BUNDLE=0: run by run as in round 3)
     int cullMin = 4;              // leaves of at least this many references are tested against their tight box first (the test costs about two triangles)
     unsigned long long *stamps = nullptr;   // this launch's row of device-clock stamps (device_util.h), or null
@@ -111,17 +113,18 @@ struct PacketArgs {
     int splitNI = 0, splitNR = 0;      // capacities
     unsigned splitSerial = 0;          // this launch's number: the value of an item's `ready` word (the arena is never cleared)
     int splitBudget = 0, splitBudgetItem = 0;   // ticks a packet / an item may walk before it looks for pending subtrees to hand over
-    // ... and which packets are split EAGERLY: a packet remembers what it cost (ticks; a split packet keeps the larger of that and what it remembered) in
-    // splitCost[packet number], and the same packet of the context's next frame, if that is above splitLong, hands pending subtrees over every splitBudgetLong
-    // ticks from the start, as do the takers of its items.  (Waiting for a walk to PROVE long costs half of it; splitting every walk early is speculation --
-    // the far siblings of a ray that is about to find a near hit would have been pruned: measured 2-3 x the frame time, profiles/r04/split_walks.txt.)
+    // ... and which packets are split EAGERLY: a packet remembers the block entries it made (a split packet keeps the larger of that and what it remembered) in
+    // splitCost[packet number], and the same packet of the context's next frame, if that is above splitLong, hands its pending subtrees over every splitBudgetLong
+    // block entries from the start, as do the takers of its items.  (Waiting for a walk to PROVE long costs half of it; splitting every walk early is speculation --
+    // the far siblings of a ray that is about to find a near hit would have been pruned; and a cost in TICKS is contagious: the speculative work slows every packet,
+    // more of them count as long.  profiles/r04/split_walks.txt.)
     unsigned *splitCost = nullptr;
     int splitLong = 0, splitBudgetLong = 0;
 };
 constexpr int PACKET_QUEUE_HEADS = 8, PACKET_HEAD_STRIDE = 64;   // every head on a 256-byte line of its own: atomics on one line serialise whatever the word
 constexpr int PACKET_SPLIT_WORDS = 320;                          // ... and behind the heads the lines of the split-walk counters (PacketArgs::splitCtl: 9 x 128 bytes, aligned)
 constexpr int PACKET_QUEUE_WORDS = PACKET_QUEUE_HEADS * PACKET_HEAD_STRIDE + PACKET_SPLIT_WORDS;
-// an item: [0] ready (== PacketArgs::splitSerial), [1] packet, [2] record, [3] block, [4] pending children (front-to-back bits), [5..6] lanes, [7] the taker's budget, [32..95] the lanes' accepted
+// an item: [0] ready (== PacketArgs::splitSerial), [1] packet, [2] record, [3] block, [4] pending children (front-to-back bits), [5..6] lanes, [7] the taker's budget (ticks), [8] its eager interval (block entries), [32..95] the lanes' accepted
 // children of that block (cb), [96..] the lanes' best answers so far, 7 words each ([word][lane]: found, key, distance, u, v, reference, leaf) -- on the way in what the
 // giver had when it gave, on the way out what the taker has; a record: [0] units outstanding (the packet itself + its items), [1] items -- a line that only atomics
 // touch --, [32..63] their indices, [64..] the packet's own partial answers

@@ -49,6 +49,7 @@ constexpr bool PK_BUNDLE = true;
 constexpr bool PK_BUNDLE = false;
 #endif
 constexpr int PK_BUNDLE_AT = PK_SPLIT_AT + 8;    // ... and the packet's ray bundle (xrt_core.h RayBundle: 20 words) + [20] "the bundle may be used"
+constexpr bool PK_FORCE6 = true;    // (the one-body kernels are compiled for six waves per SIMD explicitly: with the prefetches in, the allocator left to itself takes 82-83 registers)
 constexpr int PK_STACK_WORDS = PK_BUNDLE_AT + 24;
 constexpr int PK_SLEVELS = 12;       // scene octree levels a packet can stack (deeper scene trees: k_intersect)
 constexpr int PK_SFRAME_WORDS = 4;   // scene block, pending children, lanes (2)
@@ -69,6 +70,7 @@ constexpr int PK_SGPRS = PK_SINGLE_WAVES >= 7 ? 96 : 112;   // SGPR allocation t
 #endif
 #ifdef XRT_PK_TICKS
 __device__ unsigned long long g_pkWorst[16];   // the packet that took longest: ticks, work item, segment, its walks / blocks / child visits / triangle steps / run tests, valid rays, packets of its launch
+__device__ unsigned g_pkDump[2 * 65536];         // per packet of the launch's first 65536: ticks, block entries (the last launch that had more than 4096 packets wins)
 __device__ unsigned long long g_pkTicks[32];   // packets by duration: bucket b counts packets of 2^b .. 2^(b+1) - 1 ticks of the 100 MHz device clock (xrt_debug_packet_ticks)
 #endif
 #ifdef XRT_PK_COUNTERS
@@ -168,6 +170,16 @@ __device__ __forceinline__ bool pk_bundle_missed(int vB, const f4 *__restrict__ 
     };
     axis(a.x, b.x, 0); axis(a.y, b.y, 1); axis(a.z, b.z, 2);
     return ok != 0.0f && tn > tf;
+}
+
+// A prefetch: an ordinary vector load whose value nobody looks at -- what it is for is the line's trip from memory into the L2 while the walk goes on.  ONE register
+// carries it: the load's destination, which the NEXT prefetch folds into its own address as an opaque zero (so that the only wait for a prefetch is at the next one,
+// long after it has arrived) and the walk's caller retires at the end.  (A load straight into LDS, global_load_lds, needs no register at all and upset the register
+// allocation of the whole kernel: 140 vector registers.)
+__device__ __forceinline__ void pk_prefetch(const char *base /* wave-uniform */, int laneOff, bool pred, int &pend) {
+    int z = pend;
+    asm volatile("v_and_b32 %0, 0, %0" : "+v"(z));
+    if (pred) pend = *reinterpret_cast<const int *>(base + (unsigned)(laneOff + z));
 }
 
 // Data that waves hand each other inside a launch (split walks): every word of it is written with an agent-scope store and read with an agent-scope load (sc1: past the
@@ -374,7 +386,7 @@ template <bool SPLIT, bool BUNDLE = PK_BUNDLE>
 __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const float *__restrict__ refT, const float *__restrict__ lrec,
                                         const SceneView &S, int cullMin, unsigned *stk, int lane, Lane &L,
                                         const RayCull &RC, bool fastL, int rootBlock, unsigned long long lanes0, bool nodeCull,
-                                        bool resume = false) {
+                                        bool resume, bool prefetch, int &pfAcc) {
 #ifdef XRT_PK_COUNTERS
     unsigned pkc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     pkc[0] = 1;
@@ -399,7 +411,7 @@ __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const
         unsigned *const ctl = a->splitCtl, *const itemsB = a->splitItems, *const recsB = a->splitRecs;
         const int NR = a->splitNR;
         const unsigned serial = a->splitSerial, xcc = xcc_id(), NIx = (unsigned)a->splitNI / 8u;
-        const unsigned myBudget = (unsigned)rfl((int)sst[2]), takerBudget = myBudget == (unsigned)a->splitBudgetLong ? myBudget : (unsigned)a->splitBudgetItem;   // (an eagerly split packet stays one)
+        const unsigned takerBudget = (unsigned)a->splitBudgetItem, takerEvery = (unsigned)rfl((int)sst[7]);   // (an eagerly split packet stays one)
         int rec = rfl((int)sst[0]);
         for (int lvl = 0; lvl < sp; lvl++) {
             const Frame4 f = *reinterpret_cast<const Frame4 *>(stk + lvl * PK_FRAME_WORDS);
@@ -428,7 +440,7 @@ __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const
             idx += xcc * NIx;
             unsigned *const I = itemsB + (size_t)idx * SPLIT_ITEM_WORDS;
             if (lane == 0) {
-                st_ag(I + 1, sst[4]); st_ag(I + 2, (unsigned)rec); st_ag(I + 3, (unsigned)rfl((int)f.a)); st_ag(I + 4, p); st_ag(I + 5, (unsigned)rfl((int)f.c)); st_ag(I + 6, (unsigned)rfl((int)f.d)); st_ag(I + 7, takerBudget);
+                st_ag(I + 1, sst[4]); st_ag(I + 2, (unsigned)rec); st_ag(I + 3, (unsigned)rfl((int)f.a)); st_ag(I + 4, p); st_ag(I + 5, (unsigned)rfl((int)f.c)); st_ag(I + 6, (unsigned)rfl((int)f.d)); st_ag(I + 7, takerBudget); st_ag(I + 8, takerEvery);
                 st_ag(R + 32 + j, idx);
                 (void)atomicAdd(R, 1u);                  // one more unit outstanding, before anybody can take it
                 atomicAdd(&g_splitStats[0], 1ull);
@@ -452,14 +464,41 @@ __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const
         const bool in = ((U.lanes >> lane) & 1ull) != 0;
         if (entering) {
             PKC(1);
-            if (SPLIT && sp > 0) {   // (wave-uniform) has this walk been going on for long?  Then let others have what is pending above
-                const unsigned budget = (unsigned)rfl((int)sst[2]);
-                if (budget != 0u && (unsigned)wall_clock64() - (unsigned)rfl((int)sst[3]) > budget) {
-                    spill();
-                    if (lane == 0) sst[3] = (unsigned)wall_clock64();
+#ifdef XRT_PK_TICKS
+            if (lane == 0) stk[PK_SPLIT_AT + 6] += 1u;   // (development: block entries of this packet, tools/pk_ticks.py --dump)
+#endif
+#ifdef XRT_PK_PRIO
+            {   // the longer a walk has been going on, the higher its wave's priority at the instruction arbiter: a launch ends when its longest packet does, and a packet
+                // of 60-80 block entries (the median makes 15) shares its SIMD with five waves that would not miss the issue slots
+                const unsigned c = (unsigned)rfl((int)stk[PK_SPLIT_AT + 5]) + 1u;
+                if (lane == 0) stk[PK_SPLIT_AT + 5] = c;
+                if (c == (unsigned)XRT_PK_PRIO) __builtin_amdgcn_s_setprio(1);
+                else if (c == 2u * XRT_PK_PRIO) __builtin_amdgcn_s_setprio(2);
+                else if (c == 3u * XRT_PK_PRIO) __builtin_amdgcn_s_setprio(3);
+            }
+#endif
+            if constexpr (SPLIT) {   // (wave-uniform) the walk's cost in block entries (what the same packet of the next frame is judged by); has it been going on for long,
+                                     // or is it a packet that was long last time (every sst[7] block entries)?  Then let others have what is pending above
+                const unsigned cnt = (unsigned)rfl((int)sst[6]) + 1u, every = (unsigned)rfl((int)sst[7]);
+                if (lane == 0) sst[6] = cnt;
+                if (sp > 0) {
+                    const unsigned budget = (unsigned)rfl((int)sst[2]);
+                    const bool late = budget != 0u && (unsigned)wall_clock64() - (unsigned)rfl((int)sst[3]) > budget;
+                    if (late || (every != 0u && cnt % every == 0u)) {
+                        spill();
+                        if (lane == 0) sst[3] = (unsigned)wall_clock64();
+                    }
                 }
             }
             B = *reinterpret_cast<const PkBlockWords *>(pblocks + (size_t)U.blk * PBLOCK_WORDS);
+            // One level ahead: the eight children's node records (1 KB in a row) and their block records are asked for with ONE vector load, so that a walk through
+            // parts of the tree no other wave has touched lately pays one trip to memory per level instead of one per record (the loads' values are never looked at:
+            // they are OR-ed into a word the walk's caller throws away).
+            if (prefetch) {   // (wave-uniform)
+                const int cb0 = f2i(B.w[0]);
+                pk_prefetch(reinterpret_cast<const char *>(lrec + (size_t)U.blk * 8 * LREC_WORDS), lane * 64, lane < 16, pfAcc);
+                pk_prefetch(reinterpret_cast<const char *>(pblocks + (size_t)cb0 * PBLOCK_WORDS), lane * 64, lane < 10, pfAcc);
+            }
             cb = 0;
             if (in) cb = fastL ? pk_hit8_fast(L.r, B) : pk_hit8_slow(L.r, B);
             cb &= 0xff & ~((f2i(B.w[2]) >> 8) & 0xff);   // empty leaves can never hit (Q4)
@@ -528,6 +567,10 @@ __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const
                 if (!__any(go)) continue;
             }
             PKC(5);
+            if (prefetch) {   // the leaf's triangle records (52 bytes each, back to back) in one vector load; see above
+                const int bytes = (r1 - r0) * TRI_REC_BYTES;
+                pk_prefetch(reinterpret_cast<const char *>(refT) + (size_t)r0 * TRI_REC_BYTES, lane * 64, lane * 64 < bytes, pfAcc);
+            }
             // A leaf of LEAF_RUN_MIN references or more is scanned run by run (LEAF_RUN references each): every run has a
             // tight box of its own and a run no lane can reach is passed over -- the octree stops splitting at 50 triangles (MO:42) and a
             // coherent packet comes near only a few of them.  Smaller leaves are one run.
@@ -690,7 +733,7 @@ template <int M> __device__ __forceinline__ unsigned *scene_frames() {
 // instruction: the one-body kernel sits at the edge of its register budget (80 vector registers for six waves per SIMD, ~80 spilled scalars), and code that merely
 // EXISTS beside the walk moved spills into its loops (measured: a frame of twice the length with the switch off).
 template <int M, bool SP>
-__global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGLE_WAVES >= 7 ? 7 : (SP ? 6 : 1))) __attribute__((amdgpu_num_sgpr(PK_SGPRS))) void k_packet(const float *__restrict__ pblocks, const float *__restrict__ refT,
+__global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGLE_WAVES >= 7 ? 7 : ((SP || PK_FORCE6) ? 6 : 1))) __attribute__((amdgpu_num_sgpr(PK_SGPRS))) void k_packet(const float *__restrict__ pblocks, const float *__restrict__ refT,
                                                 const float *__restrict__ lrec, const MeshRec *__restrict__ meshes,
                                                 const f4 *__restrict__ snodes, const f4 *__restrict__ scull, const ObjRec *__restrict__ objects,
                                                 const int *__restrict__ objMesh, SceneView S, PacketArgs A) {
@@ -819,16 +862,20 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
         }
         if (splitOn && lane == 0) {
             sst[0] = item >= 0 ? ld_ag(itemW + 2) : 0xffffffffu;
-            unsigned budget = (unsigned)KA.args()->splitBudget, pred = 0u;
-            if (item >= 0) budget = ld_ag(itemW + 7);
-            else if (KA.args()->splitCost) { pred = KA.args()->splitCost[pk]; if (pred > (unsigned)KA.args()->splitLong) budget = (unsigned)KA.args()->splitBudgetLong; }   // (what this packet cost in the context's last frame)
-            sst[1] = (unsigned)item; sst[2] = budget; sst[3] = (unsigned)wall_clock64(); sst[4] = (unsigned)pk; sst[5] = pred;
+            unsigned budget = (unsigned)KA.args()->splitBudget, pred = 0u, every = 0u;
+            if (item >= 0) { budget = ld_ag(itemW + 7); every = ld_ag(itemW + 8); }
+            else if (KA.args()->splitCost) { pred = KA.args()->splitCost[pk]; if (pred > (unsigned)KA.args()->splitLong) every = (unsigned)KA.args()->splitBudgetLong; }   // (the block entries this packet made in the context's last frame)
+            sst[1] = (unsigned)item; sst[2] = budget; sst[3] = (unsigned)wall_clock64(); sst[4] = (unsigned)pk; sst[5] = pred; sst[6] = 0u; sst[7] = every;
         }
         if (splitOn) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+#ifdef XRT_PK_PRIO
+        __builtin_amdgcn_s_setprio(0);
+        if (lane == 0) stk[PK_SPLIT_AT + 5] = 0u;
+#endif
         // ---- the packet's 64 rays ------------------------------------------------------------------------------------
         KA.fresh();
 #ifdef XRT_PK_TICKS
@@ -885,7 +932,9 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
                 if (A.bundle) pk_bundle(stk + PK_BUNDLE_AT, lane, ((lanes0 >> lane) & 1ull) != 0ull, fastL && RC.d2 > 0.0f, L.r);   // (wave-uniform switch)
                 else if (lane == 0) stk[PK_BUNDLE_AT + 20] = 0u;
             }
-            pk_walk<splitOn>(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, lanes0, nodeCull, splitOn && item >= 0);
+            int pf = 0;
+            pk_walk<splitOn>(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, lanes0, nodeCull, splitOn && item >= 0, A.prefetch != 0, pf);
+            asm volatile("" :: "v"(pf));   // (the last prefetch is retired here)
             L.mesh = mesh;
             KA.fresh();
             bool mine = true;   // this wave writes the packet's results
@@ -941,6 +990,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
         } else {
             // ---- OSM:312-455, wave-uniform: scene octree in DFS order, bodies and meshes in list order ---------------------------
             PkScene C(parkAll + wave * PK_PARK_WORDS * 64 + lane);
+            int pfScene = 0;
             unsigned *const sfr = sframesAll + wave * PK_SLEVELS * PK_SFRAME_WORDS;
             // start of the query (traverse.h lane_begin): ignoreTriangle identity (MO:290), non-finite rays take the literal box
             // tests, a NaN component means "no intersection" at once (no triangle can be accepted)
@@ -1053,7 +1103,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
                                 const bool meshAway = nodeCull && all_back_facing(f4{mr.nbMin[0], mr.nbMin[1], mr.nbMin[2], mr.nbMin[3]}, f4{mr.nbMax[0], mr.nbMax[1], mr.nbMax[2], mr.nbMax[3]}, L.r.d);
                                 const unsigned long long lanes0 = __ballot(inRoot && !meshAway);
                                 if (lanes0 != 0ull)
-                                    pk_walk<false, false>(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, lanes0, nodeCull);
+                                    pk_walk<false, false>(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, rootBlock, lanes0, nodeCull, false, false, pfScene);   // (no prefetches in scene mode: measured +-0 on C3 / C4 and their shards, and they cost the kernel 28 bytes of scratch per lane)
                             }
                             if (L.mfound) {   // OSM:370-378
                                 L.mesh = m; C.obj = o;
@@ -1081,8 +1131,12 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
             const unsigned dt = (unsigned)(wall_clock64() - tPacket);
 #ifdef XRT_PK_TICKS
             if (lane == 0) atomicAdd(&g_pkTicks[dt ? 31 - __builtin_clz(dt) : 0], 1ull);
+            if (lane == 0 && pk < 65536 && nPk > 4096 && !seg2 && g_pkDump[2 * pk] == 0u) { g_pkDump[2 * pk] = dt; g_pkDump[2 * pk + 1] = stk[PK_SPLIT_AT + 6]; }   // (the first big launch since the last dump)
+            if (lane == 0) stk[PK_SPLIT_AT + 6] = 0u;
             {
                 const unsigned long long nv = __popcll(__ballot(valid));
+                const unsigned long long nSlow = __popcll(__ballot(valid && (L.r.par != 0 || L.weird != 0)));   // lanes that take the literal box test
+                if (lane == 0 && nSlow) { atomicAdd(&g_pkWorst[11], 1ull); atomicAdd(&g_pkWorst[12], (unsigned long long)dt); }   // packets with such lanes, their ticks
                 if (lane == 0) {
 #ifdef XRT_PK_COUNTERS
                     unsigned *cur = g_pkCur + 8 * ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 65535);
@@ -1091,7 +1145,7 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
 #endif
                     if ((unsigned long long)dt > atomicMax(&g_pkWorst[0], (unsigned long long)dt)) {
                         g_pkWorst[1] = (unsigned long long)pk; g_pkWorst[2] = seg2 ? 1ull : 0ull; g_pkWorst[3] = cur[0]; g_pkWorst[4] = cur[1]; g_pkWorst[5] = cur[2];
-                        g_pkWorst[6] = cur[3]; g_pkWorst[7] = cur[4]; g_pkWorst[8] = nv; g_pkWorst[9] = (unsigned long long)nPk;
+                        g_pkWorst[6] = cur[3]; g_pkWorst[7] = cur[4]; g_pkWorst[8] = nv; g_pkWorst[9] = (unsigned long long)nPk; g_pkWorst[10] = nSlow;
                     }
                     for (int i = 0; i < 8; i++) cur[i] = 0;
                 }
@@ -1100,8 +1154,8 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
 #else
             if constexpr (splitOn) {   // what the packet cost, for the same packet of the context's next frame (kernels.h PacketArgs::splitCost): items do not write, a split packet stays long
                 if (splitOn && lane == 0 && KA.args()->splitCost && (int)sst[1] < 0) {
-                    const unsigned pred = sst[5];
-                    KA.args()->splitCost[pk] = ((int)sst[0] >= 0 && pred > dt) ? pred : dt;
+                    const unsigned pred = sst[5], mine = sst[6];
+                    KA.args()->splitCost[pk] = ((int)sst[0] >= 0 && pred > mine) ? pred : mine;
                 }
             }
             if (lane == 0 && KA.args()->tileCost) {
@@ -1148,6 +1202,12 @@ int packet_blocks_per_cu(int mode) {
 extern "C" int xrt_debug_packet_worst(unsigned long long *out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pkWorst), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pkWorst), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+extern "C" int xrt_debug_packet_dump(unsigned *out, int n) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pkDump), (size_t)n * sizeof(unsigned)) != hipSuccess) return -1;
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_pkDump)) != hipSuccess || hipMemset(p, 0, sizeof(g_pkDump)) != hipSuccess) return -1;
     return 0;
 }
 extern "C" int xrt_debug_packet_ticks(unsigned long long *out32, int reset) {

@@ -245,13 +245,15 @@ struct xrt_scene {
     bool heavyShiftGiven = false;
     bool packetMerge = true;   // the closest-hit and the shadow packets of a step share one launch (XRT_PK_MERGE=0: two launches, as round 2)
     bool noAnswerAtEmission = false;   // XRT_AE=0: k_shade emits every ray (kernels.h ShadeArgs::ae off)
+    int packetPrefetch = -1;   // XRT_PK_PREFETCH: -1 launches of fewer than packetPrefetchBelow packets per resident wave prefetch (kernels.h PacketArgs::prefetch), 0 never, 1 always
+    int packetPrefetchBelow = 12;
     bool packetBundle = true;  // XRT_PK_BUNDLE=0: no bundle prefilter (kernels.h PacketArgs::bundle)
     int packetCullMin = 4;     // XRT_PK_CULL_MIN (development): leaves with fewer references skip the tight-box test
     // Split walks (packet.hip): one-body scenes; a packet / an item that has walked for this many microseconds looks for pending subtrees to hand to other waves
     // (XRT_PK_SPLIT=0: off; XRT_PK_BUDGET / XRT_PK_BUDGET_ITEM in microseconds; XRT_PK_SPLIT_ITEMS: capacity of a frame context's arena)
     bool packetSplit = false;   // (measured: no gain yet -- profiles/r04/split_walks.txt; XRT_PK_SPLIT=1 switches the split-walk variant of the packet kernel on)
     int packetBudgetUs = 350, packetBudgetItemUs = 150, packetSplitItems = 8192;
-    int packetLongUs = 0, packetBudgetLongUs = 40;   // XRT_PK_LONG / XRT_PK_BUDGET_LONG: a packet that cost more than the first in the context's last frame hands subtrees over every <second> microseconds from the start (XRT_PK_LONG=0: no prediction)
+    int packetLongUs = 0, packetBudgetLongUs = 8;    // XRT_PK_LONG / XRT_PK_BUDGET_LONG (block entries, whatever the names say): a packet that made more than the first in the context's last frame hands subtrees over every <second> block entries from the start (XRT_PK_LONG=0: no prediction)
     unsigned splitSerial = 0;
     std::map<int, std::pair<DevBuf<unsigned>, DevBuf<unsigned>>> apiSplit;   // seam 1 (testing aid, XRT_PACKET & 8): an arena per stream
     int packetGrabMax = 2;     // XRT_PK_GRAB (development): 8 -> 2 shortened the tail of a launch (C5 blocking 9.0 -> 7.8 ms); 1 loses to contention on the queue word
@@ -985,13 +987,16 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
                             W.splitCostStride = stride;
                         }
                         PA.splitCost = W.splitCost.p + stride * (size_t)(2 * k + word);
-                        PA.splitLong = s->packetLongUs * 100; PA.splitBudgetLong = std::max(1, s->packetBudgetLongUs * 100);
+                        PA.splitLong = s->packetLongUs; PA.splitBudgetLong = std::max(1, s->packetBudgetLongUs);
                     }
                 }
                 hipEvent_t a0 = get_event(F.events, ev), a1 = get_event(F.events, ev + 1);
                 if (!a0 || !a1) return fail(XRT_E_HIP, "hipEventCreate failed");
                 int grid = s->numCUs * s->blocksPerCUPacket;
                 if (nHost >= 0) { const long long want = (nHost + 255) / 256; if (want < grid) grid = (int)(want < 1 ? 1 : want); }
+                // a small launch -- a tile shard of a frame, a late generation -- walks parts of the octree no other wave keeps warm: it prefetches (packet.hip pk_prefetch);
+                // a launch of many packets per wave has its neighbours for that and would only pay for the extra loads (C5's primary launch: +4 %)
+                PA.prefetch = s->packetPrefetch >= 0 ? s->packetPrefetch : ((nHost >= 0 && nHost / 64 < (long long)s->packetPrefetchBelow * grid * 4) ? 1 : 0);
                 if (useStamps && grid * 4 <= STAMP_SLOTS && F.stampRows < s->maxStampRows) { PA.stamps = W.stamps.p + (size_t)F.stampRows++ * STAMP_STRIDE; a0 = a1 = nullptr; }
                 else if (s->noLaunchTiming) a0 = a1 = nullptr;
                 else { pairs.push_back({ev, ev + 1}); ev += 2; }
@@ -1454,7 +1459,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->shadowBytes = s->shadowBytes; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->packetBundle = s->packetBundle; r->noAnswerAtEmission = s->noAnswerAtEmission; r->packetMerge = s->packetMerge; r->packetSplit = s->packetSplit; r->packetBudgetUs = s->packetBudgetUs; r->packetBudgetItemUs = s->packetBudgetItemUs; r->packetSplitItems = s->packetSplitItems; r->packetLongUs = s->packetLongUs; r->packetBudgetLongUs = s->packetBudgetLongUs; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->shadowBytes = s->shadowBytes; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->packetBundle = s->packetBundle; r->packetPrefetch = s->packetPrefetch; r->packetPrefetchBelow = s->packetPrefetchBelow; r->noAnswerAtEmission = s->noAnswerAtEmission; r->packetMerge = s->packetMerge; r->packetSplit = s->packetSplit; r->packetBudgetUs = s->packetBudgetUs; r->packetBudgetItemUs = s->packetBudgetItemUs; r->packetSplitItems = s->packetSplitItems; r->packetLongUs = s->packetLongUs; r->packetBudgetLongUs = s->packetBudgetLongUs; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1961,6 +1966,8 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_SPLIT_MS")) s->splitMinMs = (float)atof(e);
     if (const char *e = getenv("XRT_SPLIT_PARTS")) { const int v = atoi(e); if (v >= 2 && v <= 4) s->splitParts = v; }
     if (const char *e = getenv("XRT_PK_BUNDLE")) s->packetBundle = atoi(e) != 0;
+    if (const char *e = getenv("XRT_PK_PREFETCH")) { const int v = atoi(e); if (v >= -1 && v <= 1) s->packetPrefetch = v; }
+    if (const char *e = getenv("XRT_PK_PREFETCH_BELOW")) { const int v = atoi(e); if (v >= 0 && v <= 100000) s->packetPrefetchBelow = v; }
     if (const char *e = getenv("XRT_PK_CULL_MIN")) s->packetCullMin = atoi(e);
     if (const char *e = getenv("XRT_AE")) s->noAnswerAtEmission = atoi(e) == 0;
     if (const char *e = getenv("XRT_PK_MERGE")) s->packetMerge = atoi(e) != 0;
