@@ -49,7 +49,13 @@ constexpr bool PK_BUNDLE = true;
 constexpr bool PK_BUNDLE = false;
 #endif
 constexpr int PK_BUNDLE_AT = PK_SPLIT_AT + 8;    // ... and the packet's ray bundle (xrt_core.h RayBundle: 20 words) + [20] "the bundle may be used"
-constexpr bool PK_FORCE6 = true;    // (the one-body kernels are compiled for six waves per SIMD explicitly: with the prefetches in, the allocator left to itself takes 82-83 registers)
+// make variant NAME=pf DEFS=-DXRT_PK_PREFETCH: the prefetches of small launches (pk_prefetch below; PacketArgs::prefetch switches them per launch).  Not in the shipped kernel: merely
+// compiled in -- and switched off -- they change the register allocation of the walk (89-92 spilled scalars instead of 84-87) and cost whole C5 frames 2 % (profiles/r04/split_walks.txt).
+#ifdef XRT_PK_PREFETCH
+constexpr bool PK_PREFETCH = true, PK_FORCE6 = true;    // (compiled for six waves per SIMD explicitly: left to itself the allocator takes 82-83 registers)
+#else
+constexpr bool PK_PREFETCH = false, PK_FORCE6 = false;
+#endif
 constexpr int PK_STACK_WORDS = PK_BUNDLE_AT + 24;
 constexpr int PK_SLEVELS = 12;       // scene octree levels a packet can stack (deeper scene trees: k_intersect)
 constexpr int PK_SFRAME_WORDS = 4;   // scene block, pending children, lanes (2)
@@ -494,7 +500,7 @@ __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const
             // One level ahead: the eight children's node records (1 KB in a row) and their block records are asked for with ONE vector load, so that a walk through
             // parts of the tree no other wave has touched lately pays one trip to memory per level instead of one per record (the loads' values are never looked at:
             // they are OR-ed into a word the walk's caller throws away).
-            if (prefetch) {   // (wave-uniform)
+            if (PK_PREFETCH && prefetch) {   // (wave-uniform)
                 const int cb0 = f2i(B.w[0]);
                 pk_prefetch(reinterpret_cast<const char *>(lrec + (size_t)U.blk * 8 * LREC_WORDS), lane * 64, lane < 16, pfAcc);
                 pk_prefetch(reinterpret_cast<const char *>(pblocks + (size_t)cb0 * PBLOCK_WORDS), lane * 64, lane < 10, pfAcc);
@@ -567,7 +573,7 @@ __device__ __forceinline__ void pk_walk(const float *__restrict__ pblocks, const
                 if (!__any(go)) continue;
             }
             PKC(5);
-            if (prefetch) {   // the leaf's triangle records (52 bytes each, back to back) in one vector load; see above
+            if (PK_PREFETCH && prefetch) {   // the leaf's triangle records (52 bytes each, back to back) in one vector load; see above
                 const int bytes = (r1 - r0) * TRI_REC_BYTES;
                 pk_prefetch(reinterpret_cast<const char *>(refT) + (size_t)r0 * TRI_REC_BYTES, lane * 64, lane * 64 < bytes, pfAcc);
             }
@@ -933,8 +939,8 @@ __global__ __launch_bounds__(256, (M == MODE_SCENE) ? PK_SCENE_WAVES : (PK_SINGL
                 else if (lane == 0) stk[PK_BUNDLE_AT + 20] = 0u;
             }
             int pf = 0;
-            pk_walk<splitOn>(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, lanes0, nodeCull, splitOn && item >= 0, A.prefetch != 0, pf);
-            asm volatile("" :: "v"(pf));   // (the last prefetch is retired here)
+            pk_walk<splitOn>(pblocks, refT, lrec, S, A.cullMin, stk, lane, L, RC, fastL, mr.rootBlock, lanes0, nodeCull, splitOn && item >= 0, PK_PREFETCH && A.prefetch != 0, pf);
+            if constexpr (PK_PREFETCH) asm volatile("" :: "v"(pf));   // (the last prefetch is retired here)
             L.mesh = mesh;
             KA.fresh();
             bool mine = true;   // this wave writes the packet's results
