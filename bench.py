@@ -493,8 +493,8 @@ def roofline_block(config, alg_bytes_per_launch, ms_per_launch, launches_per_fra
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)   # (60 frames of ~4 ms: the timed region is a quarter of a second; 20 left +-2 % of noise in it)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C5", choices=list(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the image (debug only; invalid as a benchmark)")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements of the other configs")
