@@ -187,6 +187,15 @@ def test_leaf_group_quirk_and_ties_on_triangle_soups(xrt, orc, emul, n, seed, th
     assert hits_equal(o.intersect(sec), e.intersect(sec)) == {}
 
 
+def test_driver_entry_point_builds():
+    """__graft_entry__.build() is what the driver runs first: it must build (everything is up to date here) and agree with the header's ABI version."""
+    import re
+    import __graft_entry__ as g
+    pkg = g.build()
+    ver = int(re.search(r"#define XRT_VERSION (\d+)", open(os.path.join(ROOT, "include", "xrt.h")).read()).group(1))
+    assert pkg.abi.lib().xrt_version() == ver == pkg.abi.XRT_VERSION
+
+
 def test_equal_distance_ties_inside_a_leaf(xrt, orc, emul):
     """MO:293-294: of two triangles of one leaf hit at exactly the same distance the earlier in the list wins.  The device arrays store the references of a big
     leaf in runs of neighbouring triangles (scene_host.cpp spatial_runs) and the traversal settles such ties by the smaller triangle index (a leaf's list is
