@@ -938,11 +938,11 @@ def test_overlapping_frames_on_two_streams(xrt, monkeypatch):
 @pytest.mark.parametrize("env", [{"XRT_TUNE": "8,4,4,0"}, {"XRT_TUNE": "40,64,64,64"}, {"XRT_HEAVY": "0.02"}, {"XRT_HEAVY": "0.02", "XRT_NO_FEEDBACK": "1"},
                                  {"XRT_NO_RECT_CULL": "1"}, {"XRT_NO_SINGLE": "1"}, {"XRT_LONG_FRAC": "40,60"},
                                  {"XRT_NODE_CULL": "0"}, {"XRT_NODE_CULL": "2"}, {"XRT_AE": "0"}, {"XRT_AE": "0", "XRT_NODE_CULL": "2", "XRT_PACKET": "31"}, {"XRT_SPLIT": "2"},
-                                 {"XRT_PK_PREFETCH": "1", "XRT_PACKET": "31"}, {"XRT_PK_PREFETCH": "0", "XRT_PACKET": "31"}, {"XRT_LEAF_ORDER": "0", "XRT_PACKET": "31"}, {"XRT_LEAF_ORDER": "0"}])
+                                 {"XRT_PK_PREFETCH": "1", "XRT_PACKET": "31"}, {"XRT_PK_PREFETCH": "0", "XRT_PACKET": "31"}, {"XRT_LEAF_ORDER": "0", "XRT_PACKET": "31"}, {"XRT_LEAF_ORDER": "0"}, {"XRT_LEVEL_MAP": "0"}])
 def test_scheduling_switches_never_change_results(xrt, monkeypatch, env):
     """Knobs of the persistent loop, the cooperative leaf step, the long-ray list (geometric estimate and cost
     feedback), the screen-rectangle cull, the single-object mode, the normal boxes of nodes and meshes (off / rays leaving a surface / every
-    ray), answering at emission, frame bands, the prefetches of small packet launches and the storage order of big leaves are scheduling / work-avoidance only: hits of a
+    ray), answering at emission, frame bands, the prefetches of small packet launches, the storage order of big leaves and the compact level records are scheduling / work-avoidance / layout only: hits of a
     secondary-ray population and three consecutive frames (the feedback needs history) are those of the default build."""
     spec = xrt.configs.heightfield_scene(320, 180, m=96)
     scene, tracer = xrt.configs.build_product(spec)

@@ -159,6 +159,7 @@ struct ShadeArgs {
     // part B
     const SlotRec *slotPrev; const int *slotNodePrev; const int *scntPrev; const xrt_hit *shadowHits;
     f4 *lvlA, *lvlB; float *lvlAlpha;
+    LvlMap lvl;        // where a path's level records live (xrt_core.h lvl_at; P is the stride of a level)
     HeavyArgs heavy;   // for the rays of generation level+1
     unsigned *costOut = nullptr;   // cost map of generation `level` (part A writes what its rays cost), tagged with `epoch`
     unsigned epoch = 0;

@@ -602,6 +602,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
                 const bool listed = g.quadLevel > 0;   // quadrant centres come from a list, every entry is valid
                 if (!listed && !path_pixel(g, gp >> sshift, x, y)) {
                     if (!index) store_ray(rays + p, mk(0, 0, 0), mk(0, 0, 0), DEAD_RAY, -1);
+                    record = g.cullSkipsRecord == 0;   // (a path without a pixel -- the rim of an edge tile -- is treated like a pixel outside the rectangle: k_compose reads no record of it)
                 } else if (index && !listed && (x < g.cullX0 || x > g.cullX1 || y < g.cullY0 || y > g.cullY1)) {
                     record = g.cullSkipsRecord == 0;   // cannot reach the root box (RayGenParams): live stays false
                 } else {
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_raygen(RayGenParams g, SceneVi
                     if (!index) store_ray(rays + p, nearP, dir, -1, -1);
                     keepO[r] = nearP; keepD[r] = dir;   // (a culled ray is never read: it gets no place)
                 }
-                if (index && !live && record) lvlB0[p] = f4{0, 0, 0, i2f(FLAG_MISS)};   // generation 0 ends here (RT:729-733)
+                if (index && !live && record) lvlB0[lvl_at(g.lvl, p)] = f4{0, 0, 0, i2f(FLAG_MISS)};   // generation 0 ends here (RT:729-733)
             }
             const unsigned long long ml = __ballot(live), mh = __ballot(heavy);
             liveAt[r] = live ? lanes_below(ml) : -1;
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
         for (int s = tid; s < n; s += stride) {
             const SlotRec rec = X.slotPrev[s];   // left by part A of the previous step
             const int node = X.heap ? X.slotNodePrev[s] : X.level - 1;
-            const size_t at = (size_t)node * P + (size_t)rec.path;
+            const size_t at = (size_t)node * P + lvl_at(X.lvl, rec.path);
             const v3 normal = mk(rec.nx, rec.ny, rec.nz), w = mk(rec.wx, rec.wy, rec.wz);
             v3 lightResult = mk(0, 0, 0);
             for (int l = 0; l < V.nLights; l++) {
@@ -836,7 +837,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
                 X.costOut[p] = (X.epoch << 16) | (unsigned)(c > 0xffff ? 0xffff : (c < 0 ? 0 : c));
             }
             if (X.heap) { node = X.rayNode ? X.rayNode[i] : 0; curRef = X.rayRef ? X.rayRef[i] : 1.0f; }   // generation 0: root, in vacuum (RT:424)
-            if (!hit) X.lvlB[(size_t)node * P + p] = f4{0, 0, 0, i2f(FLAG_MISS)};
+            if (!hit) X.lvlB[(size_t)node * P + lvl_at(X.lvl, p)] = f4{0, 0, 0, i2f(FLAG_MISS)};
         }
         const int slot = block_append(X.scnt, hit != 0, ldsCounts);
         if (hit && slot >= X.shadowCap) { *X.overflow = 1; hit = 0; }   // more rays than the chunk's buffers hold: the host retries with fewer paths
@@ -881,7 +882,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
                     surf = mk(c.x, c.y, c.z);
                 }
                 const bool transparent = (M.flags & MAT_TRANSPARENT) != 0;
-                const size_t at = (size_t)node * P + (size_t)p;
+                const size_t at = (size_t)node * P + lvl_at(X.lvl, p);
                 X.slotOut[slot] = SlotRec{w.x, w.y, w.z, p, normal.x, normal.y, normal.z, M.reflectiveness};
                 if (X.heap) X.slotNodeOut[slot] = node;
                 X.lvlB[at] = f4{surf.x, surf.y, surf.z, i2f(FLAG_HIT | (transparent ? FLAG_TRANSPARENT : 0))};
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(APPEND_BLOCK) void k_shade(SceneView S, ShadeView V
         if (!emitNext) continue;
         if (!X.heap && X.ae) {   // chain of reflections, answered at emission: a reflection the whole mesh faces away from ends its path here
             const bool emit = hit && !faces_away_single(S, w, rdir);
-            if (hit && !emit) X.lvlB[(size_t)(X.level + 1) * P + p] = f4{0, 0, 0, i2f(FLAG_MISS)};   // what part A of the next step writes for a miss (RT:729-733)
+            if (hit && !emit) X.lvlB[(size_t)(X.level + 1) * P + lvl_at(X.lvl, p)] = f4{0, 0, 0, i2f(FLAG_MISS)};   // what part A of the next step writes for a miss (RT:729-733)
             const int pos = block_append(X.nextCnt, emit, ldsCounts);
             const bool heavy = emit && X.heavy.list && pos < X.nextCap && long_ray(S, X.heavy, p, w, rdir);
             if (emit && pos < X.nextCap) {   // (pos <= the parent's slot < cap: a guard, not a code path)
@@ -1013,9 +1014,11 @@ __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB,
             int cx, cy;
             if (path_pixel(RA.g, (RA.pixelBase + p) >> sshift, cx, cy))
                 culled = cx < RA.g.cullX0 || cx > RA.g.cullX1 || cy < RA.g.cullY0 || cy > RA.g.cullY1;
+            else culled = true;   // (a path without a pixel: no record, and nobody looks at its colour)
         }
+        const size_t lp = culled ? 0 : lvl_at(RA.g.lvl, p);   // (a culled path has no records)
         while (!culled) {
-            flag = f2i(lvlB[(size_t)kd * P + p].w);
+            flag = f2i(lvlB[(size_t)kd * P + lp].w);
             if (!(flag & FLAG_HIT) || kd == maxReflections) break;
             kd++;
         }
@@ -1023,12 +1026,12 @@ __global__ __launch_bounds__(256) void k_compose(const f4 *lvlA, const f4 *lvlB,
         uint32_t col;
         if (!(flag & FLAG_HIT)) col = pack_color(mk(0, 0, 0));   // RT:732
         else {   // RT:708-727: generation MaxReflections has no reflection term
-            f4 a = lvlA[(size_t)kd * P + p], b = lvlB[(size_t)kd * P + p];
+            f4 a = lvlA[(size_t)kd * P + lp], b = lvlB[(size_t)kd * P + lp];
             cv = mul(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z));
             col = pack_color(cv);
         }
         for (int k = kd - 1; k >= 0; k--) {   // RT:584 + RT:705
-            f4 a = lvlA[(size_t)k * P + p], b = lvlB[(size_t)k * P + p];
+            f4 a = lvlA[(size_t)k * P + lp], b = lvlB[(size_t)k * P + lp];
             cv = mul(lerp(unpack_color(col), mk(b.x, b.y, b.z), 1.0f - a.w), mk(a.x, a.y, a.z));
             col = pack_color(cv);
         }

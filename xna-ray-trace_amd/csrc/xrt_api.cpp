@@ -251,6 +251,8 @@ struct xrt_scene {
     int packetCullMin = 4;     // XRT_PK_CULL_MIN (development): leaves with fewer references skip the tight-box test
     // Split walks (packet.hip): one-body scenes; a packet / an item that has walked for this many microseconds looks for pending subtrees to hand to other waves
     // (XRT_PK_SPLIT=0: off; XRT_PK_BUDGET / XRT_PK_BUDGET_ITEM in microseconds; XRT_PK_SPLIT_ITEMS: capacity of a frame context's arena)
+    int lvlCheckedTilesX = 0; long long lvlCheckedTiles = 0;   // (LvlMap::inv verified for this frame geometry)
+    bool noLevelMap = false;   // XRT_LEVEL_MAP=0: level records for every path of the frame (as before round 4's last build)
     bool packetSplit = false;   // (measured: no gain yet -- profiles/r04/split_walks.txt; XRT_PK_SPLIT=1 switches the split-walk variant of the packet kernel on)
     int packetBudgetUs = 350, packetBudgetItemUs = 150, packetSplitItems = 8192;
     int packetLongUs = 0, packetBudgetLongUs = 8;    // XRT_PK_LONG / XRT_PK_BUDGET_LONG (block entries, whatever the names say): a packet that made more than the first in the context's last frame hands subtrees over every <second> block entries from the start (XRT_PK_LONG=0: no prediction)
@@ -722,6 +724,27 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         const long long rectPaths = (long long)std::max(0, g.cullX1 - g.cullX0 + 1) * (long long)std::max(0, g.cullY1 - g.cullY0 + 1) * g.samples + 64;
         if (rectPaths < (long long)rayCap) { rayCap = (size_t)rectPaths; F.liveCap = rayCap; }
     }
+    // ... and the two per-level records (16 bytes each per path and level: the largest arrays of a frame) exist only for the TILES that overlap the rectangle (xrt_core.h
+    // LvlMap): plain unsharded frames of one chunk and one part, whose tiles are numbered row by row.  (C5: 3.2 -> 1.7 GB per frame context.)
+    size_t lvlStride = (size_t)P;
+    std::memset(&g.lvl, 0, sizeof(g.lvl));
+    if (!heap && !adaptive && firstPaths <= chunkPaths && nParts == 1 && partStart == 0 && g.shardCount == 1 && !tabled && g.cullSkipsRecord && !s->noLevelMap &&
+        g.cullX1 >= g.cullX0 && g.cullY1 >= g.cullY0) {
+        const int shift = 9 + (g.samples == 16 ? 4 : (g.samples == 4 ? 2 : 0));
+        const int tx0 = g.cullX0 / XRT_TILE_W, tx1 = g.cullX1 / XRT_TILE_W, ty0 = g.cullY0 / XRT_TILE_H, ty1 = g.cullY1 / XRT_TILE_H;
+        const long long kept = (long long)(tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+        if (kept < totalTiles && (kept << shift) < (long long)P) {
+            g.lvl.on = 1; g.lvl.tilesX = g.tilesX; g.lvl.tx0 = tx0; g.lvl.ty0 = ty0; g.lvl.rw = tx1 - tx0 + 1; g.lvl.shift = shift;
+            g.lvl.inv = (unsigned)(((1ULL << 32) + (unsigned)g.tilesX - 1) / (unsigned)g.tilesX);
+            bool exact = totalTiles < (1LL << 24);
+            if (exact && !(s->lvlCheckedTilesX == g.tilesX && s->lvlCheckedTiles >= totalTiles)) {   // (checked once per frame geometry)
+                for (long long t = 0; exact && t < totalTiles; t++) exact = (unsigned)(((unsigned long long)t * g.lvl.inv) >> 32) == (unsigned)(t / g.tilesX);
+                if (exact) { s->lvlCheckedTilesX = g.tilesX; s->lvlCheckedTiles = totalTiles; }
+            }
+            if (exact) lvlStride = (size_t)(kept << shift);
+            else std::memset(&g.lvl, 0, sizeof(g.lvl));
+        }
+    }
     if (heap) {
         const size_t capL = (size_t)std::min<long long>(s->heapRayCap, lightBound);   // (>= 8192 >= ... see above; P <= lightBound as well)
         rayCap = (R < 20 && ((size_t)P << R) < capL) ? ((size_t)P << R) : capL;
@@ -736,8 +759,8 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
         (rc = W.path1.ensure(rayCap)) || (rc = W.hitFlags0.ensure(rayCap)) ||
         (rc = W.shadowFlags.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = W.slot0.ensure(rayCap)) ||
         (rc = W.slot1.ensure(rayCap)) || (rc = W.index0.ensure(rayCap)) || (rc = W.heavyList.ensure(rayCap)) || (rc = W.shadowRays.ensure(rayCap * (nL > 0 ? nL : 1))) ||
-        (rc = W.shadowHits.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = W.lvlA.ensure((size_t)P * nodes)) ||
-        (rc = W.lvlB.ensure((size_t)P * nodes)) || (rc = W.sampleColor.ensure(P)) || (rc = W.lights.ensure(nL > 0 ? nL : 1)) ||
+        (rc = W.shadowHits.ensure(rayCap * (nL > 0 ? nL : 1))) || (rc = W.lvlA.ensure(lvlStride * nodes)) ||
+        (rc = W.lvlB.ensure(lvlStride * nodes)) || (rc = W.sampleColor.ensure(P)) || (rc = W.lights.ensure(nL > 0 ? nL : 1)) ||
         (rc = s->counters.ensure(2 * C_COUNT + 8)))
         return rc;
     if (!s->waveTimesPath.empty() && !s->waveTimes.p) {
@@ -1032,7 +1055,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             ShadeArgs X;
             std::memset(&X, 0, sizeof(X));
             X.level = k; X.doA = hasClosest ? 1 : 0; X.doB = k >= 1 ? 1 : 0;
-            X.maxReflections = R; X.P = P; X.heap = heap ? 1 : 0; X.overflow = overflowFlag;
+            X.maxReflections = R; X.P = (int)lvlStride; X.lvl = gp.lvl; X.heap = heap ? 1 : 0; X.overflow = overflowFlag;
             X.rays = rays[cur]; X.hits = hitsOf[cur]; X.hitFlags = flagsOf[cur]; X.shadowFlags = shadowFlagsOf[(k + 1) & 1]; X.nDev = nClosest; X.nHost = Pc; X.cap = (int)rayCap;
             X.index = nullptr; X.rayPath = k == 0 ? W.index0.p : paths[cur];   // (generation 0: the j-th live ray belongs to path index0[j])
             X.rayNode = (heap && k > 0) ? nodesOf[cur] : nullptr; X.rayRef = (heap && k > 0) ? refOf[cur] : nullptr;
@@ -1064,7 +1087,7 @@ int frame_begin(xrt_scene *s, xrt_scene::FrameCtx &F, const xrt_camera *cam, con
             RA.stamps = fold;
             if (epi) { RA.cntSrc = epi->cntSrc; RA.hostCnt = epi->hostCnt; RA.cntWords = epi->cntWords; RA.zeroWords = epi->zeroWords; RA.zeroFrom = epi->zeroFrom; }
             else if (fast && !adaptive) { RA.cntSrc = cnt; RA.hostCnt = F.pinnedDev; RA.cntWords = cntStride; RA.zeroWords = cntStride + qStride; }
-            launch_compose(W.lvlA.p, W.lvlB.p, Pc, P, R, sampleOut ? sampleOut : W.sampleColor.p, (wantF32 && !fuseResolve) ? W.sampleF32.p : nullptr, RA, st,
+            launch_compose(W.lvlA.p, W.lvlB.p, Pc, (int)lvlStride, R, sampleOut ? sampleOut : W.sampleColor.p, (wantF32 && !fuseResolve) ? W.sampleF32.p : nullptr, RA, st,
                            (fast && fuseResolve) ? e1 : nullptr);
         }
         return XRT_OK;
@@ -1459,7 +1482,7 @@ int ensure_replicas(xrt_scene *s, int n) {
         r->device = s->fakeGpus ? s->device : s->device + i;
         r->host = s->host;
         r->noRectCull = s->noRectCull; r->oneStream = s->oneStream; r->noFeedback = s->noFeedback; r->overlapMinMs = s->overlapMinMs;
-        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->shadowBytes = s->shadowBytes; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->packetBundle = s->packetBundle; r->packetPrefetch = s->packetPrefetch; r->packetPrefetchBelow = s->packetPrefetchBelow; r->noAnswerAtEmission = s->noAnswerAtEmission; r->packetMerge = s->packetMerge; r->packetSplit = s->packetSplit; r->packetBudgetUs = s->packetBudgetUs; r->packetBudgetItemUs = s->packetBudgetItemUs; r->packetSplitItems = s->packetSplitItems; r->packetLongUs = s->packetLongUs; r->packetBudgetLongUs = s->packetBudgetLongUs; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
+        r->heapRayCap = s->heapRayCap; r->maxChunkPaths = s->maxChunkPaths; r->shadowBytes = s->shadowBytes; r->packetMask = s->packetMask; r->packetMaskHeap = s->packetMaskHeap; r->packetCullMin = s->packetCullMin; r->packetBundle = s->packetBundle; r->packetPrefetch = s->packetPrefetch; r->packetPrefetchBelow = s->packetPrefetchBelow; r->noAnswerAtEmission = s->noAnswerAtEmission; r->packetMerge = s->packetMerge; r->packetSplit = s->packetSplit; r->noLevelMap = s->noLevelMap; r->packetBudgetUs = s->packetBudgetUs; r->packetBudgetItemUs = s->packetBudgetItemUs; r->packetSplitItems = s->packetSplitItems; r->packetLongUs = s->packetLongUs; r->packetBudgetLongUs = s->packetBudgetLongUs; r->batchMax = s->batchMax; r->heavyShift = s->heavyShift; r->heavyShiftGiven = s->heavyShiftGiven; r->batchMin = s->batchMin; r->spreadMin = s->spreadMin; r->tuneGiven = s->tuneGiven;
         for (int k = 0; k < 4; k++) r->tune[k] = s->tune[k];
         HIPCHECK(hipSetDevice(r->device));
         hipDeviceProp_t prop;
@@ -1946,6 +1969,7 @@ int xrt_scene_create(int device, xrt_scene **scene_out) {
     if (const char *e = getenv("XRT_HEAVY_SHIFT")) { const int v = atoi(e); if (v >= 0 && v <= 6) { s->heavyShift = v; s->heavyShiftGiven = true; } }
     if (const char *e = getenv("XRT_BATCH_MAX")) { const int v = atoi(e); if (v >= 16 && v <= 4096 && v % 16 == 0) s->batchMax = v; }
     if (const char *e = getenv("XRT_PK_SPLIT")) s->packetSplit = atoi(e) != 0;
+    if (const char *e = getenv("XRT_LEVEL_MAP")) s->noLevelMap = atoi(e) == 0;
     if (const char *e = getenv("XRT_PK_BUDGET")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) s->packetBudgetUs = v; }   // (0: a walk looks for pending subtrees at every block it enters)
     if (const char *e = getenv("XRT_PK_BUDGET_ITEM")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) s->packetBudgetItemUs = v; }
     if (const char *e = getenv("XRT_PK_LONG")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) s->packetLongUs = v; }

@@ -433,6 +433,20 @@ inline void mat_invert(const float *m, float *r) {   // Matrix.Invert
 // Per-frame ray-generation constants: Viewport.Unproject inverts world*view*proj on every call
 // (RT:415,419) — the same matrix for every pixel, so it is computed once on the host with the same
 // arithmetic and handed to the kernel.
+// Where the level records of path p live (lvlA / lvlB [level * stride + lvl_at(p)]).  Plain unsharded frames keep records only for the TILES that overlap the screen rectangle of
+// the scene's root box (RayGenParams::cull*): no other path ever writes or reads one (k_raygen answers those pixels, k_compose knows the rectangle), and on C5 the rectangle
+// is half the image -- 1.5 GB of 3.2 per frame context.  Tiles are numbered row by row over the frame (tile = path >> shift), the kept ones row by row over their own grid.
+struct LvlMap {
+    int on;               // 0: lvl_at(p) = p
+    int tilesX, tx0, ty0, rw, shift;
+    unsigned inv;         // ceil(2^32 / tilesX): tile / tilesX == (tile * inv) >> 32 for every tile of the frame (checked on the host)
+};
+XRT_HD size_t lvl_at(const LvlMap &m, int p) {
+    if (!m.on) return (size_t)p;
+    const unsigned t = (unsigned)p >> m.shift, within = (unsigned)p & ((1u << m.shift) - 1u);
+    const unsigned ty = (unsigned)(((unsigned long long)t * m.inv) >> 32), tx = t - ty * (unsigned)m.tilesX;
+    return ((size_t)((ty - (unsigned)m.ty0) * (unsigned)m.rw + (tx - (unsigned)m.tx0)) << m.shift) + within;
+}
 struct RayGenParams {
     float m[16];          // Invert(Multiply(Multiply(Identity, view), proj))
     float vpX, vpY, vpW, vpH, minDepth, depthRange;
@@ -449,6 +463,7 @@ struct RayGenParams {
     // (OSM:318-320) without building their rays.
     int   cullX0, cullY0, cullX1, cullY1;
     int   cullSkipsRecord;         // k_compose knows the rectangle too: no generation-0 record is written or read for those pixels
+    LvlMap lvl;                    // ... and the level records exist for the rectangle's tiles only (above)
     // A pass whose size only the device knows (the deeper quadrant levels of an adaptive frame in flight): the pass has
     // min(*pathsDev, pathsCap) * pathsMul paths; null: the host's count
     const int *pathsDev;
